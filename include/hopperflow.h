@@ -1,0 +1,160 @@
+/* include/hopperflow.h -- C ABI of the MI355X-native optical-flow frame interpolator.
+ *
+ * This is the drop-in boundary for ONE hot path of HopperLogger/HopperRender: the
+ * OpticalFlowCalc{SDR,HDR} calculator (reference HopperRender/opticalFlowCalc.h:24-138 and
+ * opticalFlowCalc{SDR,HDR}.cpp).  The reference's filter talks to that path through a C++
+ * class; include/opticalFlowCalc.h re-creates that class source-compatibly ON TOP of this C
+ * ABI, and any other host language binds these symbols directly.
+ *
+ * Conventions: plain C types only; every call returns 0 on success or a negative hf_status;
+ * nothing throws; hf_last_error() returns a human-readable string for the last failure of
+ * that context (or of hf_create when ctx == NULL).  Strides are in ELEMENTS (uint8 for NV12,
+ * uint16 for P010), exactly like the reference (opticalFlowCalcHDR.cpp:20,279-282).
+ * One context = one GPU + one HIP stream; a context is not thread-safe (reference: one object
+ * per filter instance); contexts are independent of each other, also
+ * on the same device, which is how independent frame pairs are batched and sharded.
+ *
+ * All file:line citations are relative to the reference's HopperRender/ directory.
+ */
+#ifndef HOPPERFLOW_H
+#define HOPPERFLOW_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HF_ABI_VERSION 1
+
+typedef struct hf_ctx hf_ctx;
+
+typedef enum hf_status {
+    HF_OK = 0,
+    HF_ERR_INVALID_ARGUMENT = -1, /* bad config / NULL pointer / blending scalar > 1 (opticalFlowCalcSDR.cpp:143-146) */
+    HF_ERR_NO_DEVICE = -2,        /* no HIP device satisfies the request (reference: detectDevices throws, opticalFlowCalc.cpp:97-109) */
+    HF_ERR_OUT_OF_MEMORY = -3,
+    HF_ERR_HIP = -4,              /* a HIP runtime call failed (reference: CHECK_ERROR, opticalFlowCalc.h:15-22) */
+    HF_ERR_STATE = -5             /* call made in a state the reference would have mis-rendered (e.g. warp before any flow) */
+} hf_status;
+
+/* Frame output modes of warpFrames (reference HopperRender.h:10-18, warpFrameKernelSDR.h:133-183). */
+typedef enum hf_output_mode {
+    HF_MODE_WARPED_FRAME_12 = 0,
+    HF_MODE_WARPED_FRAME_21 = 1,
+    HF_MODE_BLENDED_FRAME = 2,
+    HF_MODE_HSV_FLOW = 3,
+    HF_MODE_GREY_FLOW = 4,
+    HF_MODE_SIDE_BY_SIDE_1 = 5,
+    HF_MODE_SIDE_BY_SIDE_2 = 6
+} hf_output_mode;
+
+#define HF_FLAG_ASYNC 0x1 /* calls only enqueue; results/timings valid after hf_sync(). Default: every
+                             call blocks like the reference (CL_TRUE transfers, clWaitForEvents). */
+#define HF_FLAG_NO_GRAPH 0x2 /* launch the flow chain eagerly instead of replaying a hipGraph (debug) */
+
+/* The nine constructor arguments of OpticalFlowCalcSDR/HDR (opticalFlowCalcSDR.cpp:206-208)
+ * plus build-side extensions (0 selects the reference behaviour for each). */
+typedef struct hf_config {
+    uint32_t struct_size;   /* = sizeof(hf_config), for ABI evolution */
+    int32_t is_hdr;         /* 0: NV12 8-bit (OpticalFlowCalcSDR), 1: P010 16-bit (OpticalFlowCalcHDR) */
+    int32_t frame_height;   /* ctor arg 1 */
+    int32_t frame_width;    /* ctor arg 2 */
+    int32_t input_stride;   /* ctor arg 3, elements; <= 0 -> frame_width (:212) */
+    int32_t output_stride;  /* ctor arg 4, elements; <= 0 -> frame_width (:213) */
+    int32_t delta_scalar;   /* ctor arg 5, config.h:23 default 8 */
+    int32_t neighbor_scalar;/* ctor arg 6, config.h:24 default 6 */
+    float black_level;      /* ctor arg 7, 0..255 */
+    float white_level;      /* ctor arg 8, 0..255 */
+    int32_t max_calc_res;   /* ctor arg 9, config.h:4 default 270 */
+    /* --- extensions --- */
+    int32_t device_index;   /* HIP device ordinal (reference: first suitable OpenCL device) */
+    int32_t iterations;     /* NUM_ITERATIONS (config.h:6) made runtime; 0 = auto */
+    int32_t blur_radius;    /* KERNEL_RADIUS (blurFlowKernelSDR.h:4) made runtime; 0 -> 4 */
+    int32_t search_radius;  /* initial m_opticalFlowSearchRadius; 0 -> MIN_SEARCH_RADIUS 5 (:216) */
+    uint32_t flags;         /* HF_FLAG_* */
+} hf_config;
+
+/* The public fields the filter reads/writes on the calculator (opticalFlowCalc.h:27-48). */
+typedef struct hf_params {
+    int32_t delta_scalar;    /* m_deltaScalar           (r/w by the settings thread, HopperRender.cpp:1385-1390) */
+    int32_t neighbor_scalar; /* m_neighborBiasScalar */
+    float black_level;       /* m_outputBlackLevel */
+    float white_level;       /* m_outputWhiteLevel */
+    int32_t search_radius;   /* m_opticalFlowSearchRadius, 5..16 (governor, HopperRender.cpp:1438-1463) */
+    uint32_t frame_count;    /* m_frameCount (NewSegment zeroes it, HopperRender.cpp:840) */
+} hf_params;
+
+typedef struct hf_stats {
+    uint32_t total_frame_delta; /* m_totalFrameDelta (bug-compatible, opticalFlowCalcSDR.cpp:91-94) */
+    uint32_t frame_count;       /* m_frameCount */
+    double ofc_calc_time;       /* m_ofcCalcTime: upload start -> blur end, seconds (:125-127) */
+    double ofc_avg_calc_time;   /* m_ofcAvgCalcTime (:128-133) */
+    double ofc_peak_calc_time;  /* m_ofcPeakCalcTime (:131,136-138) */
+    double warp_calc_time;      /* m_warpCalcTime: first warp/copy launch -> readback end (:36-41) */
+    int32_t res_scalar;         /* m_opticalFlowResScalar */
+    int32_t low_width;          /* m_opticalFlowFrameWidth */
+    int32_t low_height;         /* m_opticalFlowFrameHeight */
+    int32_t frame_width, frame_height, input_stride, output_stride;
+    int32_t iterations;         /* effective refinement iterations of the last flow calc */
+    int32_t initial_window;     /* first window size (opticalFlowCalcSDR.cpp:49-59) */
+    uint64_t input_frame_bytes; /* bytes updateFrame reads  = bpp*(H*S_in + (H/2)*S_in)  (:20) */
+    uint64_t output_frame_bytes;/* bytes downloadFrame writes = bpp*(H*S_out + (H/2)*S_out) (:33) */
+} hf_stats;
+
+/* ---- lifecycle: constructor / destructor (opticalFlowCalcSDR.cpp:206-325, :185-204) ---- */
+int hf_create(const hf_config* cfg, hf_ctx** out_ctx);
+void hf_destroy(hf_ctx* ctx);
+const char* hf_last_error(const hf_ctx* ctx);
+int hf_abi_version(void);
+
+/* ---- the five virtuals of OpticalFlowCalc (opticalFlowCalc.h:100-132) ---- */
+/* updateFrame (opticalFlowCalcSDR.cpp:19-29): upload one NV12/P010 frame, rotate the 3-frame ring, frame_count++ */
+int hf_update_frame(hf_ctx* ctx, const void* host_frame);
+/* calculateOpticalFlow (opticalFlowCalcSDR.cpp:44-139): flow between ring[1] (N-1) and ring[2] (N) */
+int hf_calculate_optical_flow(hf_ctx* ctx);
+/* warpFrames (opticalFlowCalcSDR.cpp:141-168): blending_scalar in [.., 1], mode = hf_output_mode */
+int hf_warp_frames(hf_ctx* ctx, float blending_scalar, int frame_output_mode);
+/* copyFrame (opticalFlowCalcSDR.cpp:170-183) */
+int hf_copy_frame(hf_ctx* ctx);
+/* downloadFrame (opticalFlowCalcSDR.cpp:31-42): blocking readback of the output frame */
+int hf_download_frame(hf_ctx* ctx, void* host_out);
+
+/* ---- public-field access ---- */
+int hf_get_params(const hf_ctx* ctx, hf_params* out);
+int hf_set_params(hf_ctx* ctx, const hf_params* in);
+int hf_get_stats(hf_ctx* ctx, hf_stats* out);
+
+/* ---- device-resident variants (batch driver / benchmarks: inputs and outputs stay in HBM) ---- */
+/* Same as hf_update_frame but the source is a device pointer on ctx's device (device-to-device). */
+int hf_update_frame_device(hf_ctx* ctx, const void* device_frame);
+/* Device-to-device copy of the output frame into caller-owned device memory. */
+int hf_download_frame_device(hf_ctx* ctx, void* device_out);
+/* Redirect warp/copy output into caller-owned device memory (NULL restores the internal buffer). */
+int hf_set_output_buffer(hf_ctx* ctx, void* device_out);
+/* Block until everything enqueued on ctx's stream has finished; finalises timings/total_frame_delta. */
+int hf_sync(hf_ctx* ctx);
+
+/* ---- parity / debugging taps on the reference's device buffers ---- */
+/* m_offsetArray: int16 [2][low_h][low_w] (raw flow of the last calc) */
+int hf_read_offsets(hf_ctx* ctx, int16_t* host_out);
+/* m_blurredOffsetArray[idx]: idx 0 = flow consumed by warpFrames, 1 = newest (opticalFlowCalcSDR.cpp:121-123) */
+int hf_read_blurred_flow(hf_ctx* ctx, int idx, int16_t* host_out);
+int hf_write_blurred_flow(hf_ctx* ctx, int idx, const int16_t* host_in);
+
+/* ---- measurement: HIP events on ctx's own stream (torch events cannot see this stream) ---- */
+int hf_timer_begin(hf_ctx* ctx);
+int hf_timer_end(hf_ctx* ctx, float* elapsed_ms); /* synchronises on the end event */
+
+/* ---- plain device-memory helpers so non-HIP hosts (ctypes, cgo, JNI) can stage frames ---- */
+int hf_device_count(void);
+int hf_device_malloc(int device_index, size_t bytes, void** out_dev_ptr);
+int hf_device_free(int device_index, void* dev_ptr);
+int hf_memcpy_h2d(int device_index, void* dev_dst, const void* host_src, size_t bytes);
+int hf_memcpy_d2h(int device_index, void* host_dst, const void* dev_src, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HOPPERFLOW_H */
