@@ -1,0 +1,77 @@
+"""Builds the native libraries IN-TREE (so the .so files travel with the repo snapshot).
+
+    libhopperflow.so       HIP kernels + C ABI (include/hopperflow.h)        hipcc, gfx950 only
+    libopticalflowcalc.so  source-compatible C++ adapter (include/opticalFlowCalc.h)   g++
+
+`python -m hopperrender_amd.build` or hopperrender_amd.build.build_all().  hipcc cross-compiles
+without a GPU.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIBDIR = os.path.join(PKG, "lib")
+INCLUDE = os.path.join(ROOT, "include")
+
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+             "-Wall", "-Wno-unused-function"]
+
+LIB_FLOW = os.path.join(LIBDIR, "libhopperflow.so")
+LIB_ADAPTER = os.path.join(LIBDIR, "libopticalflowcalc.so")
+
+
+def _stale(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(" ".join(cmd) + "\n" + r.stdout[-4000:] + r.stderr[-8000:])
+        raise RuntimeError("native build failed")
+    return r
+
+
+def build_flow(force=False):
+    os.makedirs(LIBDIR, exist_ok=True)
+    srcs = [os.path.join(CSRC, f) for f in ("hf_kernels.hip", "hf_capi.hip")]
+    deps = srcs + [os.path.join(CSRC, "hf_kernels.h"), os.path.join(INCLUDE, "hopperflow.h")]
+    if force or _stale(LIB_FLOW, deps):
+        objs = []
+        for s in srcs:
+            o = os.path.join(LIBDIR, os.path.basename(s) + ".o")
+            _run([HIPCC] + HIP_FLAGS + ["-I", INCLUDE, "-c", s, "-o", o])
+            objs.append(o)
+        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_FLOW] + objs +
+             ["-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined"])
+    return LIB_FLOW
+
+
+def build_adapter(force=False):
+    src = os.path.join(CSRC, "opticalFlowCalc.cpp")
+    if not os.path.exists(src):
+        return None
+    deps = [src, os.path.join(INCLUDE, "opticalFlowCalc.h"), os.path.join(INCLUDE, "hopperflow.h")]
+    if force or _stale(LIB_ADAPTER, deps + [LIB_FLOW]):
+        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", "-I", INCLUDE, src, "-o", LIB_ADAPTER,
+              "-L", LIBDIR, "-lhopperflow", "-Wl,-rpath,$ORIGIN", "-Wl,--no-undefined"])
+    return LIB_ADAPTER
+
+
+def build_all(force=False):
+    build_flow(force)
+    build_adapter(force)
+    return LIB_FLOW
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv)
+    print(LIB_FLOW)

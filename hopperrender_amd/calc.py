@@ -1,0 +1,222 @@
+"""Python mirror of the reference's OpticalFlowCalc interface (reference HopperRender/
+opticalFlowCalc.h:24-138, opticalFlowCalcSDR.h:10-56, opticalFlowCalcHDR.h:10-56) on the C ABI.
+
+Same constructor arguments, same method names (updateFrame / downloadFrame / calculateOpticalFlow /
+warpFrames / copyFrame) and the same public field names (m_*), so tests read like calls made by the
+reference's filter (HopperRender.cpp:907-1189).  `init` and `blendFrames` are the aliases
+BASELINE.json's north_star uses for the constructor body and warpFrames(t, 2).
+Errors surface as HopperFlowError (reference: std::runtime_error).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+BlendedFrame = 2  # HopperRender.h:10-18
+WarpedFrame12, WarpedFrame21, HSVFlow, GreyFlow, SideBySide1, SideBySide2 = 0, 1, 3, 4, 5, 6
+
+
+def _ptr(a):
+    if isinstance(a, np.ndarray):
+        if not a.flags["C_CONTIGUOUS"]:
+            raise ValueError("frame buffers must be C-contiguous")
+        return a.ctypes.data_as(C.c_void_p)
+    return C.c_void_p(a)
+
+
+class OpticalFlowCalc:
+    """Abstract base in the reference; here the shared implementation (is_hdr set by subclasses)."""
+
+    is_hdr = False
+
+    def __init__(self, frameHeight, frameWidth, inputStride=0, outputStride=0, deltaScalar=8, neighborScalar=6,
+                 blackLevel=0.0, whiteLevel=255.0, maxCalcRes=270, *, device_index=0, iterations=0, blur_radius=0,
+                 search_radius=0, flags=0):
+        self._lib = capi.load()
+        self._ctx = C.c_void_p()
+        self.init(frameHeight, frameWidth, inputStride, outputStride, deltaScalar, neighborScalar, blackLevel,
+                  whiteLevel, maxCalcRes, device_index=device_index, iterations=iterations, blur_radius=blur_radius,
+                  search_radius=search_radius, flags=flags)
+
+    def init(self, frameHeight, frameWidth, inputStride, outputStride, deltaScalar, neighborScalar, blackLevel,
+             whiteLevel, maxCalcRes, *, device_index=0, iterations=0, blur_radius=0, search_radius=0, flags=0):
+        """Constructor body (opticalFlowCalcSDR.cpp:206-325)."""
+        if self._ctx:
+            self._lib.hf_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+        cfg = capi.HfConfig(C.sizeof(capi.HfConfig), int(self.is_hdr), frameHeight, frameWidth, inputStride, outputStride,
+                            deltaScalar, neighborScalar, blackLevel, whiteLevel, maxCalcRes, device_index, iterations,
+                            blur_radius, search_radius, flags)
+        capi.check(self._lib.hf_create(C.byref(cfg), C.byref(self._ctx)))
+        self.device_index = device_index
+        st = self._stats()
+        self.m_frameWidth, self.m_frameHeight = st.frame_width, st.frame_height
+        self.m_inputStride, self.m_outputStride = st.input_stride, st.output_stride
+        self.m_opticalFlowResScalar = st.res_scalar
+        self.m_opticalFlowFrameWidth, self.m_opticalFlowFrameHeight = st.low_width, st.low_height
+        self.input_frame_bytes, self.output_frame_bytes = st.input_frame_bytes, st.output_frame_bytes
+        self.dtype = np.uint16 if self.is_hdr else np.uint8
+
+    # ---- public fields of the reference object, backed by the context ----
+    def _params(self):
+        p = capi.HfParams()
+        capi.check(self._lib.hf_get_params(self._ctx, C.byref(p)), self._ctx)
+        return p
+
+    def _set(self, **kw):
+        p = self._params()
+        for k, v in kw.items():
+            setattr(p, k, v)
+        capi.check(self._lib.hf_set_params(self._ctx, C.byref(p)), self._ctx)
+
+    def _stats(self):
+        s = capi.HfStats()
+        capi.check(self._lib.hf_get_stats(self._ctx, C.byref(s)), self._ctx)
+        return s
+
+    m_deltaScalar = property(lambda s: s._params().delta_scalar, lambda s, v: s._set(delta_scalar=int(v)))
+    m_neighborBiasScalar = property(lambda s: s._params().neighbor_scalar, lambda s, v: s._set(neighbor_scalar=int(v)))
+    m_outputBlackLevel = property(lambda s: s._params().black_level, lambda s, v: s._set(black_level=float(v)))
+    m_outputWhiteLevel = property(lambda s: s._params().white_level, lambda s, v: s._set(white_level=float(v)))
+    m_opticalFlowSearchRadius = property(lambda s: s._params().search_radius, lambda s, v: s._set(search_radius=int(v)))
+    m_frameCount = property(lambda s: s._params().frame_count, lambda s, v: s._set(frame_count=int(v)))
+    m_totalFrameDelta = property(lambda s: s._stats().total_frame_delta)
+    m_ofcCalcTime = property(lambda s: s._stats().ofc_calc_time)
+    m_ofcAvgCalcTime = property(lambda s: s._stats().ofc_avg_calc_time)
+    m_ofcPeakCalcTime = property(lambda s: s._stats().ofc_peak_calc_time)
+    m_warpCalcTime = property(lambda s: s._stats().warp_calc_time)
+
+    # ---- the five virtuals ----
+    def updateFrame(self, inputPlanes):
+        """opticalFlowCalcSDR.cpp:19-29.  inputPlanes: host ndarray (NV12 uint8 / P010 uint16)."""
+        a = np.ascontiguousarray(inputPlanes)
+        if a.nbytes < self.input_frame_bytes:
+            raise ValueError(f"input frame has {a.nbytes} bytes, need {self.input_frame_bytes}")
+        capi.check(self._lib.hf_update_frame(self._ctx, _ptr(a)), self._ctx)
+
+    def downloadFrame(self, outputPlanes=None):
+        """opticalFlowCalcSDR.cpp:31-42.  Returns the flat output frame (allocated if not given)."""
+        if outputPlanes is None:
+            outputPlanes = np.empty(self.output_frame_bytes // np.dtype(self.dtype).itemsize, dtype=self.dtype)
+        if outputPlanes.nbytes < self.output_frame_bytes:
+            raise ValueError("output buffer too small")
+        capi.check(self._lib.hf_download_frame(self._ctx, _ptr(outputPlanes)), self._ctx)
+        return outputPlanes
+
+    def calculateOpticalFlow(self):
+        """opticalFlowCalcSDR.cpp:44-139."""
+        capi.check(self._lib.hf_calculate_optical_flow(self._ctx), self._ctx)
+
+    def warpFrames(self, blendingScalar, frameOutputMode):
+        """opticalFlowCalcSDR.cpp:141-168."""
+        capi.check(self._lib.hf_warp_frames(self._ctx, float(blendingScalar), int(frameOutputMode)), self._ctx)
+
+    def blendFrames(self, blendingScalar):
+        self.warpFrames(blendingScalar, BlendedFrame)
+
+    def copyFrame(self):
+        """opticalFlowCalcSDR.cpp:170-183."""
+        capi.check(self._lib.hf_copy_frame(self._ctx), self._ctx)
+
+    # ---- device-resident / async extensions ----
+    def updateFrameDevice(self, dev_ptr):
+        capi.check(self._lib.hf_update_frame_device(self._ctx, C.c_void_p(dev_ptr)), self._ctx)
+
+    def downloadFrameDevice(self, dev_ptr):
+        capi.check(self._lib.hf_download_frame_device(self._ctx, C.c_void_p(dev_ptr)), self._ctx)
+
+    def setOutputBuffer(self, dev_ptr):
+        capi.check(self._lib.hf_set_output_buffer(self._ctx, C.c_void_p(dev_ptr or 0)), self._ctx)
+
+    def sync(self):
+        capi.check(self._lib.hf_sync(self._ctx), self._ctx)
+
+    def timerBegin(self):
+        capi.check(self._lib.hf_timer_begin(self._ctx), self._ctx)
+
+    def timerEnd(self):
+        ms = C.c_float()
+        capi.check(self._lib.hf_timer_end(self._ctx, C.byref(ms)), self._ctx)
+        return ms.value
+
+    # ---- parity taps ----
+    def readOffsets(self):
+        a = np.empty((2, self.m_opticalFlowFrameHeight, self.m_opticalFlowFrameWidth), dtype=np.int16)
+        capi.check(self._lib.hf_read_offsets(self._ctx, _ptr(a)), self._ctx)
+        return a
+
+    def readBlurredFlow(self, idx):
+        a = np.empty((2, self.m_opticalFlowFrameHeight, self.m_opticalFlowFrameWidth), dtype=np.int16)
+        capi.check(self._lib.hf_read_blurred_flow(self._ctx, idx, _ptr(a)), self._ctx)
+        return a
+
+    def writeBlurredFlow(self, idx, flow):
+        a = np.ascontiguousarray(flow, dtype=np.int16)
+        assert a.shape == (2, self.m_opticalFlowFrameHeight, self.m_opticalFlowFrameWidth)
+        capi.check(self._lib.hf_write_blurred_flow(self._ctx, idx, _ptr(a)), self._ctx)
+
+    def deviceRcp(self, values):
+        x = np.ascontiguousarray(values, dtype=np.float32)
+        y = np.empty_like(x)
+        capi.check(self._lib.hf_device_rcp(self._ctx, _ptr(x), _ptr(y), len(x)), self._ctx)
+        return y
+
+    def stats(self):
+        s = self._stats()
+        return {k: getattr(s, k) for k, _ in s._fields_}
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.hf_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class OpticalFlowCalcSDR(OpticalFlowCalc):
+    """NV12, 8-bit (opticalFlowCalcSDR.h:10-56)."""
+    is_hdr = False
+
+
+class OpticalFlowCalcHDR(OpticalFlowCalc):
+    """P010, 16-bit (opticalFlowCalcHDR.h:10-56)."""
+    is_hdr = True
+
+
+class DeviceBuffer:
+    """A plain hipMalloc'ed buffer through the C ABI helpers (bench / batch staging)."""
+
+    def __init__(self, nbytes, device_index=0):
+        self._lib = capi.load()
+        self.device_index, self.nbytes = device_index, nbytes
+        p = C.c_void_p()
+        capi.check(self._lib.hf_device_malloc(device_index, nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, a):
+        a = np.ascontiguousarray(a)
+        assert a.nbytes <= self.nbytes
+        capi.check(self._lib.hf_memcpy_h2d(self.device_index, C.c_void_p(self.ptr), _ptr(a), a.nbytes))
+
+    def download(self, dtype, count=None):
+        dt = np.dtype(dtype)
+        n = count if count is not None else self.nbytes // dt.itemsize
+        a = np.empty(n, dtype=dt)
+        capi.check(self._lib.hf_memcpy_d2h(self.device_index, _ptr(a), C.c_void_p(self.ptr), a.nbytes))
+        return a
+
+    def free(self):
+        if self.ptr:
+            self._lib.hf_device_free(self.device_index, C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

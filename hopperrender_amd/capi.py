@@ -1,0 +1,107 @@
+"""ctypes binding of the C ABI (include/hopperflow.h) -- the same symbols a cgo/JNI/N-API host binds.
+
+There is NO fallback: if libhopperflow.so is missing or cannot be loaded, importing the product
+path raises (the library is built in-tree by hopperrender_amd.build / __graft_entry__.build()).
+"""
+import ctypes as C
+import os
+
+from . import build as _build
+
+HF_FLAG_ASYNC = 0x1
+HF_FLAG_NO_GRAPH = 0x2
+
+(HF_OK, HF_ERR_INVALID_ARGUMENT, HF_ERR_NO_DEVICE, HF_ERR_OUT_OF_MEMORY, HF_ERR_HIP, HF_ERR_STATE) = (0, -1, -2, -3, -4, -5)
+
+
+class HfConfig(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("is_hdr", C.c_int32), ("frame_height", C.c_int32),
+                ("frame_width", C.c_int32), ("input_stride", C.c_int32), ("output_stride", C.c_int32),
+                ("delta_scalar", C.c_int32), ("neighbor_scalar", C.c_int32), ("black_level", C.c_float),
+                ("white_level", C.c_float), ("max_calc_res", C.c_int32), ("device_index", C.c_int32),
+                ("iterations", C.c_int32), ("blur_radius", C.c_int32), ("search_radius", C.c_int32),
+                ("flags", C.c_uint32)]
+
+
+class HfParams(C.Structure):
+    _fields_ = [("delta_scalar", C.c_int32), ("neighbor_scalar", C.c_int32), ("black_level", C.c_float),
+                ("white_level", C.c_float), ("search_radius", C.c_int32), ("frame_count", C.c_uint32)]
+
+
+class HfStats(C.Structure):
+    _fields_ = [("total_frame_delta", C.c_uint32), ("frame_count", C.c_uint32), ("ofc_calc_time", C.c_double),
+                ("ofc_avg_calc_time", C.c_double), ("ofc_peak_calc_time", C.c_double), ("warp_calc_time", C.c_double),
+                ("res_scalar", C.c_int32), ("low_width", C.c_int32), ("low_height", C.c_int32),
+                ("frame_width", C.c_int32), ("frame_height", C.c_int32), ("input_stride", C.c_int32),
+                ("output_stride", C.c_int32), ("iterations", C.c_int32), ("initial_window", C.c_int32),
+                ("input_frame_bytes", C.c_uint64), ("output_frame_bytes", C.c_uint64)]
+
+
+# name -> (restype, argtypes); must list every symbol include/hopperflow.h declares (tests check this)
+_vp, _i, _f = C.c_void_p, C.c_int, C.c_float
+SIGNATURES = {
+    "hf_create": (_i, [C.POINTER(HfConfig), C.POINTER(_vp)]),
+    "hf_destroy": (None, [_vp]),
+    "hf_last_error": (C.c_char_p, [_vp]),
+    "hf_abi_version": (_i, []),
+    "hf_update_frame": (_i, [_vp, _vp]),
+    "hf_calculate_optical_flow": (_i, [_vp]),
+    "hf_warp_frames": (_i, [_vp, _f, _i]),
+    "hf_copy_frame": (_i, [_vp]),
+    "hf_download_frame": (_i, [_vp, _vp]),
+    "hf_get_params": (_i, [_vp, C.POINTER(HfParams)]),
+    "hf_set_params": (_i, [_vp, C.POINTER(HfParams)]),
+    "hf_get_stats": (_i, [_vp, C.POINTER(HfStats)]),
+    "hf_update_frame_device": (_i, [_vp, _vp]),
+    "hf_download_frame_device": (_i, [_vp, _vp]),
+    "hf_set_output_buffer": (_i, [_vp, _vp]),
+    "hf_sync": (_i, [_vp]),
+    "hf_read_offsets": (_i, [_vp, _vp]),
+    "hf_read_blurred_flow": (_i, [_vp, _i, _vp]),
+    "hf_write_blurred_flow": (_i, [_vp, _i, _vp]),
+    "hf_device_rcp": (_i, [_vp, _vp, _vp, _i]),
+    "hf_timer_begin": (_i, [_vp]),
+    "hf_timer_end": (_i, [_vp, C.POINTER(C.c_float)]),
+    "hf_device_count": (_i, []),
+    "hf_device_malloc": (_i, [_i, C.c_size_t, C.POINTER(_vp)]),
+    "hf_device_free": (_i, [_i, _vp]),
+    "hf_memcpy_h2d": (_i, [_i, _vp, _vp, C.c_size_t]),
+    "hf_memcpy_d2h": (_i, [_i, _vp, _vp, C.c_size_t]),
+}
+
+_lib = None
+
+
+def lib_path():
+    return _build.LIB_FLOW
+
+
+def load():
+    """Load libhopperflow.so (raises if absent: the product has no CPU path)."""
+    global _lib
+    if _lib is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: run `python -m hopperrender_amd.build` "
+                               "(or __graft_entry__.build()); there is no fallback implementation")
+        L = C.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+class HopperFlowError(RuntimeError):
+    """Mirror of the reference's std::runtime_error (opticalFlowCalc.h:15-22); .code = hf_status."""
+
+    def __init__(self, code, msg):
+        super().__init__(msg)
+        self.code = code
+
+
+def check(rc, ctx=None):
+    if rc != 0:
+        msg = load().hf_last_error(ctx)
+        raise HopperFlowError(rc, (msg or b"").decode(errors="replace") or f"[HopperRender] error {rc}")

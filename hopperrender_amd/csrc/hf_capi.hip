@@ -1,0 +1,615 @@
+// hopperrender_amd/csrc/hf_capi.hip -- the C ABI of include/hopperflow.h on top of the gfx950
+// kernels: device memory, the 3-frame ring, the 16-step refinement chain as a cached hipGraph,
+// HIP-event timing with the reference's span definitions.
+//
+// Host orchestration restated from the reference's opticalFlowCalcSDR.cpp / opticalFlowCalcHDR.cpp
+// (cited per function); the architecture differs on purpose:
+//   * per step ONE fused launch for windows <= 16, two for larger windows (reference: fill +
+//     calcDeltaSums + determineLowestLayer + adjustOffsetArray = 4 enqueues, 2.6-8.3 MB of fills);
+//   * offsets live in ping-pong planes so a step never reads what it writes;
+//   * frame N's grid samples are decimated once at upload;
+//   * m_totalFrameDelta is produced on the device and copied to pinned memory inside the graph
+//     (reference: blocking 4-byte readback in the middle of the chain, opticalFlowCalcSDR.cpp:91-94);
+//   * the whole chain replays as one hipGraph keyed by (ring phase, search radius, scalars).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <new>
+#include <string>
+#include <tuple>
+
+#include "../../include/hopperflow.h"
+#include "hf_kernels.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+constexpr int kMinSearchRadius = 5;    // config.h:8
+constexpr int kMaxSearchRadius = 16;   // config.h:9
+constexpr int kCalcTimeInterval = 240; // config.h:17
+constexpr int kMaxSteps = 32;          // 2 * log2(max window)
+
+}  // namespace
+
+struct hf_ctx {
+    hf::Geom g{};
+    hf_config cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // public fields of the reference object (opticalFlowCalc.h:27-48)
+    hf_params p{};
+    uint32_t total_frame_delta = 0;
+    double ofc_calc_time = 0, ofc_avg = 0, ofc_peak = 0, ofc_sum = 0, warp_calc_time = 0;
+    int ofc_count = 0;
+
+    // device memory (reference buffers: opticalFlowCalcSDR.cpp:272-280)
+    size_t in_bytes = 0, out_bytes = 0, plane_elems = 0;
+    void* ring[3] = {nullptr, nullptr, nullptr};       // m_inputFrameArray, ring[2] = newest
+    uint32_t* grid[3] = {nullptr, nullptr, nullptr};   // decimated samples of each ring frame
+    void* out_frame = nullptr;                         // m_outputFrameArray
+    void* out_target = nullptr;                        // where warp/copy write (out_frame or caller's)
+    int16_t* off[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [axis][ping-pong] m_offsetArray
+    int off_cur[2] = {0, 0};
+    int16_t* blurred[2] = {nullptr, nullptr};          // m_blurredOffsetArray
+    uint32_t* sums = nullptr;                          // [kMaxSteps][n_windows_max][16]
+    size_t sums_bytes = 0;
+    size_t sums_stride = 0;                            // elements per step
+    uint32_t* d_total_delta = nullptr;
+    uint32_t* h_total_delta = nullptr;                 // pinned
+    float* d_probe = nullptr;
+
+    int ring_phase = 0;   // number of rotations mod 3 (graph key)
+    int blur_phase = 0;   // number of swaps mod 2
+    bool have_flow = false;
+    bool delta_pending = false;
+    int last_iterations = 0, initial_window = 0;
+
+    // timing (reference spans: opticalFlowCalcSDR.cpp:36-41,119-127)
+    hipEvent_t ev_upload = nullptr, ev_flow_end = nullptr, ev_warp_start = nullptr, ev_warp_end = nullptr;
+    hipEvent_t ev_user0 = nullptr, ev_user1 = nullptr;
+    bool upload_recorded = false, flow_timing_pending = false, warp_started = false;
+
+    std::map<std::tuple<int, int, int, int, int>, hipGraphExec_t> graphs;
+
+    bool async() const { return (cfg.flags & HF_FLAG_ASYNC) != 0; }
+};
+
+namespace {
+
+int fail(hf_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    std::string msg = std::string("[HopperRender] ") + buf;  // same prefix as the reference's exceptions
+    if (c) c->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define HF_HIP(c, call)                                                                              \
+    do {                                                                                             \
+        hipError_t _e = (call);                                                                      \
+        if (_e != hipSuccess)                                                                        \
+            return fail((c), _e == hipErrorOutOfMemory ? HF_ERR_OUT_OF_MEMORY : HF_ERR_HIP,          \
+                        "HIP error %d (%s) in %s at %s:%d", (int)_e, hipGetErrorString(_e), #call,  \
+                        __FILE__, __LINE__);                                                         \
+    } while (0)
+
+#define HF_CHECK_CTX(c) \
+    if (!(c)) return fail(nullptr, HF_ERR_INVALID_ARGUMENT, "null context")
+
+int set_device(hf_ctx* c) {
+    HF_HIP(c, hipSetDevice(c->device));
+    return HF_OK;
+}
+
+// opticalFlowCalcSDR.cpp:49-59
+int initial_window(int lw, int lh) {
+    int max_dim = lw > lh ? lw : lh;
+    int ws;
+    if (max_dim && !(max_dim & (max_dim - 1))) {
+        ws = max_dim;
+    } else {
+        while (max_dim & (max_dim - 1)) max_dim &= (max_dim - 1);
+        ws = max_dim << 1;
+    }
+    return ws / 2;
+}
+
+int ilog2(int v) {
+    int l = 0;
+    while ((1 << (l + 1)) <= v) l++;
+    return l;
+}
+
+// Enqueue the refinement chain + blur (opticalFlowCalcSDR.cpp:44-116).  Capturable.
+int enqueue_flow_chain(hf_ctx* c) {
+    const hf::Geom& g = c->g;
+    hipStream_t s = c->stream;
+    const size_t plane_bytes = c->plane_elems * sizeof(int16_t);
+    int cur[2] = {0, 0};  // chain always starts from planes [axis][0] = 0 (:68-69: no temporal state)
+    HF_HIP(c, hipMemsetAsync(c->off[0][0], 0, plane_bytes, s));
+    HF_HIP(c, hipMemsetAsync(c->off[1][0], 0, plane_bytes, s));
+    HF_HIP(c, hipMemsetAsync(c->sums, 0, c->sums_bytes, s));
+
+    int window = initial_window(g.lw, g.lh);
+    int iters = ilog2(window);                                   // :62-65
+    if (c->cfg.iterations > 0 && c->cfg.iterations < iters) iters = c->cfg.iterations;
+    c->initial_window = window;
+    c->last_iterations = iters;
+    const int R = c->p.search_radius;
+    int step_index = 0;
+    if (iters == 0) {
+        // degenerate grid (<= 2 px): the reference runs no step and keeps the previous m_totalFrameDelta
+    }
+    for (int iter = 0; iter < iters; iter++) {
+        for (int step = 0; step < 2; step++, step_index++) {
+            hf::StepArgs a{};
+            a.frame1 = c->ring[1];                               // :79 frame N-1
+            a.grid2 = c->grid[2];                                // :80 frame N (decimated)
+            a.off_x = c->off[0][cur[0]];
+            a.off_y = c->off[1][cur[1]];
+            a.off_out = c->off[step][cur[step] ^ 1];
+            a.sums = c->sums + (size_t)step_index * c->sums_stride;
+            a.total_delta = c->d_total_delta;
+            a.window = window;
+            a.window_log2 = ilog2(window);
+            a.n_win_x = (g.lw + window - 1) / window;
+            a.R = R;
+            a.step = step;
+            a.use_neighbors = iter >= 4;                         // calcDeltaSumsKernelSDR.h:3,112
+            a.delta_scalar = c->p.delta_scalar;
+            a.neighbor_scalar = c->p.neighbor_scalar;
+            a.capture_delta = (iter == 0 && step == 0);          // :91
+            a.delta_divisor = (uint32_t)(g.lh * g.lw * (g.hdr ? 6 : 10));  // :93 / HDR :93
+            hf::launch_flow_step(g, a, s);
+            if (window > 16) hf::launch_argmin_adjust(g, a, s);
+            cur[step] ^= 1;
+        }
+        window = (window >> 1) > 1 ? (window >> 1) : 1;          // :110
+        if (window < 2) break;  // window 1 is unreachable in the reference's auto mode
+    }
+    c->off_cur[0] = cur[0];
+    c->off_cur[1] = cur[1];
+    hf::launch_blur_flow(g, c->off[0][cur[0]], c->off[1][cur[1]], c->blurred[0], c->cfg.blur_radius, s);  // :115-116
+    HF_HIP(c, hipMemcpyAsync(c->h_total_delta, c->d_total_delta, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HF_HIP(c, hipGetLastError());
+    return HF_OK;
+}
+
+void finish_flow_timing(hf_ctx* c) {
+    // opticalFlowCalcSDR.cpp:125-138
+    if (!c->flow_timing_pending) return;
+    c->flow_timing_pending = false;
+    float ms = 0.f;
+    if (c->upload_recorded && hipEventElapsedTime(&ms, c->ev_upload, c->ev_flow_end) == hipSuccess)
+        c->ofc_calc_time = (double)ms / 1e3;
+    if (c->ofc_count >= kCalcTimeInterval) {
+        c->ofc_avg = c->ofc_sum / c->ofc_count;
+        c->ofc_count = 0;
+        c->ofc_sum = 0.0;
+        c->ofc_peak = c->ofc_calc_time;
+    }
+    c->ofc_count++;
+    c->ofc_sum += c->ofc_calc_time;
+    if (c->ofc_calc_time > c->ofc_peak) c->ofc_peak = c->ofc_calc_time;
+}
+
+int sync_ctx(hf_ctx* c) {
+    HF_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->delta_pending) { c->total_frame_delta = *c->h_total_delta; c->delta_pending = false; }
+    finish_flow_timing(c);
+    return HF_OK;
+}
+
+int rotate_after_upload(hf_ctx* c) {
+    // opticalFlowCalcSDR.cpp:22-28 : [0] <- [1] <- [2] <- new ; frame_count++
+    void* f = c->ring[0];
+    uint32_t* gr = c->grid[0];
+    c->ring[0] = c->ring[1]; c->grid[0] = c->grid[1];
+    c->ring[1] = c->ring[2]; c->grid[1] = c->grid[2];
+    c->ring[2] = f;          c->grid[2] = gr;
+    c->ring_phase = (c->ring_phase + 1) % 3;
+    c->p.frame_count++;
+    return HF_OK;
+}
+
+int update_common(hf_ctx* c, const void* src, hipMemcpyKind kind) {
+    if (int rc = set_device(c)) return rc;
+    HF_HIP(c, hipEventRecord(c->ev_upload, c->stream));  // m_ofcStartedEvent (:20)
+    c->upload_recorded = true;
+    HF_HIP(c, hipMemcpyAsync(c->ring[0], src, c->in_bytes, kind, c->stream));
+    hf::launch_decimate(c->g, c->ring[0], c->grid[0], c->stream);
+    HF_HIP(c, hipGetLastError());
+    rotate_after_upload(c);
+    if (!c->async()) return sync_ctx(c);
+    return HF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hf_abi_version(void) { return HF_ABI_VERSION; }
+
+const char* hf_last_error(const hf_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int hf_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int hf_create(const hf_config* cfg, hf_ctx** out_ctx) {
+    if (!cfg || !out_ctx) return fail(nullptr, HF_ERR_INVALID_ARGUMENT, "hf_create: null argument");
+    *out_ctx = nullptr;
+    if (cfg->struct_size != sizeof(hf_config))
+        return fail(nullptr, HF_ERR_INVALID_ARGUMENT, "hf_create: hf_config.struct_size %u != %zu", cfg->struct_size, sizeof(hf_config));
+    if (cfg->frame_height < 4 || cfg->frame_width < 4 || (cfg->frame_height & 1) || (cfg->frame_width & 1))
+        return fail(nullptr, HF_ERR_INVALID_ARGUMENT, "hf_create: frame size %dx%d must be even and >= 4", cfg->frame_width, cfg->frame_height);
+    if (cfg->max_calc_res < 1) return fail(nullptr, HF_ERR_INVALID_ARGUMENT, "hf_create: max_calc_res must be >= 1");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(nullptr, HF_ERR_NO_DEVICE, "Error in function detectDevices: no HIP device available");
+    if (cfg->device_index < 0 || cfg->device_index >= ndev)
+        return fail(nullptr, HF_ERR_NO_DEVICE, "Error in function detectDevices: device %d of %d", cfg->device_index, ndev);
+
+    hf_ctx* c = new (std::nothrow) hf_ctx();
+    if (!c) return fail(nullptr, HF_ERR_OUT_OF_MEMORY, "hf_create: host allocation failed");
+    c->cfg = *cfg;
+    c->device = cfg->device_index;
+    hf::Geom& g = c->g;
+    g.hdr = cfg->is_hdr ? 1 : 0;
+    g.H = cfg->frame_height;
+    g.W = cfg->frame_width;
+    g.in_stride = cfg->input_stride > 0 ? cfg->input_stride : g.W;     // opticalFlowCalcSDR.cpp:212
+    g.out_stride = cfg->output_stride > 0 ? cfg->output_stride : g.W;  // :213
+    g.rs = 0;
+    while ((g.H >> g.rs) > cfg->max_calc_res) g.rs++;                  // :217-220
+    g.lw = (int)std::ceil((double)g.W / std::pow(2.0, g.rs));          // :221
+    g.lh = (int)std::ceil((double)g.H / std::pow(2.0, g.rs));          // :222
+    if (g.in_stride < g.W || g.out_stride < g.W) {
+        delete c;
+        return fail(nullptr, HF_ERR_INVALID_ARGUMENT, "hf_create: strides must be >= frame width");
+    }
+    if (c->cfg.blur_radius <= 0) c->cfg.blur_radius = 4;               // blurFlowKernelSDR.h:4
+    if (c->cfg.blur_radius > 64) { delete c; return fail(nullptr, HF_ERR_INVALID_ARGUMENT, "hf_create: blur_radius must be <= 64"); }
+    c->p.delta_scalar = cfg->delta_scalar;
+    c->p.neighbor_scalar = cfg->neighbor_scalar;
+    c->p.black_level = cfg->black_level;
+    c->p.white_level = cfg->white_level;
+    c->p.search_radius = cfg->search_radius > 0 ? cfg->search_radius : kMinSearchRadius;  // :216
+    c->p.frame_count = 0;
+    if (c->p.search_radius < 2 || c->p.search_radius > kMaxSearchRadius) {
+        delete c;
+        return fail(nullptr, HF_ERR_INVALID_ARGUMENT, "hf_create: search_radius must be in [2, 16]");
+    }
+
+    const size_t bpp = g.hdr ? 2 : 1;
+    c->in_bytes = bpp * ((size_t)g.H * g.in_stride + (size_t)(g.H / 2) * g.in_stride);     // :20
+    c->out_bytes = bpp * ((size_t)g.H * g.out_stride + (size_t)(g.H / 2) * g.out_stride);  // :33
+    c->plane_elems = (size_t)g.lw * g.lh;
+    const int ws0 = initial_window(g.lw, g.lh);
+    // largest per-step window table: windows > 16 only, at most ceil(lw/32)*ceil(lh/32)
+    const size_t nwin_max = (size_t)((g.lw + 31) / 32) * ((g.lh + 31) / 32) + 1;
+    c->sums_stride = nwin_max * 16;
+    c->sums_bytes = (size_t)kMaxSteps * c->sums_stride * sizeof(uint32_t);
+    (void)ws0;
+
+    int rc = HF_OK;
+    auto bail = [&](int code) { std::string e = c->err; hf_destroy(c); g_create_error = e; return code; };
+    if ((rc = set_device(c))) return bail(rc);
+#define HF_TRY(call) do { hipError_t _e = (call); if (_e != hipSuccess) { \
+        fail(c, _e == hipErrorOutOfMemory ? HF_ERR_OUT_OF_MEMORY : HF_ERR_HIP, "HIP error %d (%s) in %s", (int)_e, hipGetErrorString(_e), #call); \
+        return bail(_e == hipErrorOutOfMemory ? HF_ERR_OUT_OF_MEMORY : HF_ERR_HIP); } } while (0)
+    HF_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (int i = 0; i < 3; i++) {
+        HF_TRY(hipMalloc(&c->ring[i], c->in_bytes));
+        HF_TRY(hipMalloc((void**)&c->grid[i], c->plane_elems * sizeof(uint32_t)));
+        HF_TRY(hipMemsetAsync(c->ring[i], 0, c->in_bytes, c->stream));
+        HF_TRY(hipMemsetAsync(c->grid[i], 0, c->plane_elems * sizeof(uint32_t), c->stream));
+    }
+    HF_TRY(hipMalloc(&c->out_frame, c->out_bytes));
+    HF_TRY(hipMemsetAsync(c->out_frame, 0, c->out_bytes, c->stream));
+    c->out_target = c->out_frame;
+    for (int a = 0; a < 2; a++)
+        for (int b = 0; b < 2; b++) {
+            HF_TRY(hipMalloc((void**)&c->off[a][b], c->plane_elems * sizeof(int16_t)));
+            HF_TRY(hipMemsetAsync(c->off[a][b], 0, c->plane_elems * sizeof(int16_t), c->stream));
+        }
+    for (int i = 0; i < 2; i++) {
+        HF_TRY(hipMalloc((void**)&c->blurred[i], 2 * c->plane_elems * sizeof(int16_t)));
+        HF_TRY(hipMemsetAsync(c->blurred[i], 0, 2 * c->plane_elems * sizeof(int16_t), c->stream));
+    }
+    HF_TRY(hipMalloc((void**)&c->sums, c->sums_bytes));
+    HF_TRY(hipMalloc((void**)&c->d_total_delta, sizeof(uint32_t)));
+    HF_TRY(hipMemsetAsync(c->d_total_delta, 0, sizeof(uint32_t), c->stream));
+    HF_TRY(hipMalloc((void**)&c->d_probe, 64 * sizeof(float)));
+    HF_TRY(hipHostMalloc((void**)&c->h_total_delta, sizeof(uint32_t), hipHostMallocDefault));
+    *c->h_total_delta = 0;
+    HF_TRY(hipEventCreate(&c->ev_upload));
+    HF_TRY(hipEventCreate(&c->ev_flow_end));
+    HF_TRY(hipEventCreate(&c->ev_warp_start));
+    HF_TRY(hipEventCreate(&c->ev_warp_end));
+    HF_TRY(hipEventCreate(&c->ev_user0));
+    HF_TRY(hipEventCreate(&c->ev_user1));
+    HF_TRY(hipStreamSynchronize(c->stream));
+#undef HF_TRY
+    *out_ctx = c;
+    return HF_OK;
+}
+
+void hf_destroy(hf_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);  // clFinish (opticalFlowCalcSDR.cpp:186)
+    for (auto& kv : c->graphs) hipGraphExecDestroy(kv.second);
+    for (int i = 0; i < 3; i++) { if (c->ring[i]) hipFree(c->ring[i]); if (c->grid[i]) hipFree(c->grid[i]); }
+    if (c->out_frame) hipFree(c->out_frame);
+    for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++) if (c->off[a][b]) hipFree(c->off[a][b]);
+    for (int i = 0; i < 2; i++) if (c->blurred[i]) hipFree(c->blurred[i]);
+    if (c->sums) hipFree(c->sums);
+    if (c->d_total_delta) hipFree(c->d_total_delta);
+    if (c->d_probe) hipFree(c->d_probe);
+    if (c->h_total_delta) hipHostFree(c->h_total_delta);
+    hipEvent_t evs[] = {c->ev_upload, c->ev_flow_end, c->ev_warp_start, c->ev_warp_end, c->ev_user0, c->ev_user1};
+    for (hipEvent_t e : evs) if (e) hipEventDestroy(e);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int hf_update_frame(hf_ctx* c, const void* host_frame) {
+    HF_CHECK_CTX(c);
+    if (!host_frame) return fail(c, HF_ERR_INVALID_ARGUMENT, "hf_update_frame: null frame");
+    return update_common(c, host_frame, hipMemcpyHostToDevice);
+}
+
+int hf_update_frame_device(hf_ctx* c, const void* device_frame) {
+    HF_CHECK_CTX(c);
+    if (!device_frame) return fail(c, HF_ERR_INVALID_ARGUMENT, "hf_update_frame_device: null frame");
+    return update_common(c, device_frame, hipMemcpyDeviceToDevice);
+}
+
+int hf_calculate_optical_flow(hf_ctx* c) {
+    HF_CHECK_CTX(c);
+    if (int rc = set_device(c)) return rc;
+    const int R = c->p.search_radius;
+    if (R < 2 || R > kMaxSearchRadius) return fail(c, HF_ERR_INVALID_ARGUMENT, "calculateOpticalFlow: search radius %d outside [2, 16]", R);
+    if (c->p.delta_scalar < 0 || c->p.delta_scalar > 24 || c->p.neighbor_scalar < 0 || c->p.neighbor_scalar > 24)
+        return fail(c, HF_ERR_INVALID_ARGUMENT, "calculateOpticalFlow: delta/neighbor scalar outside [0, 24]");
+
+    if (c->cfg.flags & HF_FLAG_NO_GRAPH) {
+        if (int rc = enqueue_flow_chain(c)) return rc;
+    } else {
+        const auto key = std::make_tuple(c->ring_phase, c->blur_phase, R, c->p.delta_scalar, c->p.neighbor_scalar);
+        auto it = c->graphs.find(key);
+        if (it == c->graphs.end()) {
+            hipGraph_t graph = nullptr;
+            HF_HIP(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+            const int rc = enqueue_flow_chain(c);
+            const hipError_t e = hipStreamEndCapture(c->stream, &graph);
+            if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
+            HF_HIP(c, e);
+            hipGraphExec_t exec = nullptr;
+            HF_HIP(c, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+            hipGraphDestroy(graph);
+            if (c->graphs.size() >= 96) {  // bound the cache (parameters poked by a settings UI)
+                for (auto& kv : c->graphs) hipGraphExecDestroy(kv.second);
+                c->graphs.clear();
+            }
+            it = c->graphs.emplace(key, exec).first;
+        } else {
+            // replay path: recompute the bookkeeping enqueue_flow_chain() would have set
+            int window = initial_window(c->g.lw, c->g.lh);
+            int iters = ilog2(window);
+            if (c->cfg.iterations > 0 && c->cfg.iterations < iters) iters = c->cfg.iterations;
+            c->initial_window = window;
+            c->last_iterations = iters;
+            c->off_cur[0] = iters & 1;
+            c->off_cur[1] = iters & 1;
+        }
+        HF_HIP(c, hipGraphLaunch(it->second, c->stream));
+    }
+    HF_HIP(c, hipEventRecord(c->ev_flow_end, c->stream));
+    c->delta_pending = c->last_iterations > 0;
+    c->flow_timing_pending = true;
+    // opticalFlowCalcSDR.cpp:121-123 : swap so that [1] = newest flow, [0] = previous flow
+    int16_t* t = c->blurred[0];
+    c->blurred[0] = c->blurred[1];
+    c->blurred[1] = t;
+    c->blur_phase ^= 1;
+    c->have_flow = true;
+    if (!c->async()) return sync_ctx(c);
+    return HF_OK;
+}
+
+int hf_warp_frames(hf_ctx* c, float t, int mode) {
+    HF_CHECK_CTX(c);
+    if (t > 1.0f) return fail(c, HF_ERR_INVALID_ARGUMENT, "Error in function warpFrames: blending scalar is greater than 1.0");  // :143-146
+    if (mode < 0 || mode > 6) return fail(c, HF_ERR_INVALID_ARGUMENT, "warpFrames: frame output mode %d outside [0, 6]", mode);
+    if (int rc = set_device(c)) return rc;
+    const float scale = c->g.hdr ? 256.0f : 1.0f;  // opticalFlowCalcHDR.cpp:151-152
+    if (!c->warp_started) { HF_HIP(c, hipEventRecord(c->ev_warp_start, c->stream)); c->warp_started = true; }
+    // frames N-2 / N-1 and the PREVIOUS flow (:154-156)
+    hf::launch_warp(c->g, c->ring[0], c->ring[1], c->blurred[0], c->out_target, t, mode,
+                    c->p.black_level * scale, c->p.white_level * scale, c->stream);
+    HF_HIP(c, hipGetLastError());
+    return HF_OK;
+}
+
+int hf_copy_frame(hf_ctx* c) {
+    HF_CHECK_CTX(c);
+    if (int rc = set_device(c)) return rc;
+    const float scale = c->g.hdr ? 256.0f : 1.0f;  // opticalFlowCalcHDR.cpp:173-174
+    const int idx = c->p.frame_count >= 3 ? 0 : c->p.frame_count >= 2 ? 1 : 2;  // opticalFlowCalcSDR.cpp:173
+    if (!c->warp_started) { HF_HIP(c, hipEventRecord(c->ev_warp_start, c->stream)); c->warp_started = true; }
+    hf::launch_copy(c->g, c->ring[idx], c->out_target, c->p.black_level * scale, c->p.white_level * scale, c->stream);
+    HF_HIP(c, hipGetLastError());
+    return HF_OK;
+}
+
+static int download_common(hf_ctx* c, void* dst, hipMemcpyKind kind) {
+    if (int rc = set_device(c)) return rc;
+    if (c->out_target != dst) HF_HIP(c, hipMemcpyAsync(dst, c->out_target, c->out_bytes, kind, c->stream));
+    HF_HIP(c, hipEventRecord(c->ev_warp_end, c->stream));
+    if (kind == hipMemcpyDeviceToHost || !c->async()) {
+        if (int rc = sync_ctx(c)) return rc;
+        float ms = 0.f;
+        if (c->warp_started && hipEventElapsedTime(&ms, c->ev_warp_start, c->ev_warp_end) == hipSuccess)
+            c->warp_calc_time = (double)ms / 1e3;  // opticalFlowCalcSDR.cpp:36-41
+    }
+    c->warp_started = false;
+    return HF_OK;
+}
+
+int hf_download_frame(hf_ctx* c, void* host_out) {
+    HF_CHECK_CTX(c);
+    if (!host_out) return fail(c, HF_ERR_INVALID_ARGUMENT, "hf_download_frame: null buffer");
+    return download_common(c, host_out, hipMemcpyDeviceToHost);
+}
+
+int hf_download_frame_device(hf_ctx* c, void* device_out) {
+    HF_CHECK_CTX(c);
+    if (!device_out) return fail(c, HF_ERR_INVALID_ARGUMENT, "hf_download_frame_device: null buffer");
+    return download_common(c, device_out, hipMemcpyDeviceToDevice);
+}
+
+int hf_set_output_buffer(hf_ctx* c, void* device_out) {
+    HF_CHECK_CTX(c);
+    c->out_target = device_out ? device_out : c->out_frame;
+    return HF_OK;
+}
+
+int hf_sync(hf_ctx* c) {
+    HF_CHECK_CTX(c);
+    if (int rc = set_device(c)) return rc;
+    return sync_ctx(c);
+}
+
+int hf_get_params(const hf_ctx* c, hf_params* out) {
+    if (!c || !out) return HF_ERR_INVALID_ARGUMENT;
+    *out = c->p;
+    return HF_OK;
+}
+
+int hf_set_params(hf_ctx* c, const hf_params* in) {
+    HF_CHECK_CTX(c);
+    if (!in) return fail(c, HF_ERR_INVALID_ARGUMENT, "hf_set_params: null");
+    c->p = *in;  // validated at use, like the reference (fields are poked directly)
+    return HF_OK;
+}
+
+int hf_get_stats(hf_ctx* c, hf_stats* out) {
+    HF_CHECK_CTX(c);
+    if (!out) return fail(c, HF_ERR_INVALID_ARGUMENT, "hf_get_stats: null");
+    memset(out, 0, sizeof(*out));
+    out->total_frame_delta = c->total_frame_delta;
+    out->frame_count = c->p.frame_count;
+    out->ofc_calc_time = c->ofc_calc_time;
+    out->ofc_avg_calc_time = c->ofc_avg;
+    out->ofc_peak_calc_time = c->ofc_peak;
+    out->warp_calc_time = c->warp_calc_time;
+    out->res_scalar = c->g.rs;
+    out->low_width = c->g.lw;
+    out->low_height = c->g.lh;
+    out->frame_width = c->g.W;
+    out->frame_height = c->g.H;
+    out->input_stride = c->g.in_stride;
+    out->output_stride = c->g.out_stride;
+    out->iterations = c->last_iterations;
+    out->initial_window = c->initial_window;
+    out->input_frame_bytes = c->in_bytes;
+    out->output_frame_bytes = c->out_bytes;
+    return HF_OK;
+}
+
+int hf_read_offsets(hf_ctx* c, int16_t* host_out) {
+    HF_CHECK_CTX(c);
+    if (!host_out) return fail(c, HF_ERR_INVALID_ARGUMENT, "hf_read_offsets: null");
+    if (int rc = set_device(c)) return rc;
+    if (int rc = sync_ctx(c)) return rc;
+    const size_t pb = c->plane_elems * sizeof(int16_t);
+    HF_HIP(c, hipMemcpy(host_out, c->off[0][c->off_cur[0]], pb, hipMemcpyDeviceToHost));
+    HF_HIP(c, hipMemcpy(host_out + c->plane_elems, c->off[1][c->off_cur[1]], pb, hipMemcpyDeviceToHost));
+    return HF_OK;
+}
+
+int hf_read_blurred_flow(hf_ctx* c, int idx, int16_t* host_out) {
+    HF_CHECK_CTX(c);
+    if (!host_out || idx < 0 || idx > 1) return fail(c, HF_ERR_INVALID_ARGUMENT, "hf_read_blurred_flow: bad argument");
+    if (int rc = set_device(c)) return rc;
+    if (int rc = sync_ctx(c)) return rc;
+    HF_HIP(c, hipMemcpy(host_out, c->blurred[idx], 2 * c->plane_elems * sizeof(int16_t), hipMemcpyDeviceToHost));
+    return HF_OK;
+}
+
+int hf_write_blurred_flow(hf_ctx* c, int idx, const int16_t* host_in) {
+    HF_CHECK_CTX(c);
+    if (!host_in || idx < 0 || idx > 1) return fail(c, HF_ERR_INVALID_ARGUMENT, "hf_write_blurred_flow: bad argument");
+    if (int rc = set_device(c)) return rc;
+    if (int rc = sync_ctx(c)) return rc;
+    HF_HIP(c, hipMemcpy(c->blurred[idx], host_in, 2 * c->plane_elems * sizeof(int16_t), hipMemcpyHostToDevice));
+    return HF_OK;
+}
+
+int hf_timer_begin(hf_ctx* c) {
+    HF_CHECK_CTX(c);
+    if (int rc = set_device(c)) return rc;
+    HF_HIP(c, hipEventRecord(c->ev_user0, c->stream));
+    return HF_OK;
+}
+
+int hf_timer_end(hf_ctx* c, float* elapsed_ms) {
+    HF_CHECK_CTX(c);
+    if (!elapsed_ms) return fail(c, HF_ERR_INVALID_ARGUMENT, "hf_timer_end: null");
+    if (int rc = set_device(c)) return rc;
+    HF_HIP(c, hipEventRecord(c->ev_user1, c->stream));
+    HF_HIP(c, hipEventSynchronize(c->ev_user1));
+    HF_HIP(c, hipEventElapsedTime(elapsed_ms, c->ev_user0, c->ev_user1));
+    return HF_OK;
+}
+
+int hf_device_rcp(hf_ctx* c, const float* host_in, float* host_out, int n) {
+    HF_CHECK_CTX(c);
+    if (!host_in || !host_out || n < 1 || n > 32) return fail(c, HF_ERR_INVALID_ARGUMENT, "hf_device_rcp: bad argument");
+    if (int rc = set_device(c)) return rc;
+    if (int rc = sync_ctx(c)) return rc;
+    HF_HIP(c, hipMemcpy(c->d_probe, host_in, n * sizeof(float), hipMemcpyHostToDevice));
+    hf::launch_rcp_probe(c->d_probe, c->d_probe + 32, n, c->stream);
+    HF_HIP(c, hipStreamSynchronize(c->stream));
+    HF_HIP(c, hipMemcpy(host_out, c->d_probe + 32, n * sizeof(float), hipMemcpyDeviceToHost));
+    return HF_OK;
+}
+
+int hf_device_malloc(int device_index, size_t bytes, void** out) {
+    if (!out) return HF_ERR_INVALID_ARGUMENT;
+    if (hipSetDevice(device_index) != hipSuccess) return fail(nullptr, HF_ERR_NO_DEVICE, "hf_device_malloc: bad device %d", device_index);
+    hipError_t e = hipMalloc(out, bytes);
+    if (e != hipSuccess) return fail(nullptr, e == hipErrorOutOfMemory ? HF_ERR_OUT_OF_MEMORY : HF_ERR_HIP, "hf_device_malloc: %s", hipGetErrorString(e));
+    return HF_OK;
+}
+
+int hf_device_free(int device_index, void* p) {
+    if (hipSetDevice(device_index) != hipSuccess) return HF_ERR_NO_DEVICE;
+    return hipFree(p) == hipSuccess ? HF_OK : HF_ERR_HIP;
+}
+
+int hf_memcpy_h2d(int device_index, void* d, const void* h, size_t bytes) {
+    if (hipSetDevice(device_index) != hipSuccess) return HF_ERR_NO_DEVICE;
+    return hipMemcpy(d, h, bytes, hipMemcpyHostToDevice) == hipSuccess ? HF_OK : HF_ERR_HIP;
+}
+
+int hf_memcpy_d2h(int device_index, void* h, const void* d, size_t bytes) {
+    if (hipSetDevice(device_index) != hipSuccess) return HF_ERR_NO_DEVICE;
+    return hipMemcpy(h, d, bytes, hipMemcpyDeviceToHost) == hipSuccess ? HF_OK : HF_ERR_HIP;
+}
+
+}  // extern "C"

@@ -1,0 +1,540 @@
+// hopperrender_amd/csrc/hf_kernels.hip -- hand-written gfx950 (CDNA4) kernels of the
+// OpticalFlowCalc hot path.  Wave = 64 lanes everywhere.  Build with -ffp-contract=off: the
+// only fused operations are the ones written explicitly (see "fp32 flavour" below).
+//
+// What each kernel replaces (reference HopperRender/):
+//   decimate_kernel      - the frame2 half of calcDeltaSumsKernel{SDR,HDR}.h:98-100, hoisted: the
+//                          grid samples of frame N are candidate-independent, so they are gathered
+//                          ONCE per frame instead of 16 steps x R candidates times.
+//   flow_step_kernel     - calcDeltaSumsKernel{SDR,HDR}.h:36-191; for windows <= 16 also
+//                          determineLowestLayerKernelSDR.h:4-28 + adjustOffsetArrayKernelSDR.h:4-21
+//                          (one launch per step, no sums buffer, no fills, no atomics).
+//   argmin_adjust_kernel - determineLowestLayer + adjustOffsetArray for windows > 16.
+//   blur_flow_kernel     - blurFlowKernelSDR.h:17-92, separable through LDS, runtime radius.
+//   warp_kernel          - warpFrameKernel{SDR,HDR}.h:116-184 (all 7 modes), both planes, one launch.
+//   copy_kernel          - copyFrameKernel{SDR,HDR}.h:12-25, both planes, one launch.
+//
+// fp32 flavour: blend/levels reproduce the reference AS IT RUNS ON gfx950 through AMD OpenCL
+// (measured, tests/golden/levels_ramp.npz): "a*u + b*t" is contracted to fma(a, u, b*t); the
+// division in apply_levels* is x * v_rcp_f32(y); "q*max + mid" is fma(q, max, mid).
+#include "hf_kernels.h"
+
+namespace hf {
+
+namespace {
+
+template <typename E> struct ElemTraits;
+template <> struct ElemTraits<uint8_t> {
+    static constexpr bool hdr = false;
+    static constexpr float maxv = 255.0f;
+    static constexpr float mid = 128.0f;
+    static constexpr unsigned midu = 128u;
+    __device__ static __forceinline__ unsigned top8(uint8_t v) { return v; }
+};
+template <> struct ElemTraits<uint16_t> {
+    static constexpr bool hdr = true;
+    static constexpr float maxv = 65535.0f;
+    static constexpr float mid = 32768.0f;
+    static constexpr unsigned midu = 32768u;
+    __device__ static __forceinline__ unsigned top8(uint16_t v) { return (unsigned)(v >> 8); }  // calcDeltaSumsKernelHDR.h:98
+};
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
+__device__ __forceinline__ unsigned absdiff(unsigned a, unsigned b) { return a > b ? a - b : b - a; }
+
+// sgn(d)*d*d, d = layer - R/2 (calcDeltaSumsKernelSDR.h:70-74)
+__device__ __forceinline__ int rel_offset(int layer, int R) {
+    const int d = layer - (R >> 1);
+    return d > 0 ? d * d : -(d * d);
+}
+
+// ------------------------------------------------------------------------------------------
+// decimate: frame N -> packed grid samples
+// ------------------------------------------------------------------------------------------
+template <typename E>
+__global__ __launch_bounds__(256) void decimate_kernel(const E* __restrict__ f, uint32_t* __restrict__ grid,
+                                                        int H, int W, int S, int rs, int lw, int lh) {
+    using T = ElemTraits<E>;
+    const int cx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int cy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (cx >= lw || cy >= lh) return;
+    const int sx = cx << rs, sy = cy << rs;
+    uint32_t p = 0;
+    if (sx < W && sy < H) {  // calcDeltaSumsKernelSDR.h:82 (always true for lw = ceil(W / 2^rs))
+        const E* uv = f + (size_t)H * S + (size_t)(sy >> 1) * S + (sx & ~1);
+        p = T::top8(f[(size_t)sy * S + sx]) | (T::top8(uv[0]) << 8) | (T::top8(uv[1]) << 16) | (1u << 24);
+    }
+    grid[(size_t)cy * lw + cx] = p;
+}
+
+// ------------------------------------------------------------------------------------------
+// flow step
+// ------------------------------------------------------------------------------------------
+
+// Sum over aligned groups of G lanes (G = 4, 16, 64); every lane of the group gets the sum.
+template <int G>
+__device__ __forceinline__ uint32_t group_sum(uint32_t v) {
+#pragma unroll
+    for (int m = G >> 1; m >= 1; m >>= 1) v += (uint32_t)__shfl_xor((int)v, m, 64);
+    return v;
+}
+
+// Lane -> pixel inside the workgroup's 16x16 grid tile, chosen so that every window of the
+// current size is a contiguous, aligned lane group (64, 64, 16 or 4 lanes).
+__device__ __forceinline__ void lane_to_tile_xy(int window, int wave, int lane, int& lx, int& ly) {
+    if (window >= 16) {            // tile = (part of) one window; wave = 16x4 strip
+        lx = lane & 15;
+        ly = wave * 4 + (lane >> 4);
+    } else {
+        int gx, gy, ix, iy;
+        if (window == 8) {         // wave = one 8x8 window
+            gx = 0; gy = 0; ix = lane & 7; iy = lane >> 3;
+        } else if (window == 4) {  // 16 lanes = one 4x4 window
+            const int g = lane >> 4, i = lane & 15;
+            gx = (g & 1) * 4; gy = (g >> 1) * 4; ix = i & 3; iy = i >> 2;
+        } else {                   // 4 lanes = one 2x2 window
+            const int g = lane >> 2, i = lane & 3;
+            gx = (g & 3) * 2; gy = (g >> 2) * 2; ix = i & 1; iy = i >> 1;
+        }
+        lx = (wave & 1) * 8 + gx + ix;
+        ly = (wave >> 1) * 8 + gy + iy;
+    }
+}
+
+template <typename E>
+__global__ __launch_bounds__(256) void flow_step_kernel(const Geom g, const StepArgs a) {
+    using T = ElemTraits<E>;
+    __shared__ uint32_t s_part[4][16];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    int lx, ly;
+    lane_to_tile_xy(a.window, wave, lane, lx, ly);
+    const int cx = blockIdx.x * 16 + lx, cy = blockIdx.y * 16 + ly;
+    const bool in = cx < g.lw && cy < g.lh;
+    const E* __restrict__ f1 = (const E*)a.frame1;
+    const int W = g.W, H = g.H, S = g.in_stride;
+    const size_t uv_base = (size_t)H * S;
+
+    // Candidate-independent inputs: own offsets, frame-N samples, the four neighbour offsets.
+    int ox0 = 0, oy0 = 0, nb0 = 0, nb1 = 0, nb2 = 0, nb3 = 0;
+    uint32_t p2 = 0;
+    if (in) {
+        const size_t p = (size_t)cy * g.lw + cx;
+        ox0 = a.off_x[p];
+        oy0 = a.off_y[p];
+        p2 = a.grid2[p];
+        if (a.use_neighbors) {  // calcDeltaSumsKernelSDR.h:112-131, neighbours at +-2*window, clamped
+            const int16_t* __restrict__ plane = a.step ? a.off_y : a.off_x;
+            const int d = 2 * a.window;
+            const int xl = max(cx - d, 0), xr = min(cx + d, g.lw - 1);
+            const int yu = max(cy - d, 0), yd = min(cy + d, g.lh - 1);
+            nb0 = plane[(size_t)yd * g.lw + cx];
+            nb1 = plane[(size_t)cy * g.lw + xr];
+            nb2 = plane[(size_t)cy * g.lw + xl];
+            nb3 = plane[(size_t)yu * g.lw + cx];
+        }
+    }
+    const unsigned y2 = p2 & 0xFFu, u2 = (p2 >> 8) & 0xFFu, v2 = (p2 >> 16) & 0xFFu;
+    const bool valid = (p2 >> 24) != 0;
+    const int sx = cx << g.rs, sy = cy << g.rs;
+    const int searched0 = a.step ? oy0 : ox0;
+
+    uint32_t best_sum = 0xFFFFFFFFu;
+    int best = 0;
+    uint32_t captured = 0;
+
+    for (int c0 = 0; c0 < a.R; c0 += 4) {
+        uint32_t cost[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int cz = min(c0 + k, a.R - 1);  // tail lanes recompute the last candidate (discarded)
+            const int cand = (int)(int16_t)(searched0 + rel_offset(cz, a.R));  // short arithmetic, :75-76
+            uint32_t c = 0;
+            if (in) {
+                int nx = sx + (a.step ? ox0 : cand);
+                int ny = sy + (a.step ? cand : oy0);
+                // single reflection (:86-95); the final clamp only acts where the reference indexes
+                // outside the frame (offsets larger than the frame), keeping the kernel memory-safe
+                if (nx >= W) nx = 2 * W - nx - 1; else if (nx < 0) nx = -nx - 1;
+                if (ny >= H) ny = 2 * H - ny - 1; else if (ny < 0) ny = -ny - 1;
+                nx = clampi(nx, 0, W - 1);
+                ny = clampi(ny, 0, H - 1);
+                if (valid) {
+                    const E* uv = f1 + uv_base + (size_t)(ny >> 1) * S + (nx & ~1);
+                    const unsigned y1 = T::top8(f1[(size_t)ny * S + nx]);
+                    const unsigned u1 = T::top8(uv[0]), v1 = T::top8(uv[1]);
+                    c = (absdiff(y1, y2) + absdiff(u1, u2) + absdiff(v1, v2)) << a.delta_scalar;  // :98-101
+                }
+                c += (uint32_t)(cand < 0 ? -cand : cand) & 0xFFFFu;  // offsetBias, :105-109
+                if (a.use_neighbors) {
+                    const uint32_t nbias = ((uint32_t)abs(nb0 - cand) & 0xFFFFu) + ((uint32_t)abs(nb1 - cand) & 0xFFFFu) +
+                                           ((uint32_t)abs(nb2 - cand) & 0xFFFFu) + ((uint32_t)abs(nb3 - cand) & 0xFFFFu);
+                    c += nbias << a.neighbor_scalar;  // :143
+                }
+            }
+            cost[k] = c;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int cz = c0 + k;
+            if (cz >= a.R) break;  // wave-uniform
+            uint32_t s;
+            if (a.window >= 8) s = group_sum<64>(cost[k]);
+            else if (a.window == 4) s = group_sum<16>(cost[k]);
+            else s = group_sum<4>(cost[k]);
+            if (a.window >= 16) {
+                if (lane == 0) s_part[wave][cz] = s;
+            } else {
+                if (s < best_sum) { best_sum = s; best = cz; }  // strict '<': first minimum wins
+                if (cz == (a.R >> 1) - 1) captured = s;
+            }
+        }
+    }
+
+    if (a.window >= 16) {
+        __syncthreads();
+        if (a.window == 16) {  // the workgroup owns the whole window: finish in place
+            for (int cz = 0; cz < a.R; cz++) {
+                const uint32_t s = s_part[0][cz] + s_part[1][cz] + s_part[2][cz] + s_part[3][cz];
+                if (s < best_sum) { best_sum = s; best = cz; }
+                if (cz == (a.R >> 1) - 1) captured = s;
+            }
+        } else {               // window spans many workgroups: one atomic per candidate per workgroup
+            if (tid < a.R) {
+                const uint32_t s = s_part[0][tid] + s_part[1][tid] + s_part[2][tid] + s_part[3][tid];
+                const int win = ((blockIdx.y * 16) >> a.window_log2) * a.n_win_x + ((blockIdx.x * 16) >> a.window_log2);
+                atomicAdd(&a.sums[win * 16 + tid], s);  // wrapping uint32, like the reference's atomic_add
+            }
+            return;
+        }
+    }
+
+    if (in) {
+        a.off_out[(size_t)cy * g.lw + cx] = (int16_t)(searched0 + rel_offset(best, a.R));
+        if (a.capture_delta && cx == 0 && cy == 0) *a.total_delta = captured / a.delta_divisor;
+    }
+}
+
+// Windows > 16: every 16x16 tile lies inside one window.
+__global__ __launch_bounds__(256) void argmin_adjust_kernel(const Geom g, const StepArgs a) {
+    __shared__ int s_rel;
+    const int tid = threadIdx.x;
+    const int win = ((blockIdx.y * 16) >> a.window_log2) * a.n_win_x + ((blockIdx.x * 16) >> a.window_log2);
+    if (tid == 0) {
+        const uint32_t* s = a.sums + win * 16;
+        uint32_t best_sum = s[0];
+        int best = 0;
+        for (int z = 1; z < a.R; z++) {  // determineLowestLayerKernelSDR.h:19-24
+            const uint32_t v = s[z];
+            if (v < best_sum) { best_sum = v; best = z; }
+        }
+        s_rel = rel_offset(best, a.R);
+        if (a.capture_delta && blockIdx.x == 0 && blockIdx.y == 0)
+            *a.total_delta = s[(a.R >> 1) - 1] / a.delta_divisor;  // opticalFlowCalcSDR.cpp:91-94
+    }
+    __syncthreads();
+    const int cx = blockIdx.x * 16 + (tid & 15), cy = blockIdx.y * 16 + (tid >> 4);
+    if (cx < g.lw && cy < g.lh) {
+        const size_t p = (size_t)cy * g.lw + cx;
+        const int16_t* __restrict__ src = a.step ? a.off_y : a.off_x;
+        a.off_out[p] = (int16_t)(src[p] + s_rel);  // adjustOffsetArrayKernelSDR.h:19
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// blur
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int mirror_flow(int pos, int dim) {  // blurFlowKernelSDR.h:7-14 (+ safety clamp)
+    if (pos >= dim) pos = 2 * dim - pos - 1; else if (pos < 0) pos = -pos - 1;
+    return clampi(pos, 0, dim - 1);
+}
+
+__global__ __launch_bounds__(256) void blur_flow_kernel(const int16_t* __restrict__ off_x, const int16_t* __restrict__ off_y,
+                                                         int16_t* __restrict__ blurred, int lw, int lh, int r) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int T = 16 + 2 * r;                     // tile edge
+    int* rows = (int*)smem;                       // [T][16] horizontal sums
+    int16_t* tile = (int16_t*)(rows + T * 16);    // [T][T]
+    const int tid = threadIdx.x;
+    const int z = blockIdx.z;
+    const int16_t* __restrict__ src = z ? off_y : off_x;
+    const int x0 = blockIdx.x * 16 - r, y0 = blockIdx.y * 16 - r;
+    for (int i = tid; i < T * T; i += 256) {
+        const int ty = i / T, tx = i - ty * T;
+        tile[i] = src[(size_t)mirror_flow(y0 + ty, lh) * lw + mirror_flow(x0 + tx, lw)];
+    }
+    __syncthreads();
+    for (int i = tid; i < T * 16; i += 256) {     // taps -r .. r-1 (blurFlowKernelSDR.h:82-83)
+        const int row = i >> 4, col = i & 15;
+        const int16_t* p = tile + row * T + col;
+        int s = 0;
+        for (int k = 0; k < 2 * r; k++) s += p[k];
+        rows[i] = s;
+    }
+    __syncthreads();
+    const int tx = tid & 15, ty = tid >> 4;
+    const int gx = blockIdx.x * 16 + tx, gy = blockIdx.y * 16 + ty;
+    if (gx < lw && gy < lh) {
+        int s = 0;
+        for (int k = 0; k < 2 * r; k++) s += rows[(ty + k) * 16 + tx];
+        blurred[(size_t)z * lw * lh + (size_t)gy * lw + gx] = (int16_t)(s / (4 * r * r));  // C truncation, :89-90
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// levels / warp / copy
+// ------------------------------------------------------------------------------------------
+struct Levels {
+    float black, white, rcp_y, rcp_uv;
+};
+__device__ __forceinline__ Levels make_levels(float black, float white) {
+    Levels l;
+    l.black = black;
+    l.white = white;
+    l.rcp_y = __builtin_amdgcn_rcpf(white - black);
+    l.rcp_uv = __builtin_amdgcn_rcpf(white);
+    return l;
+}
+template <typename E>
+__device__ __forceinline__ unsigned levels_y(float v, const Levels& l) {  // warpFrameKernelSDR.h:3-5
+    using T = ElemTraits<E>;
+    float f = ((v - l.black) * l.rcp_y) * T::maxv;
+    f = fmaxf(fminf(f, T::maxv), 0.0f);
+    return (unsigned)f & 0xFFFFu;
+}
+template <typename E>
+__device__ __forceinline__ unsigned levels_uv(float v, const Levels& l) {  // warpFrameKernelSDR.h:7-9
+    using T = ElemTraits<E>;
+    float f = __builtin_fmaf((v - T::mid) * l.rcp_uv, T::maxv, T::mid);
+    f = fmaxf(fminf(f, T::maxv), 0.0f);
+    return (unsigned)f & 0xFFFFu;
+}
+
+__device__ __forceinline__ int mirror_warp(int pos, int dim) {  // warpFrameKernelSDR.h:12-20
+    int res = pos;
+    if (pos >= dim - 1) res = pos - ((pos - (dim - 2)) * 2);
+    else if (pos < 1) res = -pos + 1;
+    return min(max(res, 1), dim - 2);
+}
+
+// warpFrameKernelSDR.h:23-113 / HDR :23-113 -- diagnostic HSV visualisation (mode 3)
+template <typename E>
+__device__ unsigned visualize_flow(int ox_in, int oy_in, unsigned curr, int channel, int res_impact) {
+    using T = ElemTraits<E>;
+    const int16_t ox = (int16_t)ox_in, oy = (int16_t)oy_in;
+    unsigned r = 0, gch = 0, b = 0;
+    const unsigned ax = (unsigned)(ox < 0 ? -ox : ox) & 0xFFFFu, ay = (unsigned)(oy < 0 ? -oy : oy) & 0xFFFFu;
+    if (!((float)ax < 1.0f && (float)ay < 1.0f)) {
+        const float angle_rad = atan2f((float)oy, (float)ox);
+        float angle_deg = angle_rad * (180.0f / 3.14159274101257f);
+        if (angle_deg < 0) angle_deg += 360.0f;
+        angle_deg = fmodf(angle_deg, 360.0f);
+        if (angle_deg < 0) angle_deg += 360.0f;
+        const float hue = angle_deg / 360.0f;
+        const int h_i = (int)(hue * 6.0f);
+        const float f = hue * 6.0f - (float)h_i;
+        const float q = 1.0f - f;
+        switch (h_i % 6) {
+            case 0: r = 255; gch = (unsigned)(f * 255.0f) & 0xFFu; b = 0; break;
+            case 1: r = (unsigned)(q * 255.0f) & 0xFFu; gch = 255; b = 0; break;
+            case 2: r = 0; gch = 255; b = (unsigned)(f * 255.0f) & 0xFFu; break;
+            case 3: r = 0; gch = (unsigned)(q * 255.0f) & 0xFFu; b = 255; break;
+            case 4: r = (unsigned)(f * 255.0f) & 0xFFu; gch = 0; b = 255; break;
+            case 5: r = 255; gch = 0; b = (unsigned)(q * 255.0f) & 0xFFu; break;
+            default: break;
+        }
+        const int mag = (int)ax + (int)ay;
+        r = (unsigned)fmaxf(fminf((float)r / 255.0f * (float)mag * (float)res_impact, 255.0f), 0.0f) & 0xFFu;
+        gch = (unsigned)fmaxf(fminf((float)gch / 255.0f * (float)ay * 2.0f * (float)res_impact, 255.0f), 0.0f) & 0xFFu;
+        b = (unsigned)fmaxf(fminf((float)b / 255.0f * (float)mag * (float)res_impact, 255.0f), 0.0f) & 0xFFu;
+    }
+    const float fr = (float)r, fg = (float)gch, fb = (float)b;
+    if (channel == 0) {
+        const unsigned y = (unsigned)fmaxf(fminf(fr * 0.299f + fg * 0.587f + fb * 0.114f, 255.0f), 0.0f);
+        if (T::hdr) return (((y & 0xFFFFu) << 7) + (curr >> 1)) & 0xFFFFu;
+        return (((y & 0xFFu) >> 1) + ((curr & 0xFFu) >> 1)) & 0xFFu;
+    }
+    float c;
+    if (channel == 1) c = fmaxf(fminf(fr * -0.168736f + fg * -0.331264f + fb * 0.5f + 128.0f, 255.0f), 0.0f);
+    else c = fmaxf(fminf(fr * 0.5f + fg * -0.418688f + fb * -0.081312f + 128.0f, 255.0f), 0.0f);
+    if (T::hdr) return (((unsigned)c & 0xFFFFu) << 8) & 0xFFFFu;
+    return (unsigned)c & 0xFFu;
+}
+
+struct WarpArgs {
+    const void* frame12;
+    const void* frame21;
+    const int16_t* flow;   // blurred flow [2][lh][lw]
+    void* out;
+    float s12, s21;        // frameScalar12 = t, frameScalar21 = 1 - t (opticalFlowCalcSDR.cpp:149-150)
+    int mode;
+    float black, white;
+};
+
+// One output element of warpFrameKernel (all modes).
+template <typename E>
+__device__ __forceinline__ unsigned warp_element(const Geom& g, const WarpArgs& a, const Levels& lv, int cz, int cx, int cy) {
+    using T = ElemTraits<E>;
+    const E* __restrict__ A = (const E*)a.frame12;
+    const E* __restrict__ B = (const E*)a.frame21;
+    const int H = g.H, W = g.W, Si = g.in_stride, rs = g.rs, lw = g.lw, lh = g.lh;
+    const size_t plane = (size_t)cz * H * Si;
+    int ax = cx, ay = cy;
+    const int mode = a.mode;
+    if (mode == 5 && cx < (W >> 1)) return A[plane + (size_t)cy * Si + cx];  // :133-135
+    if (mode == 6) {                                                          // :136-150
+        const int vo = (H >> 2) >> cz;
+        const bool in_rows = cy >= vo && cy < vo + (H >> (1 + cz));
+        if (in_rows && cx < (W >> 1)) return A[plane + (size_t)((cy - vo) << 1) * Si + (cx << 1) + (cz ? (cx & 1) : 0)];
+        if (in_rows && cx < W) { ax = (cx - (W >> 1)) << 1; ay = (cy - vo) << 1; }
+        else return cz ? T::midu : 0u;
+    }
+    const size_t N = (size_t)lw * lh;
+    const int lx = cz ? ((ax >> rs) & ~1) : (ax >> rs);   // :153-154
+    const int ly = cz ? ((ay >> rs) << 1) : (ay >> rs);
+    const int ox12 = a.flow[(size_t)ly * lw + lx];
+    const int oy12 = a.flow[N + (size_t)ly * lw + lx];
+    const int py = clampi(ly - (oy12 >> rs), 0, lh - 1);  // arithmetic shift, :157-158
+    const int px = clampi(lx - (ox12 >> rs), 0, lw - 1);
+    const int ox21 = a.flow[(size_t)py * lw + px];
+    const int oy21 = a.flow[N + (size_t)py * lw + px];
+    if (mode == 4) {                                      // :161-164
+        if (cz) return T::midu;
+        const unsigned mag = (unsigned)abs(ox12) + (unsigned)abs(oy12);
+        return T::hdr ? min(mag << 10, 65535u) : min(mag << 2, 255u);
+    }
+    const float hy = cz ? 0.5f : 1.0f;
+    const int dim_y = cz ? (H >> 1) : H;
+    const int x12 = mirror_warp(ax + (int)roundf((float)ox12 * a.s12), W);           // :167-170
+    const int y12 = mirror_warp(ay + (int)roundf((float)oy12 * a.s12 * hy), dim_y);
+    const int x21 = mirror_warp(ax - (int)roundf((float)ox21 * a.s21), W);
+    const int y21 = mirror_warp(ay - (int)roundf((float)oy21 * a.s21 * hy), dim_y);
+    const int par = cz ? (cx & 1) : 0;
+    if (mode == 0) return A[plane + (size_t)y12 * Si + (cz ? (x12 & ~1) : x12) + par];
+    if (mode == 1) return B[plane + (size_t)y21 * Si + (cz ? (x21 & ~1) : x21) + par];
+    const float fa = (float)A[plane + (size_t)y12 * Si + (cz ? (x12 & ~1) : x12) + par];
+    const float fb = (float)B[plane + (size_t)y21 * Si + (cz ? (x21 & ~1) : x21) + par];
+    unsigned blended = (unsigned)__builtin_fmaf(fa, a.s21, fb * a.s12) & 0xFFFFu;     // :176-177 as compiled on gfx950
+    if (mode == 3) blended = visualize_flow<E>(-ox12, -oy12, blended, cz + par, rs <= 2 ? 4 : 1);
+    return cz ? levels_uv<E>((float)blended, lv) : levels_y<E>((float)blended, lv);
+}
+
+// Each thread produces VEC consecutive elements of one row and stores them with one wide store.
+template <typename E, int VEC, bool ALIGNED>
+__global__ __launch_bounds__(256) void warp_kernel(const Geom g, const WarpArgs a) {
+    const int row = blockIdx.y * 4 + (threadIdx.x >> 6);  // 0 .. H + H/2 - 1 : Y rows then UV rows
+    const int cx0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * VEC;
+    const int rows_total = g.H + (g.H >> 1);
+    if (row >= rows_total || cx0 >= g.W) return;
+    const int cz = row >= g.H;
+    const int cy = cz ? row - g.H : row;
+    const Levels lv = make_levels(a.black, a.white);
+    E* __restrict__ out = (E*)a.out + (size_t)cz * g.H * g.out_stride + (size_t)cy * g.out_stride + cx0;
+    if (ALIGNED && cx0 + VEC <= g.W) {
+        static_assert(sizeof(E) * VEC == 16, "one 16-byte store per thread");
+        __attribute__((aligned(16))) E v[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; i++) v[i] = (E)warp_element<E>(g, a, lv, cz, cx0 + i, cy);
+        *(uint4*)out = *(const uint4*)v;
+    } else {
+        for (int i = 0; i < VEC && cx0 + i < g.W; i++) out[i] = (E)warp_element<E>(g, a, lv, cz, cx0 + i, cy);
+    }
+}
+
+template <typename E, int VEC, bool ALIGNED>
+__global__ __launch_bounds__(256) void copy_kernel(const Geom g, const E* __restrict__ src, E* __restrict__ dst,
+                                                    float black, float white) {
+    const int row = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int cx0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * VEC;
+    const int rows_total = g.H + (g.H >> 1);
+    if (row >= rows_total || cx0 >= g.W) return;
+    const int cz = row >= g.H;
+    const Levels lv = make_levels(black, white);
+    const E* __restrict__ s = src + (size_t)row * g.in_stride + cx0;   // UV plane starts at row H
+    E* __restrict__ d = dst + (size_t)row * g.out_stride + cx0;
+    if (ALIGNED && cx0 + VEC <= g.W) {
+        static_assert(sizeof(E) * VEC == 16, "one 16-byte load/store per thread");
+        __attribute__((aligned(16))) E v[VEC];
+        *(uint4*)v = *(const uint4*)s;
+#pragma unroll
+        for (int i = 0; i < VEC; i++) v[i] = (E)(cz ? levels_uv<E>((float)v[i], lv) : levels_y<E>((float)v[i], lv));
+        *(uint4*)d = *(const uint4*)v;
+    } else {
+        for (int i = 0; i < VEC && cx0 + i < g.W; i++)
+            d[i] = (E)(cz ? levels_uv<E>((float)s[i], lv) : levels_y<E>((float)s[i], lv));
+    }
+}
+
+__global__ void rcp_probe_kernel(const float* in, float* out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = __builtin_amdgcn_rcpf(in[i]);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+void launch_decimate(const Geom& g, const void* frame, uint32_t* grid, hipStream_t stream) {
+    const dim3 grd((g.lw + 63) / 64, (g.lh + 3) / 4);
+    if (g.hdr) decimate_kernel<uint16_t><<<grd, 256, 0, stream>>>((const uint16_t*)frame, grid, g.H, g.W, g.in_stride, g.rs, g.lw, g.lh);
+    else decimate_kernel<uint8_t><<<grd, 256, 0, stream>>>((const uint8_t*)frame, grid, g.H, g.W, g.in_stride, g.rs, g.lw, g.lh);
+}
+
+void launch_flow_step(const Geom& g, const StepArgs& a, hipStream_t stream) {
+    const dim3 grd((g.lw + 15) / 16, (g.lh + 15) / 16);
+    if (g.hdr) flow_step_kernel<uint16_t><<<grd, 256, 0, stream>>>(g, a);
+    else flow_step_kernel<uint8_t><<<grd, 256, 0, stream>>>(g, a);
+}
+
+void launch_argmin_adjust(const Geom& g, const StepArgs& a, hipStream_t stream) {
+    const dim3 grd((g.lw + 15) / 16, (g.lh + 15) / 16);
+    argmin_adjust_kernel<<<grd, 256, 0, stream>>>(g, a);
+}
+
+void launch_blur_flow(const Geom& g, const int16_t* off_x, const int16_t* off_y, int16_t* blurred, int radius,
+                      hipStream_t stream) {
+    const dim3 grd((g.lw + 15) / 16, (g.lh + 15) / 16, 2);
+    const int T = 16 + 2 * radius;
+    const size_t smem = (size_t)T * 16 * sizeof(int) + (size_t)T * T * sizeof(int16_t);
+    blur_flow_kernel<<<grd, 256, smem, stream>>>(off_x, off_y, blurred, g.lw, g.lh, radius);
+}
+
+template <typename E>
+static void launch_warp_t(const Geom& g, const WarpArgs& a, hipStream_t stream) {
+    constexpr int VEC = 16 / sizeof(E);  // 16-byte stores
+    const bool aligned = (g.out_stride % VEC) == 0 && (((uintptr_t)a.out) & 15) == 0;
+    const dim3 grd((g.W + 64 * VEC - 1) / (64 * VEC), (g.H + (g.H >> 1) + 3) / 4);
+    if (aligned) warp_kernel<E, VEC, true><<<grd, 256, 0, stream>>>(g, a);
+    else warp_kernel<E, VEC, false><<<grd, 256, 0, stream>>>(g, a);
+}
+
+void launch_warp(const Geom& g, const void* frame12, const void* frame21, const int16_t* flow, void* out, float t,
+                 int mode, float black, float white, hipStream_t stream) {
+    WarpArgs a;
+    a.frame12 = frame12; a.frame21 = frame21; a.flow = flow; a.out = out;
+    a.s12 = t; a.s21 = 1.0f - t; a.mode = mode; a.black = black; a.white = white;
+    if (g.hdr) launch_warp_t<uint16_t>(g, a, stream);
+    else launch_warp_t<uint8_t>(g, a, stream);
+}
+
+template <typename E>
+static void launch_copy_t(const Geom& g, const void* src, void* out, float black, float white, hipStream_t stream) {
+    constexpr int VEC = 16 / sizeof(E);
+    const bool aligned = (g.in_stride % VEC) == 0 && (g.out_stride % VEC) == 0 &&
+                         (((uintptr_t)src | (uintptr_t)out) & 15) == 0;
+    const dim3 grd((g.W + 64 * VEC - 1) / (64 * VEC), (g.H + (g.H >> 1) + 3) / 4);
+    if (aligned) copy_kernel<E, VEC, true><<<grd, 256, 0, stream>>>(g, (const E*)src, (E*)out, black, white);
+    else copy_kernel<E, VEC, false><<<grd, 256, 0, stream>>>(g, (const E*)src, (E*)out, black, white);
+}
+
+void launch_copy(const Geom& g, const void* src, void* out, float black, float white, hipStream_t stream) {
+    if (g.hdr) launch_copy_t<uint16_t>(g, src, out, black, white, stream);
+    else launch_copy_t<uint8_t>(g, src, out, black, white, stream);
+}
+
+void launch_rcp_probe(const float* in, float* out, int n, hipStream_t stream) {
+    rcp_probe_kernel<<<(n + 63) / 64, 64, 0, stream>>>(in, out, n);
+}
+
+}  // namespace hf

@@ -143,6 +143,10 @@ int hf_read_offsets(hf_ctx* ctx, int16_t* host_out);
 int hf_read_blurred_flow(hf_ctx* ctx, int idx, int16_t* host_out);
 int hf_write_blurred_flow(hf_ctx* ctx, int idx, const int16_t* host_in);
 
+/* v_rcp_f32 of the device for n <= 32 values.  The reference's apply_levels* divide through it when
+ * built by AMD OpenCL (x / y -> x * rcp(y)); CPU checkers use this to reproduce levels bit-exactly. */
+int hf_device_rcp(hf_ctx* ctx, const float* host_in, float* host_out, int n);
+
 /* ---- measurement: HIP events on ctx's own stream (torch events cannot see this stream) ---- */
 int hf_timer_begin(hf_ctx* ctx);
 int hf_timer_end(hf_ctx* ctx, float* elapsed_ms); /* synchronises on the end event */

@@ -11,7 +11,7 @@
 #include <string.h>
 
 /* Default = flavour 1/1: bit-exact with the reference as it actually runs on an MI355X through
- * AMD OpenCL (tests/golden/*.npz); flavour 0/0 is the strict-IEEE reading of the same source. */
+ * AMD OpenCL (the tests/golden fixtures); flavour 0/0 is the strict-IEEE reading of the same source. */
 static int g_blend_flavour = 1;
 static int g_levels_flavour = 1;
 void hfo_set_blend_flavour(int f) { g_blend_flavour = f; }

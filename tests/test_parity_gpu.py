@@ -1,0 +1,152 @@
+"""GPU parity: the HIP path (through the C ABI) against (a) the committed golden vectors produced by
+the reference itself and (b) the CPU oracle on seeded inputs.  Bar: bit-exact for the integer flow
+stages, gather modes and copy; bit-exact for blend/levels too (the HIP kernels reproduce the fp32
+operations of the reference's gfx950 OpenCL build); HSV visualisation (mode 3, atan2/fmod) <= 2 LSB
+of 8 bits (<= 2*256 codes in HDR)."""
+import numpy as np
+import pytest
+
+from helpers import ALL_GOLDEN, Golden, parse_frame_name, sha
+
+pytestmark = pytest.mark.gpu
+
+
+def make_calc(case, R, delta, nb, **kw):
+    from hopperrender_amd.calc import OpticalFlowCalcHDR, OpticalFlowCalcSDR
+    cls = OpticalFlowCalcHDR if case["hdr"] else OpticalFlowCalcSDR
+    c = cls(case["H"], case["W"], case["si"], case["so"], delta, nb, 0.0, 255.0, 270, **kw)
+    c.m_opticalFlowSearchRadius = R
+    return c
+
+
+@pytest.mark.parametrize("name", ALL_GOLDEN)
+def test_flow_and_frames_match_reference_golden(native_lib, name):
+    g = Golden(name)
+    frames = g.frames()
+    for key in g.keys:
+        R, delta, nb = g.params(key)
+        c = make_calc(g.case, R, delta, nb)
+        for f in frames[:3]:
+            c.updateFrame(f)
+        c.calculateOpticalFlow()
+        assert c.m_totalFrameDelta == g.meta[key]["stats_a"]["total_frame_delta"]
+        assert (c.readOffsets() == g.arr(key, "off_a")).all(), f"{name} {key}: raw flow differs"
+        assert (c.readBlurredFlow(1) == g.arr(key, "blur_a")).all(), f"{name} {key}: blurred flow differs"
+        c.updateFrame(frames[3])
+        c.calculateOpticalFlow()
+        assert c.m_totalFrameDelta == g.meta[key]["stats_b"]["total_frame_delta"]
+        assert (c.readOffsets() == g.arr(key, "off_b")).all()
+        assert (c.readBlurredFlow(1) == g.arr(key, "blur_b")).all()
+        assert (c.readBlurredFlow(0) == g.arr(key, "blur_a")).all(), "ping-pong: [0] must hold the previous flow"
+        for fname in g.frame_names(key):
+            kind, mode, t, (bk, wh) = parse_frame_name(fname)
+            c.m_outputBlackLevel, c.m_outputWhiteLevel = bk, wh
+            if kind == "warp":
+                c.warpFrames(t, mode)
+            else:
+                c.copyFrame()
+            out = c.downloadFrame()
+            if mode == 3:  # diagnostic HSV (atan2/fmod): tolerance instead of hash
+                if g.has(key, fname):
+                    d = np.abs(out.astype(np.int64) - g.arr(key, fname).astype(np.int64))
+                    assert d.max() <= (2 * 256 if g.case["hdr"] else 2), f"{name} {key} {fname}: max diff {d.max()}"
+                continue
+            assert sha(out) == g.frame_sha(key, fname), f"{name} {key} {fname}: output frame differs from the reference"
+        c.close()
+
+
+def test_eager_and_graph_paths_agree(native_lib):
+    from hopperrender_amd import capi
+    g = Golden("sdr_360p")
+    frames = g.frames()
+    outs = []
+    for flags in (0, capi.HF_FLAG_NO_GRAPH, capi.HF_FLAG_ASYNC):
+        c = make_calc(g.case, 16, 8, 6, flags=flags)
+        for f in frames[:3]:
+            c.updateFrame(f)
+        c.calculateOpticalFlow()
+        c.calculateOpticalFlow()  # second call replays the cached graph
+        c.sync()
+        outs.append((c.readOffsets(), c.readBlurredFlow(1), c.m_totalFrameDelta))
+        c.close()
+    for o in outs[1:]:
+        assert (o[0] == outs[0][0]).all() and (o[1] == outs[0][1]).all() and o[2] == outs[0][2]
+    assert (outs[0][0] == g.arr("R16_d8_n6", "off_a")).all()
+
+
+@pytest.mark.parametrize("hdr,H,W,si,so,R,it,blur", [
+    (0, 36, 64, 0, 0, 16, 0, 4),       # tiny: first window 32
+    (0, 18, 32, 0, 0, 5, 0, 4),        # tiny: first window 16 (single-launch path from step 0)
+    (1, 90, 160, 176, 168, 11, 3, 4),  # runtime `iterations` extension (cfg 1 of BASELINE.json: 3 levels)
+    (0, 360, 640, 0, 0, 16, 3, 4),     # BASELINE config 1: 640x360 SDR, 3-level
+    (1, 360, 640, 0, 0, 16, 0, 16),    # blur radius extension (BASELINE config 5)
+    (0, 270, 480, 0, 0, 13, 0, 32),
+    (0, 1090, 1922, 1984, 1936, 16, 0, 4),  # ragged 1080p-class, rs=3
+])
+def test_flow_matches_oracle_on_seeded_inputs(native_lib, hdr, H, W, si, so, R, it, blur):
+    from hopperrender_amd import synth
+    from oracle import oracle
+    case = dict(hdr=hdr, H=H, W=W, si=si, so=so)
+    sc = synth.Scene(H, W, bool(hdr), seed=77 + H, in_stride=si)
+    f = [sc.frame(k) for k in range(3)]
+    g = oracle.make_geom(hdr, H, W, si, so)
+    off_o, blur_o, tot_o, oob = oracle.calculate_optical_flow(f[1], f[2], g, R, it, 7, 5, blur)
+    c = make_calc(case, R, 7, 5, iterations=it, blur_radius=blur)
+    for x in f:
+        c.updateFrame(x)
+    c.calculateOpticalFlow()
+    if oob == 0:  # inside the reference's defined behaviour
+        assert (c.readOffsets() == off_o).all()
+        assert (c.readBlurredFlow(1) == blur_o).all()
+        assert c.m_totalFrameDelta == tot_o
+    c.calculateOpticalFlow()
+    for t in (0.0, 0.37, 1.0):
+        for mode in (0, 1, 2, 4, 5, 6):
+            c.warpFrames(t, mode)
+            out = c.downloadFrame()
+            ref = oracle.warp_frames(f[0], f[1], c.readBlurredFlow(0), g, t, mode)
+            assert (out == ref).all(), f"warp t={t} mode={mode}"
+    c.copyFrame()
+    assert (c.downloadFrame() == oracle.copy_frame(f[0], g)).all()
+    c.close()
+
+
+def test_levels_match_reference_ramp(native_lib):
+    """Every code value through copyFrame at several level settings, against the reference's output."""
+    import json
+    import os
+    from helpers import GOLDEN_DIR
+    from hopperrender_amd.calc import OpticalFlowCalcHDR, OpticalFlowCalcSDR
+    z = np.load(os.path.join(GOLDEN_DIR, "levels_ramp.npz"))
+    H = W = 256
+    for name in z.files:
+        if name == "meta":
+            continue
+        kind, ph, b, w = name.split("_")
+        hdr, phase, bk, wh = kind == "hdr", int(ph[1:]), float(b[1:]), float(w[1:])
+        n = (H + H // 2) * W
+        a = np.arange(n, dtype=np.uint32)
+        a[H * W:] += phase * (n - H * W)
+        f = (a % 65536).astype(np.uint16) if hdr else (a % 256).astype(np.uint8)
+        c = (OpticalFlowCalcHDR if hdr else OpticalFlowCalcSDR)(H, W, 0, 0, 8, 6, bk, wh, 270)
+        c.updateFrame(f)
+        c.copyFrame()
+        assert (c.downloadFrame() == z[name]).all(), name
+        c.close()
+
+
+def test_error_behaviour(native_lib):
+    from hopperrender_amd.calc import OpticalFlowCalcSDR
+    from hopperrender_amd.capi import HopperFlowError
+    c = OpticalFlowCalcSDR(180, 320)
+    with pytest.raises(HopperFlowError, match="greater than 1.0"):  # opticalFlowCalcSDR.cpp:143-146
+        c.warpFrames(1.5, 2)
+    with pytest.raises(HopperFlowError):
+        OpticalFlowCalcSDR(181, 320)
+    assert c.m_opticalFlowSearchRadius == 5  # MIN_SEARCH_RADIUS (opticalFlowCalcSDR.cpp:216)
+    assert c.m_frameCount == 0
+    c.updateFrame(np.zeros(180 * 320 * 3 // 2, np.uint8))
+    assert c.m_frameCount == 1
+    c.m_frameCount = 0  # NewSegment (HopperRender.cpp:840)
+    assert c.m_frameCount == 0
+    c.close()
