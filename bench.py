@@ -1,0 +1,264 @@
+#!/usr/bin/env python3
+"""bench.py -- interpolated frames/s (+ ms per flow calc) of the HIP OpticalFlowCalc path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload hdr2160_24to120] [--radius 16]
+    (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A STEP = one source-frame period for every one of the `--streams` independent frame-pair streams a
+rank owns: upload-free updateFrame (device-resident source frame -> ring), calculateOpticalFlow
+(16-step refinement + blur), then the warpFrames(t, BlendedFrame) calls the reference filter would
+issue for that period (24->120 fps: 5 or 6 outputs, reference HopperRender.cpp:944-948,1192-1197),
+each into its own output frame in HBM.  Streams are independent (flow has no temporal state), so
+ranks shard them with NO collective: weak scaling.
+
+One JSON line on rank 0.  `roofline` prices the dominant kernel (warp_kernel, HBM-bound) from HIP
+events recorded on the kernels' own streams during the timed region; `cpu_baseline` times the plain-C
+oracle port on a bounded sample; `reference_opencl` times the reference's own OpenCL path
+(oracle/_ref) on the same GPU when it is available.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (hdr, H, W, target frame time in 100ns units, description)   source = 23.976 fps
+    "hdr2160_24to120": (1, 2160, 3840, 83333, "3840x2160 HDR (P010), 24->120 fps, R=16, full pyramid, blend"),
+    "sdr1080_24to60": (0, 1080, 1920, 166667, "1920x1080 SDR (NV12), 24->60 fps, R=16, full pyramid, blend"),
+    "hdr2160_24to60": (1, 2160, 3840, 166667, "3840x2160 HDR (P010), 24->60 fps"),
+    "sdr1080_24to120": (0, 1080, 1920, 83333, "1920x1080 SDR (NV12), 24->120 fps"),
+    "sdr360_24to60": (0, 360, 640, 166667, "640x360 SDR, 24->60 fps (plumbing size)"),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="hdr2160_24to120", choices=sorted(WORKLOADS))
+    ap.add_argument("--radius", type=int, default=16)
+    ap.add_argument("--neighbor", type=int, default=6)
+    ap.add_argument("--blur-radius", type=int, default=4)
+    ap.add_argument("--streams", type=int, default=4, help="independent frame-pair streams per GPU")
+    ap.add_argument("--pool", type=int, default=6, help="distinct synthetic source frames resident in HBM")
+    ap.add_argument("--no-profile", action="store_true", help="no per-kernel HIP events in the timed region")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-reference", action="store_true")
+    ap.add_argument("--cpu-sample-pairs", type=int, default=2)
+    return ap.parse_args()
+
+
+def cpu_baseline(hdr, H, W, target, radius, neighbor, frames, n_pairs):
+    """The oracle port (single thread) on a bounded sample of the same workload."""
+    from hopperrender_amd.protocol import SOURCE_24, BlendSchedule
+    from oracle import oracle
+    g = oracle.make_geom(hdr, H, W)
+    plan = BlendSchedule(SOURCE_24, target).plan(n_pairs + 1)[1:]
+    t0 = time.perf_counter()
+    outs = 0
+    flow_s = 0.0
+    for i in range(n_pairs):
+        f0, f1, f2 = frames[i % len(frames)], frames[(i + 1) % len(frames)], frames[(i + 2) % len(frames)]
+        tf = time.perf_counter()
+        _, blur, _, _ = oracle.calculate_optical_flow(f1, f2, g, radius, 0, 8, neighbor, 4)
+        flow_s += time.perf_counter() - tf
+        for t in plan[i]:
+            oracle.warp_frames(f0, f1, blur, g, t, 2)
+            outs += 1
+    dt = time.perf_counter() - t0
+    return {"value": outs / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "ms_per_flow_calc": 1e3 * flow_s / n_pairs,
+            "sample": f"{n_pairs} source pairs ({outs} output frames) of the same workload, oracle/hf_oracle.c, 1 thread, {dt:.1f} s"}
+
+
+def reference_opencl(hdr, H, W, target, radius, neighbor, frames):
+    """The reference's own OpenCL path on this GPU (child process; outside the timed region)."""
+    from hopperrender_amd.protocol import SOURCE_24
+    from oracle import oracle
+    if not oracle.ref_available():
+        return None
+    s = oracle.RefSession(hdr, H, W, 0, 0, 8, neighbor, 0.0, 255.0, 270)
+    s.radius(radius)
+    for f in frames[:4]:
+        s.update(f)
+    s.calc(); s.calc()
+    s.time_calc(200); s.time_warp(400, 0.3996, 2)
+    js, _ = s.run(timeout=300)
+    calc_ms, warp_ms = js[0]["time_calc_ms"], js[1]["time_warp_ms"]
+    k = SOURCE_24 / target
+    return {"ms_per_flow_calc": calc_ms, "ms_per_warp": warp_ms, "frames_per_s": 1e3 * k / (calc_ms + k * warp_ms),
+            "note": "reference host code + OpenCL kernels (oracle/_ref) on the same MI355X, device time of "
+                    "back-to-back calculateOpticalFlow / warpFrames calls, no host transfers"}
+
+
+def main():
+    a = parse_args()
+    import numpy as np
+    import torch  # first: one HIP runtime for the whole process
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    n_gpus = world
+    if a.gpus != n_gpus and rank == 0 and world > 1:
+        print(f"warning: --gpus {a.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+
+    import __graft_entry__
+    __graft_entry__.build(quiet=True)
+    from hopperrender_amd import capi, synth
+    from hopperrender_amd.calc import DeviceBuffer, OpticalFlowCalcHDR, OpticalFlowCalcSDR
+    from hopperrender_amd.protocol import SOURCE_24, BlendSchedule
+
+    hdr, H, W, target, desc = WORKLOADS[a.workload]
+    dev = local_rank
+
+    # ---- synthetic source frames, resident in HBM before the timed region ----
+    scene = synth.Scene(H, W, bool(hdr), seed=1234 + rank)
+    host_frames = [scene.frame(k) for k in range(a.pool)]
+    pool = []
+    for f in host_frames:
+        b = DeviceBuffer(f.nbytes, dev)
+        b.upload(f)
+        pool.append(b)
+
+    flags = capi.HF_FLAG_ASYNC | (0 if a.no_profile else capi.HF_FLAG_PROFILE)
+    cls = OpticalFlowCalcHDR if hdr else OpticalFlowCalcSDR
+    calcs, outbufs, plans = [], [], []
+    total_steps = a.warmup + a.steps
+    max_out = 6 if target == 83333 else 3
+    for s in range(a.streams):
+        c = cls(H, W, 0, 0, 8, a.neighbor, 0.0, 255.0, 270, device_index=dev, search_radius=a.radius,
+                blur_radius=a.blur_radius, flags=flags)
+        calcs.append(c)
+        outbufs.append([DeviceBuffer(c.output_frame_bytes, dev) for _ in range(max_out)])
+        plans.append(BlendSchedule(SOURCE_24, target).plan(total_steps + 3)[3:])
+        for k in range(3):  # prime the 3-frame ring and the previous-flow slot (m_frameCount >= 3)
+            c.updateFrameDevice(pool[(s + k) % a.pool].ptr)
+        c.calculateOpticalFlow()
+        c.sync()
+
+    def run_step(i):
+        n = 0
+        for s, c in enumerate(calcs):
+            c.updateFrameDevice(pool[(s + 3 + i) % a.pool].ptr)
+            c.calculateOpticalFlow()
+            for j, t in enumerate(plans[s][i]):
+                c.setOutputBuffer(outbufs[s][j].ptr)
+                c.warpFrames(t, 2)
+                n += 1
+        return n
+
+    def sync_all():
+        for c in calcs:
+            c.sync()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        run_step(i)
+    sync_all()
+    for c in calcs:
+        if not a.no_profile:
+            c.resetProfile()
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    frames_out = 0
+    for i in range(a.warmup, a.warmup + a.steps):
+        frames_out += run_step(i)
+    sync_all()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+
+    tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    ft = torch.tensor([float(frames_out)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ft, op=dist.ReduceOp.SUM)
+    elapsed_max, frames_total = float(tt.item()), float(ft.item())
+
+    prof = {"warp_launches": 0, "warp_ms": 0.0, "flow_chains": 0, "flow_ms": 0.0}
+    if not a.no_profile:
+        for c in calcs:
+            p = c.profile()
+            for k in prof:
+                prof[k] += p[k]
+
+    if rank == 0:
+        st = calcs[0].stats()
+        N = st["low_width"] * st["low_height"]
+        bpp = 2 if hdr else 1
+        F = st["output_frame_bytes"]
+        b_out = 3 * F + 4 * N  # read 2 source frames + write 1 + blurred flow once
+        roof = None
+        if prof["warp_launches"]:
+            avg_ms = prof["warp_ms"] / prof["warp_launches"]
+            achieved = b_out / (avg_ms * 1e-3) / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath)).get(a.workload, {}).get("warp_kernel_hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            roof = {"bound": "hbm", "kernel": "warp_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "algorithmic_bytes_per_launch": b_out, "avg_launch_us": round(avg_ms * 1e3, 2),
+                    "launches": prof["warp_launches"],
+                    "frac_of_measured_copy_bw_6290": round(achieved / 6290.0, 4)}
+        out = {
+            "metric": "interpolated frames/sec + ms/flow-calc, 2160p HDR, 1/2/4/8 MI355X",
+            "value": round(frames_total / elapsed_max, 1),
+            "unit": "frames/s",
+            "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(1e3 * elapsed_max / a.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u16" if hdr else "u8", "data": "synthetic",
+            "config": {"workload": a.workload, "description": desc, "search_radius": a.radius,
+                       "delta_scalar": 8, "neighbor_scalar": a.neighbor, "blur_radius": a.blur_radius,
+                       "pair_streams_per_gpu": a.streams, "source_periods_per_step": a.streams,
+                       "output_frames_total": int(frames_total), "parallelism": f"pair-sharded x{n_gpus}, no collective",
+                       "frame_bytes": F, "flow_grid": [st["low_width"], st["low_height"]], "res_scalar": st["res_scalar"]},
+            "ms_per_flow_calc": round(prof["flow_ms"] / prof["flow_chains"], 4) if prof["flow_chains"] else None,
+            "ms_per_flow_calc_note": "device time of one refinement chain + blur while the other pair streams keep the GPU busy",
+            "roofline": roof,
+        }
+        if not a.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(hdr, H, W, target, a.radius, a.neighbor, host_frames, a.cpu_sample_pairs)
+                out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+            except Exception as e:  # the checker must never take the measurement down
+                out["cpu_baseline"] = {"error": repr(e)}
+        if not a.no_reference:
+            try:
+                r = reference_opencl(hdr, H, W, target, a.radius, a.neighbor, host_frames)
+                if r:
+                    out["reference_opencl"] = r
+                    out["speedup_vs_reference_opencl"] = round(out["value"] / n_gpus / r["frames_per_s"], 2)
+            except Exception as e:
+                out["reference_opencl"] = {"error": repr(e)}
+        print(json.dumps(out), flush=True)
+
+    for c in calcs:
+        c.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

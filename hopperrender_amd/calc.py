@@ -140,6 +140,15 @@ class OpticalFlowCalc:
         capi.check(self._lib.hf_timer_end(self._ctx, C.byref(ms)), self._ctx)
         return ms.value
 
+    def profile(self):
+        """Device-time totals since resetProfile() (needs flags=HF_FLAG_PROFILE)."""
+        pr = capi.HfProfile()
+        capi.check(self._lib.hf_get_profile(self._ctx, C.byref(pr)), self._ctx)
+        return {k: getattr(pr, k) for k, _ in pr._fields_}
+
+    def resetProfile(self):
+        capi.check(self._lib.hf_reset_profile(self._ctx), self._ctx)
+
     # ---- parity taps ----
     def readOffsets(self):
         a = np.empty((2, self.m_opticalFlowFrameHeight, self.m_opticalFlowFrameWidth), dtype=np.int16)

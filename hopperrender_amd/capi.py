@@ -10,6 +10,7 @@ from . import build as _build
 
 HF_FLAG_ASYNC = 0x1
 HF_FLAG_NO_GRAPH = 0x2
+HF_FLAG_PROFILE = 0x4
 
 (HF_OK, HF_ERR_INVALID_ARGUMENT, HF_ERR_NO_DEVICE, HF_ERR_OUT_OF_MEMORY, HF_ERR_HIP, HF_ERR_STATE) = (0, -1, -2, -3, -4, -5)
 
@@ -37,6 +38,11 @@ class HfStats(C.Structure):
                 ("input_frame_bytes", C.c_uint64), ("output_frame_bytes", C.c_uint64)]
 
 
+class HfProfile(C.Structure):
+    _fields_ = [("warp_launches", C.c_uint64), ("warp_ms", C.c_double), ("copy_launches", C.c_uint64),
+                ("copy_ms", C.c_double), ("flow_chains", C.c_uint64), ("flow_ms", C.c_double)]
+
+
 # name -> (restype, argtypes); must list every symbol include/hopperflow.h declares (tests check this)
 _vp, _i, _f = C.c_void_p, C.c_int, C.c_float
 SIGNATURES = {
@@ -60,6 +66,8 @@ SIGNATURES = {
     "hf_read_blurred_flow": (_i, [_vp, _i, _vp]),
     "hf_write_blurred_flow": (_i, [_vp, _i, _vp]),
     "hf_device_rcp": (_i, [_vp, _vp, _vp, _i]),
+    "hf_get_profile": (_i, [_vp, C.POINTER(HfProfile)]),
+    "hf_reset_profile": (_i, [_vp]),
     "hf_timer_begin": (_i, [_vp]),
     "hf_timer_end": (_i, [_vp, C.POINTER(C.c_float)]),
     "hf_device_count": (_i, []),

@@ -21,6 +21,7 @@
 #include <new>
 #include <string>
 #include <tuple>
+#include <vector>
 
 #include "../../include/hopperflow.h"
 #include "hf_kernels.h"
@@ -77,6 +78,13 @@ struct hf_ctx {
     bool upload_recorded = false, flow_timing_pending = false, warp_started = false;
 
     std::map<std::tuple<int, int, int, int, int>, hipGraphExec_t> graphs;
+
+    // HF_FLAG_PROFILE: event pairs around warp / copy / flow-chain launches
+    struct Span { hipEvent_t b, e; int kind; };
+    std::vector<hipEvent_t> ev_pool;
+    std::vector<Span> spans;
+    hf_profile prof{};
+    bool profiling() const { return (cfg.flags & HF_FLAG_PROFILE) != 0; }
 
     bool async() const { return (cfg.flags & HF_FLAG_ASYNC) != 0; }
 };
@@ -203,8 +211,42 @@ void finish_flow_timing(hf_ctx* c) {
     if (c->ofc_calc_time > c->ofc_peak) c->ofc_peak = c->ofc_calc_time;
 }
 
+hipEvent_t pool_event(hf_ctx* c) {
+    if (!c->ev_pool.empty()) { hipEvent_t e = c->ev_pool.back(); c->ev_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+// Opens a profiled span on the stream; returns the index of the span or -1.
+int span_begin(hf_ctx* c, int kind) {
+    if (!c->profiling()) return -1;
+    hf_ctx::Span s{pool_event(c), pool_event(c), kind};
+    if (!s.b || !s.e) return -1;
+    hipEventRecord(s.b, c->stream);
+    c->spans.push_back(s);
+    return (int)c->spans.size() - 1;
+}
+void span_end(hf_ctx* c, int idx) {
+    if (idx >= 0) hipEventRecord(c->spans[idx].e, c->stream);
+}
+void collect_spans(hf_ctx* c) {  // stream must be idle
+    for (auto& s : c->spans) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s.b, s.e) == hipSuccess) {
+            if (s.kind == 0) { c->prof.warp_launches++; c->prof.warp_ms += ms; }
+            else if (s.kind == 1) { c->prof.copy_launches++; c->prof.copy_ms += ms; }
+            else { c->prof.flow_chains++; c->prof.flow_ms += ms; }
+        }
+        c->ev_pool.push_back(s.b);
+        c->ev_pool.push_back(s.e);
+    }
+    c->spans.clear();
+}
+
 int sync_ctx(hf_ctx* c) {
     HF_HIP(c, hipStreamSynchronize(c->stream));
+    collect_spans(c);
     if (c->delta_pending) { c->total_frame_delta = *c->h_total_delta; c->delta_pending = false; }
     finish_flow_timing(c);
     return HF_OK;
@@ -360,6 +402,8 @@ void hf_destroy(hf_ctx* c) {
     if (c->d_total_delta) hipFree(c->d_total_delta);
     if (c->d_probe) hipFree(c->d_probe);
     if (c->h_total_delta) hipHostFree(c->h_total_delta);
+    for (auto& sp : c->spans) { hipEventDestroy(sp.b); hipEventDestroy(sp.e); }
+    for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
     hipEvent_t evs[] = {c->ev_upload, c->ev_flow_end, c->ev_warp_start, c->ev_warp_end, c->ev_user0, c->ev_user1};
     for (hipEvent_t e : evs) if (e) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -386,7 +430,9 @@ int hf_calculate_optical_flow(hf_ctx* c) {
     if (c->p.delta_scalar < 0 || c->p.delta_scalar > 24 || c->p.neighbor_scalar < 0 || c->p.neighbor_scalar > 24)
         return fail(c, HF_ERR_INVALID_ARGUMENT, "calculateOpticalFlow: delta/neighbor scalar outside [0, 24]");
 
+    int span = -1;
     if (c->cfg.flags & HF_FLAG_NO_GRAPH) {
+        span = span_begin(c, 2);
         if (int rc = enqueue_flow_chain(c)) return rc;
     } else {
         const auto key = std::make_tuple(c->ring_phase, c->blur_phase, R, c->p.delta_scalar, c->p.neighbor_scalar);
@@ -416,8 +462,10 @@ int hf_calculate_optical_flow(hf_ctx* c) {
             c->off_cur[0] = iters & 1;
             c->off_cur[1] = iters & 1;
         }
+        span = span_begin(c, 2);
         HF_HIP(c, hipGraphLaunch(it->second, c->stream));
     }
+    span_end(c, span);
     HF_HIP(c, hipEventRecord(c->ev_flow_end, c->stream));
     c->delta_pending = c->last_iterations > 0;
     c->flow_timing_pending = true;
@@ -439,8 +487,10 @@ int hf_warp_frames(hf_ctx* c, float t, int mode) {
     const float scale = c->g.hdr ? 256.0f : 1.0f;  // opticalFlowCalcHDR.cpp:151-152
     if (!c->warp_started) { HF_HIP(c, hipEventRecord(c->ev_warp_start, c->stream)); c->warp_started = true; }
     // frames N-2 / N-1 and the PREVIOUS flow (:154-156)
+    const int span = span_begin(c, 0);
     hf::launch_warp(c->g, c->ring[0], c->ring[1], c->blurred[0], c->out_target, t, mode,
                     c->p.black_level * scale, c->p.white_level * scale, c->stream);
+    span_end(c, span);
     HF_HIP(c, hipGetLastError());
     return HF_OK;
 }
@@ -451,7 +501,9 @@ int hf_copy_frame(hf_ctx* c) {
     const float scale = c->g.hdr ? 256.0f : 1.0f;  // opticalFlowCalcHDR.cpp:173-174
     const int idx = c->p.frame_count >= 3 ? 0 : c->p.frame_count >= 2 ? 1 : 2;  // opticalFlowCalcSDR.cpp:173
     if (!c->warp_started) { HF_HIP(c, hipEventRecord(c->ev_warp_start, c->stream)); c->warp_started = true; }
+    const int span = span_begin(c, 1);
     hf::launch_copy(c->g, c->ring[idx], c->out_target, c->p.black_level * scale, c->p.white_level * scale, c->stream);
+    span_end(c, span);
     HF_HIP(c, hipGetLastError());
     return HF_OK;
 }
@@ -528,6 +580,23 @@ int hf_get_stats(hf_ctx* c, hf_stats* out) {
     out->initial_window = c->initial_window;
     out->input_frame_bytes = c->in_bytes;
     out->output_frame_bytes = c->out_bytes;
+    return HF_OK;
+}
+
+int hf_get_profile(hf_ctx* c, hf_profile* out) {
+    HF_CHECK_CTX(c);
+    if (!out) return fail(c, HF_ERR_INVALID_ARGUMENT, "hf_get_profile: null");
+    if (int rc = set_device(c)) return rc;
+    if (int rc = sync_ctx(c)) return rc;
+    *out = c->prof;
+    return HF_OK;
+}
+
+int hf_reset_profile(hf_ctx* c) {
+    HF_CHECK_CTX(c);
+    if (int rc = set_device(c)) return rc;
+    if (int rc = sync_ctx(c)) return rc;
+    c->prof = hf_profile{};
     return HF_OK;
 }
 

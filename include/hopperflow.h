@@ -53,6 +53,8 @@ typedef enum hf_output_mode {
 #define HF_FLAG_ASYNC 0x1 /* calls only enqueue; results/timings valid after hf_sync(). Default: every
                              call blocks like the reference (CL_TRUE transfers, clWaitForEvents). */
 #define HF_FLAG_NO_GRAPH 0x2 /* launch the flow chain eagerly instead of replaying a hipGraph (debug) */
+#define HF_FLAG_PROFILE 0x4  /* bracket every warp/copy launch and every flow chain with HIP events on ctx's
+                                stream; totals are read with hf_get_profile() (bench.py's live roofline figure) */
 
 /* The nine constructor arguments of OpticalFlowCalcSDR/HDR (opticalFlowCalcSDR.cpp:206-208)
  * plus build-side extensions (0 selects the reference behaviour for each). */
@@ -150,6 +152,18 @@ int hf_device_rcp(hf_ctx* ctx, const float* host_in, float* host_out, int n);
 /* ---- measurement: HIP events on ctx's own stream (torch events cannot see this stream) ---- */
 int hf_timer_begin(hf_ctx* ctx);
 int hf_timer_end(hf_ctx* ctx, float* elapsed_ms); /* synchronises on the end event */
+
+/* Per-kernel device time accumulated since the last hf_reset_profile() (needs HF_FLAG_PROFILE). */
+typedef struct hf_profile {
+    uint64_t warp_launches;   /* warp_kernel launches (one per warpFrames: both planes) */
+    double warp_ms;           /* summed device time of those launches */
+    uint64_t copy_launches;
+    double copy_ms;
+    uint64_t flow_chains;     /* calculateOpticalFlow chains (16 steps + blur) */
+    double flow_ms;           /* summed device time first kernel start -> blur end */
+} hf_profile;
+int hf_get_profile(hf_ctx* ctx, hf_profile* out); /* synchronises ctx */
+int hf_reset_profile(hf_ctx* ctx);
 
 /* ---- plain device-memory helpers so non-HIP hosts (ctypes, cgo, JNI) can stage frames ---- */
 int hf_device_count(void);
