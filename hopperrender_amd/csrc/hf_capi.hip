@@ -59,6 +59,7 @@ struct hf_ctx {
     int16_t* off[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [axis][ping-pong] m_offsetArray
     int off_cur[2] = {0, 0};
     int16_t* blurred[2] = {nullptr, nullptr};          // m_blurredOffsetArray
+    uint32_t* blurred_xy[2] = {nullptr, nullptr};      // the same flow packed x | y << 16 (fast warp path)
     uint32_t* sums = nullptr;                          // [kMaxSteps][n_windows_max][16]
     size_t sums_bytes = 0;
     size_t sums_stride = 0;                            // elements per step
@@ -187,7 +188,7 @@ int enqueue_flow_chain(hf_ctx* c) {
     }
     c->off_cur[0] = cur[0];
     c->off_cur[1] = cur[1];
-    hf::launch_blur_flow(g, c->off[0][cur[0]], c->off[1][cur[1]], c->blurred[0], c->cfg.blur_radius, s);  // :115-116
+    hf::launch_blur_flow(g, c->off[0][cur[0]], c->off[1][cur[1]], c->blurred[0], c->blurred_xy[0], c->cfg.blur_radius, s);  // :115-116
     HF_HIP(c, hipMemcpyAsync(c->h_total_delta, c->d_total_delta, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HF_HIP(c, hipGetLastError());
     return HF_OK;
@@ -370,6 +371,8 @@ int hf_create(const hf_config* cfg, hf_ctx** out_ctx) {
     for (int i = 0; i < 2; i++) {
         HF_TRY(hipMalloc((void**)&c->blurred[i], 2 * c->plane_elems * sizeof(int16_t)));
         HF_TRY(hipMemsetAsync(c->blurred[i], 0, 2 * c->plane_elems * sizeof(int16_t), c->stream));
+        HF_TRY(hipMalloc((void**)&c->blurred_xy[i], c->plane_elems * sizeof(uint32_t)));
+        HF_TRY(hipMemsetAsync(c->blurred_xy[i], 0, c->plane_elems * sizeof(uint32_t), c->stream));
     }
     HF_TRY(hipMalloc((void**)&c->sums, c->sums_bytes));
     HF_TRY(hipMalloc((void**)&c->d_total_delta, sizeof(uint32_t)));
@@ -397,7 +400,7 @@ void hf_destroy(hf_ctx* c) {
     for (int i = 0; i < 3; i++) { if (c->ring[i]) hipFree(c->ring[i]); if (c->grid[i]) hipFree(c->grid[i]); }
     if (c->out_frame) hipFree(c->out_frame);
     for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++) if (c->off[a][b]) hipFree(c->off[a][b]);
-    for (int i = 0; i < 2; i++) if (c->blurred[i]) hipFree(c->blurred[i]);
+    for (int i = 0; i < 2; i++) { if (c->blurred[i]) hipFree(c->blurred[i]); if (c->blurred_xy[i]) hipFree(c->blurred_xy[i]); }
     if (c->sums) hipFree(c->sums);
     if (c->d_total_delta) hipFree(c->d_total_delta);
     if (c->d_probe) hipFree(c->d_probe);
@@ -473,6 +476,9 @@ int hf_calculate_optical_flow(hf_ctx* c) {
     int16_t* t = c->blurred[0];
     c->blurred[0] = c->blurred[1];
     c->blurred[1] = t;
+    uint32_t* txy = c->blurred_xy[0];
+    c->blurred_xy[0] = c->blurred_xy[1];
+    c->blurred_xy[1] = txy;
     c->blur_phase ^= 1;
     c->have_flow = true;
     if (!c->async()) return sync_ctx(c);
@@ -488,7 +494,7 @@ int hf_warp_frames(hf_ctx* c, float t, int mode) {
     if (!c->warp_started) { HF_HIP(c, hipEventRecord(c->ev_warp_start, c->stream)); c->warp_started = true; }
     // frames N-2 / N-1 and the PREVIOUS flow (:154-156)
     const int span = span_begin(c, 0);
-    hf::launch_warp(c->g, c->ring[0], c->ring[1], c->blurred[0], c->out_target, t, mode,
+    hf::launch_warp(c->g, c->ring[0], c->ring[1], c->blurred[0], c->blurred_xy[0], c->out_target, t, mode,
                     c->p.black_level * scale, c->p.white_level * scale, c->stream);
     span_end(c, span);
     HF_HIP(c, hipGetLastError());
@@ -626,6 +632,8 @@ int hf_write_blurred_flow(hf_ctx* c, int idx, const int16_t* host_in) {
     if (int rc = set_device(c)) return rc;
     if (int rc = sync_ctx(c)) return rc;
     HF_HIP(c, hipMemcpy(c->blurred[idx], host_in, 2 * c->plane_elems * sizeof(int16_t), hipMemcpyHostToDevice));
+    hf::launch_pack_flow(c->g, c->blurred[idx], c->blurred_xy[idx], c->stream);
+    HF_HIP(c, hipStreamSynchronize(c->stream));
     return HF_OK;
 }
 

@@ -46,11 +46,13 @@ void launch_flow_step(const Geom& g, const StepArgs& a, hipStream_t stream);
 // Windows > 16: argmin over the summed costs + offset update of every pixel of the window.
 void launch_argmin_adjust(const Geom& g, const StepArgs& a, hipStream_t stream);
 // blurFlowKernel with a runtime radius (4 == reference); in: two planes, out: [2][lh][lw].
-void launch_blur_flow(const Geom& g, const int16_t* off_x, const int16_t* off_y, int16_t* blurred,
+// Also writes `packed` = x | y << 16 per grid point (what the fast warp kernel reads).
+void launch_blur_flow(const Geom& g, const int16_t* off_x, const int16_t* off_y, int16_t* blurred, uint32_t* packed,
                       int radius, hipStream_t stream);
+void launch_pack_flow(const Geom& g, const int16_t* flow, uint32_t* packed, hipStream_t stream);
 // warpFrameKernel, both planes in one launch.  black/white already scaled for HDR.
-void launch_warp(const Geom& g, const void* frame12, const void* frame21, const int16_t* flow, void* out,
-                 float t, int mode, float black, float white, hipStream_t stream);
+void launch_warp(const Geom& g, const void* frame12, const void* frame21, const int16_t* flow, const uint32_t* flow_xy,
+                 void* out, float t, int mode, float black, float white, hipStream_t stream);
 // copyFrameKernel, both planes in one launch.
 void launch_copy(const Geom& g, const void* src, void* out, float black, float white, hipStream_t stream);
 // v_rcp_f32 of the device (parity tooling: the reference's levels use it through OpenCL's fdiv).

@@ -19,6 +19,8 @@
 // division in apply_levels* is x * v_rcp_f32(y); "q*max + mid" is fma(q, max, mid).
 #include "hf_kernels.h"
 
+#include <cstdlib>
+
 namespace hf {
 
 namespace {
@@ -249,36 +251,51 @@ __device__ __forceinline__ int mirror_flow(int pos, int dim) {  // blurFlowKerne
     return clampi(pos, 0, dim - 1);
 }
 
+// Both planes per workgroup (sequentially through the same LDS tile) so that the kernel can also
+// emit the packed (x | y << 16) copy of the blurred flow that warp_fast_kernel reads with one load.
 __global__ __launch_bounds__(256) void blur_flow_kernel(const int16_t* __restrict__ off_x, const int16_t* __restrict__ off_y,
-                                                         int16_t* __restrict__ blurred, int lw, int lh, int r) {
+                                                         int16_t* __restrict__ blurred, uint32_t* __restrict__ packed,
+                                                         int lw, int lh, int r) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int T = 16 + 2 * r;                     // tile edge
     int* rows = (int*)smem;                       // [T][16] horizontal sums
     int16_t* tile = (int16_t*)(rows + T * 16);    // [T][T]
     const int tid = threadIdx.x;
-    const int z = blockIdx.z;
-    const int16_t* __restrict__ src = z ? off_y : off_x;
     const int x0 = blockIdx.x * 16 - r, y0 = blockIdx.y * 16 - r;
-    for (int i = tid; i < T * T; i += 256) {
-        const int ty = i / T, tx = i - ty * T;
-        tile[i] = src[(size_t)mirror_flow(y0 + ty, lh) * lw + mirror_flow(x0 + tx, lw)];
-    }
-    __syncthreads();
-    for (int i = tid; i < T * 16; i += 256) {     // taps -r .. r-1 (blurFlowKernelSDR.h:82-83)
-        const int row = i >> 4, col = i & 15;
-        const int16_t* p = tile + row * T + col;
-        int s = 0;
-        for (int k = 0; k < 2 * r; k++) s += p[k];
-        rows[i] = s;
-    }
-    __syncthreads();
     const int tx = tid & 15, ty = tid >> 4;
     const int gx = blockIdx.x * 16 + tx, gy = blockIdx.y * 16 + ty;
-    if (gx < lw && gy < lh) {
+    int res[2] = {0, 0};
+    for (int z = 0; z < 2; z++) {
+        const int16_t* __restrict__ src = z ? off_y : off_x;
+        if (z) __syncthreads();
+        for (int i = tid; i < T * T; i += 256) {
+            const int py = i / T, px = i - py * T;
+            tile[i] = src[(size_t)mirror_flow(y0 + py, lh) * lw + mirror_flow(x0 + px, lw)];
+        }
+        __syncthreads();
+        for (int i = tid; i < T * 16; i += 256) {     // taps -r .. r-1 (blurFlowKernelSDR.h:82-83)
+            const int row = i >> 4, col = i & 15;
+            const int16_t* p = tile + row * T + col;
+            int s = 0;
+            for (int k = 0; k < 2 * r; k++) s += p[k];
+            rows[i] = s;
+        }
+        __syncthreads();
         int s = 0;
         for (int k = 0; k < 2 * r; k++) s += rows[(ty + k) * 16 + tx];
-        blurred[(size_t)z * lw * lh + (size_t)gy * lw + gx] = (int16_t)(s / (4 * r * r));  // C truncation, :89-90
+        res[z] = (int)(int16_t)(s / (4 * r * r));      // C truncation, :89-90
     }
+    if (gx < lw && gy < lh) {
+        const size_t p = (size_t)gy * lw + gx;
+        blurred[p] = (int16_t)res[0];
+        blurred[(size_t)lw * lh + p] = (int16_t)res[1];
+        packed[p] = ((uint32_t)res[0] & 0xFFFFu) | ((uint32_t)res[1] << 16);
+    }
+}
+
+__global__ void pack_flow_kernel(const int16_t* __restrict__ flow, uint32_t* __restrict__ packed, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) packed[i] = ((uint32_t)flow[i] & 0xFFFFu) | ((uint32_t)(uint16_t)flow[n + i] << 16);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -365,6 +382,7 @@ struct WarpArgs {
     const void* frame12;
     const void* frame21;
     const int16_t* flow;   // blurred flow [2][lh][lw]
+    const uint32_t* flow_xy; // same flow packed x | y << 16, [lh][lw]
     void* out;
     float s12, s21;        // frameScalar12 = t, frameScalar21 = 1 - t (opticalFlowCalcSDR.cpp:149-150)
     int mode;
@@ -441,6 +459,147 @@ __global__ __launch_bounds__(256) void warp_kernel(const Geom g, const WarpArgs 
     }
 }
 
+
+// Fast path (modes 0-2, rs >= 1): the GROUP consecutive elements a thread handles at once share one
+// low-res flow cell (GROUP divides 2^rs), so the flow is looked up ONCE per group (one packed load per
+// direction) and, away from the left/right frame edges where mirrorCoordinate acts, the two source
+// runs are contiguous: one unaligned GROUP-wide load each (two for a chroma run displaced by an odd
+// amount).  Groups that touch the mirror zone fall back to warp_element.
+template <typename E, int GROUP>
+struct Run { __attribute__((aligned(sizeof(E) * GROUP))) E v[GROUP]; };
+
+template <typename E, int GROUP>
+__device__ __forceinline__ Run<E, GROUP> load_run(const E* __restrict__ p) {
+    Run<E, GROUP> r;
+    __builtin_memcpy(r.v, p, sizeof(E) * GROUP);   // unaligned global_load_dword{,x2,x4}
+    return r;
+}
+
+// chroma run: out[2k] = src[base + 2k] (U), out[2k+1] = src[base + 2k + 1 + vshift] (V)
+template <typename E, int GROUP>
+__device__ __forceinline__ Run<E, GROUP> load_run_uv(const E* __restrict__ row, int x_first) {
+    // x_first = cx_g + d ; (x & ~1) + parity per element, warpFrameKernelSDR.h:173
+    if ((x_first & 1) == 0) return load_run<E, GROUP>(row + x_first);
+    const Run<E, GROUP> lo = load_run<E, GROUP>(row + x_first - 1);   // even slots (U)
+    const Run<E, GROUP> hi = load_run<E, GROUP>(row + x_first + 1);   // odd slots (V)
+    Run<E, GROUP> r;
+#pragma unroll
+    for (int i = 0; i < GROUP; i++) r.v[i] = (i & 1) ? hi.v[i] : lo.v[i];
+    return r;
+}
+
+// Body of the fast path for one plane (CZ = 0 luma, 1 chroma), everything plane-dependent is
+// compile-time so the per-element code is straight-line.
+template <typename E, int GROUP, int ROWS, int MODE, int CZ>
+__device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a, int cy0, int cx0) {
+    constexpr int VEC = 16 / sizeof(E);
+    constexpr int NG = VEC / GROUP;
+    static_assert(VEC % GROUP == 0, "group must divide the per-thread vector");
+    const int H = g.H, W = g.W, Si = g.in_stride, So = g.out_stride, rs = g.rs, lw = g.lw, lh = g.lh;
+    const int dim_y = CZ ? (H >> 1) : H;
+    const int nrows = min(ROWS, dim_y - cy0);
+    const Levels lv = make_levels(a.black, a.white);
+    E* __restrict__ out = (E*)a.out + (size_t)CZ * H * So + (size_t)cy0 * So + cx0;
+    if (cx0 + VEC > W) {  // ragged right edge
+        for (int r = 0; r < nrows; r++)
+            for (int i = 0; i < VEC && cx0 + i < W; i++) out[(size_t)r * So + i] = (E)warp_element<E>(g, a, lv, CZ, cx0 + i, cy0 + r);
+        return;
+    }
+    const E* __restrict__ A = (const E*)a.frame12 + (size_t)CZ * H * Si;
+    const E* __restrict__ B = (const E*)a.frame21 + (size_t)CZ * H * Si;
+    const int ly = CZ ? ((cy0 >> rs) << 1) : (cy0 >> rs);    // same for all ROWS rows
+    constexpr bool need_a = MODE != 1, need_b = MODE != 0;
+
+    int xa[NG], xb[NG], dya[NG], dyb[NG];
+#pragma unroll
+    for (int k = 0; k < NG; k++) {
+        const int cx = cx0 + k * GROUP;
+        const int lx = CZ ? ((cx >> rs) & ~1) : (cx >> rs);
+        const uint32_t f12 = a.flow_xy[(size_t)ly * lw + lx];
+        const int ox12 = (int)(int16_t)(f12 & 0xFFFFu), oy12 = (int)(int16_t)(f12 >> 16);
+        const int py = clampi(ly - (oy12 >> rs), 0, lh - 1);
+        const int px = clampi(lx - (ox12 >> rs), 0, lw - 1);
+        const uint32_t f21 = a.flow_xy[(size_t)py * lw + px];
+        const int ox21 = (int)(int16_t)(f21 & 0xFFFFu), oy21 = (int)(int16_t)(f21 >> 16);
+        xa[k] = cx + (int)roundf((float)ox12 * a.s12);
+        xb[k] = cx - (int)roundf((float)ox21 * a.s21);
+        if (CZ) {
+            dya[k] = (int)roundf((float)oy12 * a.s12 * 0.5f);
+            dyb[k] = -(int)roundf((float)oy21 * a.s21 * 0.5f);
+        } else {
+            dya[k] = (int)roundf((float)oy12 * a.s12);
+            dyb[k] = -(int)roundf((float)oy21 * a.s21);
+        }
+    }
+
+    Run<E, GROUP> ra[ROWS][NG], rb[ROWS][NG];
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) {
+        const int cy = min(cy0 + r, dim_y - 1);               // rows past the plane end re-read the last row (not stored)
+#pragma unroll
+        for (int k = 0; k < NG; k++) {
+            // mirrorCoordinate is the identity on [1, W-2]: contiguous run; else per-element gathers
+            if (need_a) {
+                const E* rowp = A + (size_t)mirror_warp(cy + dya[k], dim_y) * Si;
+                if (xa[k] >= 1 && xa[k] + GROUP - 1 <= W - 2) {
+                    ra[r][k] = CZ ? load_run_uv<E, GROUP>(rowp, xa[k]) : load_run<E, GROUP>(rowp + xa[k]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < GROUP; i++) {
+                        const int x = mirror_warp(xa[k] + i, W);
+                        ra[r][k].v[i] = rowp[CZ ? (x & ~1) + (i & 1) : x];
+                    }
+                }
+            }
+            if (need_b) {
+                const E* rowp = B + (size_t)mirror_warp(cy + dyb[k], dim_y) * Si;
+                if (xb[k] >= 1 && xb[k] + GROUP - 1 <= W - 2) {
+                    rb[r][k] = CZ ? load_run_uv<E, GROUP>(rowp, xb[k]) : load_run<E, GROUP>(rowp + xb[k]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < GROUP; i++) {
+                        const int x = mirror_warp(xb[k] + i, W);
+                        rb[r][k].v[i] = rowp[CZ ? (x & ~1) + (i & 1) : x];
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) {
+        if (r >= nrows) break;
+        __attribute__((aligned(16))) E v[VEC];
+#pragma unroll
+        for (int k = 0; k < NG; k++) {
+#pragma unroll
+            for (int i = 0; i < GROUP; i++) {
+                if (MODE == 0) v[k * GROUP + i] = ra[r][k].v[i];
+                else if (MODE == 1) v[k * GROUP + i] = rb[r][k].v[i];
+                else {
+                    const unsigned blended = (unsigned)__builtin_fmaf((float)ra[r][k].v[i], a.s21, (float)rb[r][k].v[i] * a.s12) & 0xFFFFu;
+                    v[k * GROUP + i] = (E)(CZ ? levels_uv<E>((float)blended, lv) : levels_y<E>((float)blended, lv));
+                }
+            }
+        }
+        *(uint4*)(out + (size_t)r * So) = *(const uint4*)v;
+    }
+}
+
+// Thread = VEC consecutive elements x ROWS consecutive rows that share one flow-cell row (ROWS
+// divides 2^rs).  Flow lookups and displacement maths are done once per GROUP and reused for the
+// ROWS rows; all 2 * ROWS source runs are requested before any is consumed.
+template <typename E, int GROUP, int ROWS, int MODE>
+__global__ __launch_bounds__(256) void warp_fast_kernel(const Geom g, const WarpArgs a, int y_groups) {
+    constexpr int VEC = 16 / sizeof(E);
+    // row group: luma groups first, then chroma; one row group per wave => the plane test is a scalar branch
+    const int rg = blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cx0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * VEC;
+    const int uv_groups = ((g.H >> 1) + ROWS - 1) / ROWS;
+    if (rg >= y_groups + uv_groups || cx0 >= g.W) return;
+    if (rg >= y_groups) warp_fast_body<E, GROUP, ROWS, MODE, 1>(g, a, (rg - y_groups) * ROWS, cx0);
+    else warp_fast_body<E, GROUP, ROWS, MODE, 0>(g, a, rg * ROWS, cx0);
+}
+
 template <typename E, int VEC, bool ALIGNED>
 __global__ __launch_bounds__(256) void copy_kernel(const Geom g, const E* __restrict__ src, E* __restrict__ dst,
                                                     float black, float white) {
@@ -492,12 +651,17 @@ void launch_argmin_adjust(const Geom& g, const StepArgs& a, hipStream_t stream) 
     argmin_adjust_kernel<<<grd, 256, 0, stream>>>(g, a);
 }
 
-void launch_blur_flow(const Geom& g, const int16_t* off_x, const int16_t* off_y, int16_t* blurred, int radius,
-                      hipStream_t stream) {
-    const dim3 grd((g.lw + 15) / 16, (g.lh + 15) / 16, 2);
+void launch_blur_flow(const Geom& g, const int16_t* off_x, const int16_t* off_y, int16_t* blurred, uint32_t* packed,
+                      int radius, hipStream_t stream) {
+    const dim3 grd((g.lw + 15) / 16, (g.lh + 15) / 16, 1);
     const int T = 16 + 2 * radius;
     const size_t smem = (size_t)T * 16 * sizeof(int) + (size_t)T * T * sizeof(int16_t);
-    blur_flow_kernel<<<grd, 256, smem, stream>>>(off_x, off_y, blurred, g.lw, g.lh, radius);
+    blur_flow_kernel<<<grd, 256, smem, stream>>>(off_x, off_y, blurred, packed, g.lw, g.lh, radius);
+}
+
+void launch_pack_flow(const Geom& g, const int16_t* flow, uint32_t* packed, hipStream_t stream) {
+    const int n = g.lw * g.lh;
+    pack_flow_kernel<<<(n + 255) / 256, 256, 0, stream>>>(flow, packed, n);
 }
 
 template <typename E>
@@ -505,14 +669,45 @@ static void launch_warp_t(const Geom& g, const WarpArgs& a, hipStream_t stream) 
     constexpr int VEC = 16 / sizeof(E);  // 16-byte stores
     const bool aligned = (g.out_stride % VEC) == 0 && (((uintptr_t)a.out) & 15) == 0;
     const dim3 grd((g.W + 64 * VEC - 1) / (64 * VEC), (g.H + (g.H >> 1) + 3) / 4);
+    const int cell = 1 << g.rs;
+    const int group = cell < VEC ? cell : VEC;
+    // chroma runs are read with element-pair granularity: needs an even input stride
+    const bool fast = aligned && a.mode >= 0 && a.mode <= 2 && a.flow_xy && (g.in_stride % 2) == 0 && g.W >= 2 * VEC &&
+                      group * (int)sizeof(E) >= 4;
+    if (fast) {
+        // rows per thread (must divide the 2^rs rows of a flow cell)
+        static const int rows_env = getenv("HF_WARP_ROWS") ? atoi(getenv("HF_WARP_ROWS")) : 0;
+        int rows = 2;  // measured on MI355X, 2160p HDR blend: 1 row 25.9 us, 2 rows 24.3 us, 4 rows 30.2 us
+        if (rows_env == 1 || rows_env == 2 || (rows_env == 4 && g.rs >= 2)) rows = rows_env;
+        const int y_groups = (g.H + rows - 1) / rows, uv_groups = ((g.H >> 1) + rows - 1) / rows;
+        const dim3 fg((g.W + 64 * VEC - 1) / (64 * VEC), (y_groups + uv_groups + 3) / 4);
+#define HF_WARP_FAST(G, R)                                                                   \
+    do {                                                                                     \
+        if (a.mode == 0) warp_fast_kernel<E, G, R, 0><<<fg, 256, 0, stream>>>(g, a, y_groups);      \
+        else if (a.mode == 1) warp_fast_kernel<E, G, R, 1><<<fg, 256, 0, stream>>>(g, a, y_groups); \
+        else warp_fast_kernel<E, G, R, 2><<<fg, 256, 0, stream>>>(g, a, y_groups);                  \
+    } while (0)
+#define HF_WARP_ROWS(R)                                   \
+    do {                                                  \
+        if (group == VEC) HF_WARP_FAST(VEC, R);           \
+        else if (group == VEC / 2) HF_WARP_FAST(VEC / 2, R); \
+        else HF_WARP_FAST(VEC / 4, R);                    \
+    } while (0)
+        if (rows == 4) HF_WARP_ROWS(4);
+        else if (rows == 2) HF_WARP_ROWS(2);
+        else HF_WARP_ROWS(1);
+#undef HF_WARP_ROWS
+#undef HF_WARP_FAST
+        return;
+    }
     if (aligned) warp_kernel<E, VEC, true><<<grd, 256, 0, stream>>>(g, a);
     else warp_kernel<E, VEC, false><<<grd, 256, 0, stream>>>(g, a);
 }
 
-void launch_warp(const Geom& g, const void* frame12, const void* frame21, const int16_t* flow, void* out, float t,
-                 int mode, float black, float white, hipStream_t stream) {
+void launch_warp(const Geom& g, const void* frame12, const void* frame21, const int16_t* flow, const uint32_t* flow_xy,
+                 void* out, float t, int mode, float black, float white, hipStream_t stream) {
     WarpArgs a;
-    a.frame12 = frame12; a.frame21 = frame21; a.flow = flow; a.out = out;
+    a.frame12 = frame12; a.frame21 = frame21; a.flow = flow; a.flow_xy = flow_xy; a.out = out;
     a.s12 = t; a.s21 = 1.0f - t; a.mode = mode; a.black = black; a.white = white;
     if (g.hdr) launch_warp_t<uint16_t>(g, a, stream);
     else launch_warp_t<uint8_t>(g, a, stream);
