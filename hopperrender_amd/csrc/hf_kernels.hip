@@ -72,14 +72,18 @@ __global__ __launch_bounds__(256) void decimate_kernel(const E* __restrict__ f, 
 // ------------------------------------------------------------------------------------------
 // flow step
 // ------------------------------------------------------------------------------------------
-
-// Sum over aligned groups of G lanes (G = 4, 16, 64); every lane of the group gets the sum.
-template <int G>
-__device__ __forceinline__ uint32_t group_sum(uint32_t v) {
-#pragma unroll
-    for (int m = G >> 1; m >= 1; m >>= 1) v += (uint32_t)__shfl_xor((int)v, m, 64);
-    return v;
-}
+//
+// Structure exploited (all exact, see DESIGN.md "flow step"):
+//  * Inside one chain the offsets are constant over every window of the CURRENT size: the chain
+//    starts from zero (opticalFlowCalcSDR.cpp:68-69) and every update adds one value per window of a
+//    size that the current size divides.  Hence the candidate offset, the offset bias
+//    (calcDeltaSumsKernelSDR.h:105-109) and the neighbour bias (:112-144; the clamped neighbour of
+//    every pixel of a window falls into ONE window) are per-window constants, and
+//        sum_w(cost) = (sum_w SAD) << deltaScalar  +  npix_w * (offsetBias + neighborBias)   (mod 2^32)
+//    so the per-pixel work is just the 3-sample SAD, done with v_sad_u8 on packed (Y,U,V) bytes.
+//  * All R candidates of a pixel are issued before any is consumed (2 loads each in flight) and the
+//    16 per-lane partial sums are reduced with a transposing butterfly: 17 cross-lane moves for a
+//    64-lane window instead of 16 x 6.
 
 // Lane -> pixel inside the workgroup's 16x16 grid tile, chosen so that every window of the
 // current size is a contiguous, aligned lane group (64, 64, 16 or 4 lanes).
@@ -103,6 +107,64 @@ __device__ __forceinline__ void lane_to_tile_xy(int window, int wave, int lane, 
     }
 }
 
+__device__ __forceinline__ uint32_t shfl_xor_u32(uint32_t v, int m) { return (uint32_t)__shfl_xor((int)v, m, 64); }
+
+// One butterfly level: lanes l and l^M exchange halves of their NV values; afterwards each lane
+// holds NV/2 values, each the pair-sum of one candidate.  Lanes with bit M set keep the upper half.
+template <int NV, int M>
+__device__ __forceinline__ void butterfly_level(uint32_t* v, int lane) {
+    const bool hi = (lane & M) != 0;
+#pragma unroll
+    for (int k = 0; k < NV / 2; k++) {
+        const uint32_t send = hi ? v[k] : v[k + NV / 2];
+        const uint32_t keep = hi ? v[k + NV / 2] : v[k];
+        v[k] = keep + shfl_xor_u32(send, M);
+    }
+}
+
+struct Best { uint32_t sum; int cz; };
+__device__ __forceinline__ void best_min(Best& b, uint32_t s, int cz) {   // first minimum wins (strict '<')
+    if (s < b.sum || (s == b.sum && cz < b.cz)) { b.sum = s; b.cz = cz; }
+}
+__device__ __forceinline__ void best_xor(Best& b, int m) {
+    const uint32_t s = shfl_xor_u32(b.sum, m);
+    const int c = __shfl_xor(b.cz, m, 64);
+    best_min(b, s, c);
+}
+
+// Per-window constant part of the cost of candidate offset `cand` (short arithmetic as in the reference).
+__device__ __forceinline__ uint32_t window_bias(int cand, bool use_nb, int nb0, int nb1, int nb2, int nb3, int nshift) {
+    uint32_t c = (uint32_t)(cand < 0 ? -cand : cand) & 0xFFFFu;                   // offsetBias, :105-109
+    if (use_nb) {
+        const uint32_t nbias = ((uint32_t)abs(nb0 - cand) & 0xFFFFu) + ((uint32_t)abs(nb1 - cand) & 0xFFFFu) +
+                               ((uint32_t)abs(nb2 - cand) & 0xFFFFu) + ((uint32_t)abs(nb3 - cand) & 0xFFFFu);
+        c += nbias << nshift;                                                     // :143
+    }
+    return c;
+}
+
+// Window-constant inputs, read at the window origin (always inside the grid).
+struct WindowConst { int ox, oy, nb0, nb1, nb2, nb3; uint32_t npix; };
+__device__ __forceinline__ WindowConst load_window_const(const Geom& g, const StepArgs& a, int wx0, int wy0) {
+    WindowConst w;
+    const size_t p = (size_t)wy0 * g.lw + wx0;
+    w.ox = a.off_x[p];
+    w.oy = a.off_y[p];
+    w.nb0 = w.nb1 = w.nb2 = w.nb3 = 0;
+    if (a.use_neighbors) {  // :112-131 ; the clamped neighbour of every pixel of the window lies in one window
+        const int16_t* __restrict__ plane = a.step ? a.off_y : a.off_x;
+        const int d = 2 * a.window;
+        const int xl = max(wx0 - d, 0), xr = min(wx0 + d, g.lw - 1);
+        const int yu = max(wy0 - d, 0), yd = min(wy0 + d, g.lh - 1);
+        w.nb0 = plane[(size_t)yd * g.lw + wx0];
+        w.nb1 = plane[(size_t)wy0 * g.lw + xr];
+        w.nb2 = plane[(size_t)wy0 * g.lw + xl];
+        w.nb3 = plane[(size_t)yu * g.lw + wx0];
+    }
+    w.npix = (uint32_t)((min(g.lw, wx0 + a.window) - wx0) * (min(g.lh, wy0 + a.window) - wy0));
+    return w;
+}
+
 template <typename E>
 __global__ __launch_bounds__(256) void flow_step_kernel(const Geom g, const StepArgs a) {
     using T = ElemTraits<E>;
@@ -114,125 +176,145 @@ __global__ __launch_bounds__(256) void flow_step_kernel(const Geom g, const Step
     const int cx = blockIdx.x * 16 + lx, cy = blockIdx.y * 16 + ly;
     const bool in = cx < g.lw && cy < g.lh;
     const E* __restrict__ f1 = (const E*)a.frame1;
-    const int W = g.W, H = g.H, S = g.in_stride;
+    const int W = g.W, H = g.H, S = g.in_stride, R = a.R;
     const size_t uv_base = (size_t)H * S;
+    const int wx0 = (cx >> a.window_log2) << a.window_log2, wy0 = (cy >> a.window_log2) << a.window_log2;
+    const bool win_in = wx0 < g.lw && wy0 < g.lh;   // false only for lanes of windows entirely outside the grid
 
-    // Candidate-independent inputs: own offsets, frame-N samples, the four neighbour offsets.
-    int ox0 = 0, oy0 = 0, nb0 = 0, nb1 = 0, nb2 = 0, nb3 = 0;
+    WindowConst wc{};
+    if (win_in) wc = load_window_const(g, a, wx0, wy0);
     uint32_t p2 = 0;
-    if (in) {
-        const size_t p = (size_t)cy * g.lw + cx;
-        ox0 = a.off_x[p];
-        oy0 = a.off_y[p];
-        p2 = a.grid2[p];
-        if (a.use_neighbors) {  // calcDeltaSumsKernelSDR.h:112-131, neighbours at +-2*window, clamped
-            const int16_t* __restrict__ plane = a.step ? a.off_y : a.off_x;
-            const int d = 2 * a.window;
-            const int xl = max(cx - d, 0), xr = min(cx + d, g.lw - 1);
-            const int yu = max(cy - d, 0), yd = min(cy + d, g.lh - 1);
-            nb0 = plane[(size_t)yd * g.lw + cx];
-            nb1 = plane[(size_t)cy * g.lw + xr];
-            nb2 = plane[(size_t)cy * g.lw + xl];
-            nb3 = plane[(size_t)yu * g.lw + cx];
-        }
-    }
-    const unsigned y2 = p2 & 0xFFu, u2 = (p2 >> 8) & 0xFFu, v2 = (p2 >> 16) & 0xFFu;
-    const bool valid = (p2 >> 24) != 0;
+    if (in) p2 = a.grid2[(size_t)cy * g.lw + cx];
+    const bool valid = in && (p2 >> 24) != 0;       // calcDeltaSumsKernelSDR.h:82
+    p2 &= 0x00FFFFFFu;
     const int sx = cx << g.rs, sy = cy << g.rs;
-    const int searched0 = a.step ? oy0 : ox0;
+    const int searched0 = a.step ? wc.oy : wc.ox;
 
-    uint32_t best_sum = 0xFFFFFFFFu;
-    int best = 0;
-    uint32_t captured = 0;
-
-    for (int c0 = 0; c0 < a.R; c0 += 4) {
-        uint32_t cost[4];
+    // ---- 1. all candidates: addresses, loads, SAD --------------------------------------------
+    uint32_t sad[16];
+    {
+        unsigned y1[16], uv1a[16], uv1b[16];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int cz = min(c0 + k, a.R - 1);  // tail lanes recompute the last candidate (discarded)
-            const int cand = (int)(int16_t)(searched0 + rel_offset(cz, a.R));  // short arithmetic, :75-76
-            uint32_t c = 0;
-            if (in) {
-                int nx = sx + (a.step ? ox0 : cand);
-                int ny = sy + (a.step ? cand : oy0);
+        for (int cz = 0; cz < 16; cz++) {
+            y1[cz] = 0; uv1a[cz] = 0; uv1b[cz] = 0;
+            if (cz < R && valid) {                  // R is wave-uniform
+                const int cand = (int)(int16_t)(searched0 + rel_offset(cz, R));  // short arithmetic, :75-76
+                int nx = sx + (a.step ? wc.ox : cand);
+                int ny = sy + (a.step ? cand : wc.oy);
                 // single reflection (:86-95); the final clamp only acts where the reference indexes
                 // outside the frame (offsets larger than the frame), keeping the kernel memory-safe
                 if (nx >= W) nx = 2 * W - nx - 1; else if (nx < 0) nx = -nx - 1;
                 if (ny >= H) ny = 2 * H - ny - 1; else if (ny < 0) ny = -ny - 1;
                 nx = clampi(nx, 0, W - 1);
                 ny = clampi(ny, 0, H - 1);
-                if (valid) {
-                    const E* uv = f1 + uv_base + (size_t)(ny >> 1) * S + (nx & ~1);
-                    const unsigned y1 = T::top8(f1[(size_t)ny * S + nx]);
-                    const unsigned u1 = T::top8(uv[0]), v1 = T::top8(uv[1]);
-                    c = (absdiff(y1, y2) + absdiff(u1, u2) + absdiff(v1, v2)) << a.delta_scalar;  // :98-101
-                }
-                c += (uint32_t)(cand < 0 ? -cand : cand) & 0xFFFFu;  // offsetBias, :105-109
-                if (a.use_neighbors) {
-                    const uint32_t nbias = ((uint32_t)abs(nb0 - cand) & 0xFFFFu) + ((uint32_t)abs(nb1 - cand) & 0xFFFFu) +
-                                           ((uint32_t)abs(nb2 - cand) & 0xFFFFu) + ((uint32_t)abs(nb3 - cand) & 0xFFFFu);
-                    c += nbias << a.neighbor_scalar;  // :143
-                }
+                const E* uv = f1 + uv_base + (size_t)(ny >> 1) * S + (nx & ~1);
+                y1[cz] = f1[(size_t)ny * S + nx];
+                uv1a[cz] = uv[0];
+                uv1b[cz] = uv[1];
             }
-            cost[k] = c;
         }
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int cz = c0 + k;
-            if (cz >= a.R) break;  // wave-uniform
-            uint32_t s;
-            if (a.window >= 8) s = group_sum<64>(cost[k]);
-            else if (a.window == 4) s = group_sum<16>(cost[k]);
-            else s = group_sum<4>(cost[k]);
-            if (a.window >= 16) {
-                if (lane == 0) s_part[wave][cz] = s;
-            } else {
-                if (s < best_sum) { best_sum = s; best = cz; }  // strict '<': first minimum wins
-                if (cz == (a.R >> 1) - 1) captured = s;
-            }
+        for (int cz = 0; cz < 16; cz++) {
+            const uint32_t p1 = T::top8((E)y1[cz]) | (T::top8((E)uv1a[cz]) << 8) | (T::top8((E)uv1b[cz]) << 16);
+            sad[cz] = (cz < R && valid) ? __builtin_amdgcn_sad_u8(p1, p2, 0u) : 0u;   // |dY| + |dU| + |dV|, :98-100
         }
+    }
+
+    // ---- 2. window reduction -------------------------------------------------------------------
+    // after the butterfly each lane owns ONE candidate `my_cz` and holds its sum over the lane group
+    int my_cz;
+    uint32_t tot;
+    if (a.window >= 8) {
+        butterfly_level<16, 32>(sad, lane); butterfly_level<8, 16>(sad, lane);
+        butterfly_level<4, 8>(sad, lane);   butterfly_level<2, 4>(sad, lane);
+        tot = sad[0];
+        tot += shfl_xor_u32(tot, 2);
+        tot += shfl_xor_u32(tot, 1);
+        my_cz = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+    } else if (a.window == 4) {
+        butterfly_level<16, 8>(sad, lane); butterfly_level<8, 4>(sad, lane);
+        butterfly_level<4, 2>(sad, lane);  butterfly_level<2, 1>(sad, lane);
+        tot = sad[0];
+        my_cz = ((lane >> 3) & 1) * 8 + ((lane >> 2) & 1) * 4 + ((lane >> 1) & 1) * 2 + (lane & 1);
+    } else {
+        butterfly_level<16, 2>(sad, lane); butterfly_level<8, 1>(sad, lane);
+        tot = 0;  // four candidates per lane, handled below
+        my_cz = ((lane >> 1) & 1) * 8 + (lane & 1) * 4;
     }
 
     if (a.window >= 16) {
+        if ((lane & 3) == 0) s_part[wave][my_cz] = tot;
         __syncthreads();
-        if (a.window == 16) {  // the workgroup owns the whole window: finish in place
-            for (int cz = 0; cz < a.R; cz++) {
-                const uint32_t s = s_part[0][cz] + s_part[1][cz] + s_part[2][cz] + s_part[3][cz];
-                if (s < best_sum) { best_sum = s; best = cz; }
-                if (cz == (a.R >> 1) - 1) captured = s;
-            }
-        } else {               // window spans many workgroups: one atomic per candidate per workgroup
-            if (tid < a.R) {
+        if (a.window > 16) {   // window spans many workgroups: one atomic per candidate per workgroup (raw SAD sums)
+            if (tid < R) {
                 const uint32_t s = s_part[0][tid] + s_part[1][tid] + s_part[2][tid] + s_part[3][tid];
                 const int win = ((blockIdx.y * 16) >> a.window_log2) * a.n_win_x + ((blockIdx.x * 16) >> a.window_log2);
-                atomicAdd(&a.sums[win * 16 + tid], s);  // wrapping uint32, like the reference's atomic_add
+                atomicAdd(&a.sums[win * 16 + tid], s);
             }
             return;
         }
+        tot = s_part[0][my_cz] + s_part[1][my_cz] + s_part[2][my_cz] + s_part[3][my_cz];
+    }
+
+    // ---- 3. argmin over candidates + offset update (windows <= 16) -------------------------------
+    Best b{0xFFFFFFFFu, 16};
+    uint32_t captured = 0;
+    const int cap_cz = (R >> 1) - 1;
+    if (a.window >= 4) {
+        if (my_cz < R) {
+            const int cand = (int)(int16_t)(searched0 + rel_offset(my_cz, R));
+            b.sum = (tot << a.delta_scalar) + wc.npix * window_bias(cand, a.use_neighbors, wc.nb0, wc.nb1, wc.nb2, wc.nb3, a.neighbor_scalar);
+            b.cz = my_cz;
+        }
+        if (a.capture_delta) { captured = (my_cz == cap_cz) ? b.sum : 0u; }
+        if (a.window >= 8) { best_xor(b, 4); best_xor(b, 8); best_xor(b, 16); best_xor(b, 32); }
+        else { best_xor(b, 1); best_xor(b, 2); best_xor(b, 4); best_xor(b, 8); }
+        if (a.capture_delta) {  // only window (0,0) of a first step is captured: bring its candidate sum to lane 0
+            if (a.window >= 8) { captured |= shfl_xor_u32(captured, 4); captured |= shfl_xor_u32(captured, 8); captured |= shfl_xor_u32(captured, 16); captured |= shfl_xor_u32(captured, 32); }
+            else { captured |= shfl_xor_u32(captured, 1); captured |= shfl_xor_u32(captured, 2); captured |= shfl_xor_u32(captured, 4); captured |= shfl_xor_u32(captured, 8); }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int cz = my_cz + k;
+            if (cz < R) {
+                const int cand = (int)(int16_t)(searched0 + rel_offset(cz, R));
+                const uint32_t sum = (sad[k] << a.delta_scalar) + wc.npix * window_bias(cand, a.use_neighbors, wc.nb0, wc.nb1, wc.nb2, wc.nb3, a.neighbor_scalar);
+                best_min(b, sum, cz);
+                if (a.capture_delta && cz == cap_cz) captured = sum;
+            }
+        }
+        best_xor(b, 1); best_xor(b, 2);
+        if (a.capture_delta) { captured |= shfl_xor_u32(captured, 1); captured |= shfl_xor_u32(captured, 2); }
     }
 
     if (in) {
-        a.off_out[(size_t)cy * g.lw + cx] = (int16_t)(searched0 + rel_offset(best, a.R));
+        a.off_out[(size_t)cy * g.lw + cx] = (int16_t)(searched0 + rel_offset(b.cz, R));   // adjustOffsetArrayKernelSDR.h:13-19
         if (a.capture_delta && cx == 0 && cy == 0) *a.total_delta = captured / a.delta_divisor;
     }
 }
 
-// Windows > 16: every 16x16 tile lies inside one window.
+// Windows > 16: every 16x16 tile lies inside one window; sums hold the raw SAD sums per candidate.
 __global__ __launch_bounds__(256) void argmin_adjust_kernel(const Geom g, const StepArgs a) {
     __shared__ int s_rel;
     const int tid = threadIdx.x;
-    const int win = ((blockIdx.y * 16) >> a.window_log2) * a.n_win_x + ((blockIdx.x * 16) >> a.window_log2);
-    if (tid == 0) {
-        const uint32_t* s = a.sums + win * 16;
-        uint32_t best_sum = s[0];
-        int best = 0;
-        for (int z = 1; z < a.R; z++) {  // determineLowestLayerKernelSDR.h:19-24
-            const uint32_t v = s[z];
-            if (v < best_sum) { best_sum = v; best = z; }
+    const int wix = (blockIdx.x * 16) >> a.window_log2, wiy = (blockIdx.y * 16) >> a.window_log2;
+    const int win = wiy * a.n_win_x + wix;
+    if (tid < 64) {
+        const WindowConst wc = load_window_const(g, a, wix << a.window_log2, wiy << a.window_log2);
+        const int searched0 = a.step ? wc.oy : wc.ox;
+        Best b{0xFFFFFFFFu, 16};
+        uint32_t mine = 0;
+        if (tid < a.R) {
+            const int cand = (int)(int16_t)(searched0 + rel_offset(tid, a.R));
+            mine = (a.sums[win * 16 + tid] << a.delta_scalar) +
+                   wc.npix * window_bias(cand, a.use_neighbors, wc.nb0, wc.nb1, wc.nb2, wc.nb3, a.neighbor_scalar);
+            b.sum = mine; b.cz = tid;
         }
-        s_rel = rel_offset(best, a.R);
-        if (a.capture_delta && blockIdx.x == 0 && blockIdx.y == 0)
-            *a.total_delta = s[(a.R >> 1) - 1] / a.delta_divisor;  // opticalFlowCalcSDR.cpp:91-94
+        best_xor(b, 1); best_xor(b, 2); best_xor(b, 4); best_xor(b, 8);   // determineLowestLayerKernelSDR.h:19-24
+        if (tid == 0) s_rel = rel_offset(b.cz, a.R);
+        if (a.capture_delta && blockIdx.x == 0 && blockIdx.y == 0 && tid == (a.R >> 1) - 1)
+            *a.total_delta = mine / a.delta_divisor;                        // opticalFlowCalcSDR.cpp:91-94
     }
     __syncthreads();
     const int cx = blockIdx.x * 16 + (tid & 15), cy = blockIdx.y * 16 + (tid >> 4);
