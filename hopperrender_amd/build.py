@@ -42,7 +42,7 @@ def _run(cmd):
 
 def build_flow(force=False):
     os.makedirs(LIBDIR, exist_ok=True)
-    srcs = [os.path.join(CSRC, f) for f in ("hf_kernels.hip", "hf_capi.hip")]
+    srcs = [os.path.join(CSRC, f) for f in ("hf_kernels.hip", "hf_flow.hip", "hf_capi.hip")]
     deps = srcs + [os.path.join(CSRC, "hf_kernels.h"), os.path.join(INCLUDE, "hopperflow.h")]
     if force or _stale(LIB_FLOW, deps):
         objs = []

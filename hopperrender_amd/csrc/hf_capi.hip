@@ -4,10 +4,12 @@
 //
 // Host orchestration restated from the reference's opticalFlowCalcSDR.cpp / opticalFlowCalcHDR.cpp
 // (cited per function); the architecture differs on purpose:
-//   * per step ONE fused launch for windows <= 16, two for larger windows (reference: fill +
-//     calcDeltaSums + determineLowestLayer + adjustOffsetArray = 4 enqueues, 2.6-8.3 MB of fills);
-//   * offsets live in ping-pong planes so a step never reads what it writes;
-//   * frame N's grid samples are decimated once at upload;
+//   * every uploaded frame is re-laid out once as mirror-padded phase planes, so the candidates of a run
+//     of grid pixels are consecutive bytes (hf_flow.hip);
+//   * offsets are kept per window in one small table per level, not per pixel;
+//   * ONE launch per level (X and Y step fused) for windows <= 32, two per axis for larger windows
+//     (reference: fill + calcDeltaSums + determineLowestLayer + adjustOffsetArray = 4 enqueues per step,
+//     2.6-8.3 MB of fills);
 //   * m_totalFrameDelta is produced on the device and copied to pinned memory inside the graph
 //     (reference: blocking 4-byte readback in the middle of the chain, opticalFlowCalcSDR.cpp:91-94);
 //   * the whole chain replays as one hipGraph keyed by (ring phase, search radius, scalars).
@@ -53,11 +55,16 @@ struct hf_ctx {
     // device memory (reference buffers: opticalFlowCalcSDR.cpp:272-280)
     size_t in_bytes = 0, out_bytes = 0, plane_elems = 0;
     void* ring[3] = {nullptr, nullptr, nullptr};       // m_inputFrameArray, ring[2] = newest
-    uint32_t* grid[3] = {nullptr, nullptr, nullptr};   // decimated samples of each ring frame
+    uint8_t* py[3] = {nullptr, nullptr, nullptr};      // luma phase planes of each ring frame (hf_flow.hip)
+    uint16_t* puv[3] = {nullptr, nullptr, nullptr};    // chroma phase planes of each ring frame
+    hf::PhaseLayout pl{};
     void* out_frame = nullptr;                         // m_outputFrameArray
     void* out_target = nullptr;                        // where warp/copy write (out_frame or caller's)
-    int16_t* off[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [axis][ping-pong] m_offsetArray
-    int off_cur[2] = {0, 0};
+    int16_t* tables = nullptr;                         // per-level window offsets (replaces the per-pixel m_offsetArray)
+    size_t tables_bytes = 0;
+    std::vector<hf::FlowLevel> levels;                 // level k = window size initial_window >> k
+    hf::FlowLevel last_level{};                        // level the last chain ended on (tx == nullptr: no step ran)
+    int16_t* off_view = nullptr;                       // scratch [2][lh][lw] for hf_read_offsets
     int16_t* blurred[2] = {nullptr, nullptr};          // m_blurredOffsetArray
     uint32_t* blurred_xy[2] = {nullptr, nullptr};      // the same flow packed x | y << 16 (fast warp path)
     uint32_t* sums = nullptr;                          // [kMaxSteps][n_windows_max][16]
@@ -139,56 +146,54 @@ int ilog2(int v) {
     return l;
 }
 
+int effective_iterations(const hf_ctx* c) {
+    int iters = ilog2(initial_window(c->g.lw, c->g.lh));             // opticalFlowCalcSDR.cpp:62-65
+    if (c->cfg.iterations > 0 && c->cfg.iterations < iters) iters = c->cfg.iterations;
+    return iters;
+}
+
 // Enqueue the refinement chain + blur (opticalFlowCalcSDR.cpp:44-116).  Capturable.
 int enqueue_flow_chain(hf_ctx* c) {
     const hf::Geom& g = c->g;
     hipStream_t s = c->stream;
-    const size_t plane_bytes = c->plane_elems * sizeof(int16_t);
-    int cur[2] = {0, 0};  // chain always starts from planes [axis][0] = 0 (:68-69: no temporal state)
-    HF_HIP(c, hipMemsetAsync(c->off[0][0], 0, plane_bytes, s));
-    HF_HIP(c, hipMemsetAsync(c->off[1][0], 0, plane_bytes, s));
-    HF_HIP(c, hipMemsetAsync(c->sums, 0, c->sums_bytes, s));
-
-    int window = initial_window(g.lw, g.lh);
-    int iters = ilog2(window);                                   // :62-65
-    if (c->cfg.iterations > 0 && c->cfg.iterations < iters) iters = c->cfg.iterations;
-    c->initial_window = window;
+    const int iters = effective_iterations(c);
+    c->initial_window = initial_window(g.lw, g.lh);
     c->last_iterations = iters;
-    const int R = c->p.search_radius;
+    bool any_big = false;
+    for (int k = 0; k < iters; k++) any_big |= c->levels[k].window > 32;
+    if (any_big) HF_HIP(c, hipMemsetAsync(c->sums, 0, c->sums_bytes, s));
+
+    hf::FlowStep a{};
+    a.py1 = c->py[1]; a.puv1 = c->puv[1];                         // :79 frame N-1
+    a.py2 = c->py[2]; a.puv2 = c->puv[2];                         // :80 frame N
+    a.pl = c->pl;
+    a.total_delta = c->d_total_delta;
+    a.R = c->p.search_radius;
+    a.delta_scalar = c->p.delta_scalar;
+    a.neighbor_scalar = c->p.neighbor_scalar;
+    a.delta_divisor = (uint32_t)(g.lh * g.lw * (g.hdr ? 6 : 10));  // :93 / HDR :93
+    hf::FlowLevel none{};
     int step_index = 0;
-    if (iters == 0) {
-        // degenerate grid (<= 2 px): the reference runs no step and keeps the previous m_totalFrameDelta
-    }
-    for (int iter = 0; iter < iters; iter++) {
-        for (int step = 0; step < 2; step++, step_index++) {
-            hf::StepArgs a{};
-            a.frame1 = c->ring[1];                               // :79 frame N-1
-            a.grid2 = c->grid[2];                                // :80 frame N (decimated)
-            a.off_x = c->off[0][cur[0]];
-            a.off_y = c->off[1][cur[1]];
-            a.off_out = c->off[step][cur[step] ^ 1];
-            a.sums = c->sums + (size_t)step_index * c->sums_stride;
-            a.total_delta = c->d_total_delta;
-            a.window = window;
-            a.window_log2 = ilog2(window);
-            a.n_win_x = (g.lw + window - 1) / window;
-            a.R = R;
-            a.step = step;
-            a.use_neighbors = iter >= 4;                         // calcDeltaSumsKernelSDR.h:3,112
-            a.delta_scalar = c->p.delta_scalar;
-            a.neighbor_scalar = c->p.neighbor_scalar;
-            a.capture_delta = (iter == 0 && step == 0);          // :91
-            a.delta_divisor = (uint32_t)(g.lh * g.lw * (g.hdr ? 6 : 10));  // :93 / HDR :93
-            hf::launch_flow_step(g, a, s);
-            if (window > 16) hf::launch_argmin_adjust(g, a, s);
-            cur[step] ^= 1;
+    for (int k = 0; k < iters; k++) {                             // window halves every level (:110)
+        a.cur = c->levels[k];
+        a.prev = k ? c->levels[k - 1] : none;                     // :68-69: the chain starts from zero offsets
+        a.use_neighbors = k >= 4;                                 // calcDeltaSumsKernelSDR.h:3,112
+        if (a.cur.window <= 32) {
+            a.capture_delta = k == 0;                             // :91
+            a.axis = 0;
+            hf::launch_flow_level_small(g, a, s);
+        } else {
+            for (int axis = 0; axis < 2; axis++, step_index++) {
+                a.axis = axis;
+                a.capture_delta = (k == 0 && axis == 0);
+                a.sums = c->sums + (size_t)step_index * c->sums_stride;
+                hf::launch_flow_big_partial(g, a, s);
+                hf::launch_flow_big_argmin(g, a, s);
+            }
         }
-        window = (window >> 1) > 1 ? (window >> 1) : 1;          // :110
-        if (window < 2) break;  // window 1 is unreachable in the reference's auto mode
     }
-    c->off_cur[0] = cur[0];
-    c->off_cur[1] = cur[1];
-    hf::launch_blur_flow(g, c->off[0][cur[0]], c->off[1][cur[1]], c->blurred[0], c->blurred_xy[0], c->cfg.blur_radius, s);  // :115-116
+    c->last_level = iters ? c->levels[iters - 1] : none;
+    hf::launch_blur_flow(g, c->last_level, c->blurred[0], c->blurred_xy[0], c->cfg.blur_radius, s);  // :115-116
     HF_HIP(c, hipMemcpyAsync(c->h_total_delta, c->d_total_delta, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HF_HIP(c, hipGetLastError());
     return HF_OK;
@@ -256,10 +261,11 @@ int sync_ctx(hf_ctx* c) {
 int rotate_after_upload(hf_ctx* c) {
     // opticalFlowCalcSDR.cpp:22-28 : [0] <- [1] <- [2] <- new ; frame_count++
     void* f = c->ring[0];
-    uint32_t* gr = c->grid[0];
-    c->ring[0] = c->ring[1]; c->grid[0] = c->grid[1];
-    c->ring[1] = c->ring[2]; c->grid[1] = c->grid[2];
-    c->ring[2] = f;          c->grid[2] = gr;
+    uint8_t* y = c->py[0];
+    uint16_t* uv = c->puv[0];
+    c->ring[0] = c->ring[1]; c->py[0] = c->py[1]; c->puv[0] = c->puv[1];
+    c->ring[1] = c->ring[2]; c->py[1] = c->py[2]; c->puv[1] = c->puv[2];
+    c->ring[2] = f;          c->py[2] = y;        c->puv[2] = uv;
     c->ring_phase = (c->ring_phase + 1) % 3;
     c->p.frame_count++;
     return HF_OK;
@@ -270,7 +276,7 @@ int update_common(hf_ctx* c, const void* src, hipMemcpyKind kind) {
     HF_HIP(c, hipEventRecord(c->ev_upload, c->stream));  // m_ofcStartedEvent (:20)
     c->upload_recorded = true;
     HF_HIP(c, hipMemcpyAsync(c->ring[0], src, c->in_bytes, kind, c->stream));
-    hf::launch_decimate(c->g, c->ring[0], c->grid[0], c->stream);
+    hf::launch_prep_frame(c->g, c->pl, c->ring[0], c->py[0], c->puv[0], c->stream);
     HF_HIP(c, hipGetLastError());
     rotate_after_upload(c);
     if (!c->async()) return sync_ctx(c);
@@ -341,12 +347,23 @@ int hf_create(const hf_config* cfg, hf_ctx** out_ctx) {
     c->out_bytes = bpp * ((size_t)g.H * g.out_stride + (size_t)(g.H / 2) * g.out_stride);  // :33
     c->plane_elems = (size_t)g.lw * g.lh;
     const int ws0 = initial_window(g.lw, g.lh);
-    // largest per-step window table: windows > 16 only, at most ceil(lw/32)*ceil(lh/32)
-    const size_t nwin_max = (size_t)((g.lw + 31) / 32) * ((g.lh + 31) / 32) + 1;
+    const int max_iters = ilog2(ws0);
+    c->pl = hf::make_phase_layout(g, max_iters);
+    {
+        size_t elems = 0;
+        for (int k = 0, w = ws0; k < max_iters; k++, w >>= 1) {
+            hf::FlowLevel L{};
+            L.window = w; L.log2w = ilog2(w);
+            L.nwx = (g.lw + w - 1) / w; L.nwy = (g.lh + w - 1) / w;
+            c->levels.push_back(L);
+            elems += 2 * (size_t)L.nwx * L.nwy;
+        }
+        c->tables_bytes = (elems + 8) * sizeof(int16_t);
+    }
+    // window sums: only levels with windows > 32 use them, at most ceil(lw/64)*ceil(lh/64) windows each
+    const size_t nwin_max = (size_t)((g.lw + 63) / 64) * ((g.lh + 63) / 64) + 1;
     c->sums_stride = nwin_max * 16;
     c->sums_bytes = (size_t)kMaxSteps * c->sums_stride * sizeof(uint32_t);
-    (void)ws0;
-
     int rc = HF_OK;
     auto bail = [&](int code) { std::string e = c->err; hf_destroy(c); g_create_error = e; return code; };
     if ((rc = set_device(c))) return bail(rc);
@@ -356,18 +373,25 @@ int hf_create(const hf_config* cfg, hf_ctx** out_ctx) {
     HF_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (int i = 0; i < 3; i++) {
         HF_TRY(hipMalloc(&c->ring[i], c->in_bytes));
-        HF_TRY(hipMalloc((void**)&c->grid[i], c->plane_elems * sizeof(uint32_t)));
+        HF_TRY(hipMalloc((void**)&c->py[i], c->pl.py_bytes));
+        HF_TRY(hipMalloc((void**)&c->puv[i], c->pl.puv_bytes));
         HF_TRY(hipMemsetAsync(c->ring[i], 0, c->in_bytes, c->stream));
-        HF_TRY(hipMemsetAsync(c->grid[i], 0, c->plane_elems * sizeof(uint32_t), c->stream));
+        HF_TRY(hipMemsetAsync(c->py[i], 0, c->pl.py_bytes, c->stream));
+        HF_TRY(hipMemsetAsync(c->puv[i], 0, c->pl.puv_bytes, c->stream));
     }
     HF_TRY(hipMalloc(&c->out_frame, c->out_bytes));
     HF_TRY(hipMemsetAsync(c->out_frame, 0, c->out_bytes, c->stream));
     c->out_target = c->out_frame;
-    for (int a = 0; a < 2; a++)
-        for (int b = 0; b < 2; b++) {
-            HF_TRY(hipMalloc((void**)&c->off[a][b], c->plane_elems * sizeof(int16_t)));
-            HF_TRY(hipMemsetAsync(c->off[a][b], 0, c->plane_elems * sizeof(int16_t), c->stream));
+    HF_TRY(hipMalloc((void**)&c->tables, c->tables_bytes));
+    HF_TRY(hipMemsetAsync(c->tables, 0, c->tables_bytes, c->stream));
+    {
+        size_t o = 0;
+        for (auto& L : c->levels) {
+            L.tx = c->tables + o; o += (size_t)L.nwx * L.nwy;
+            L.ty = c->tables + o; o += (size_t)L.nwx * L.nwy;
         }
+    }
+    HF_TRY(hipMalloc((void**)&c->off_view, 2 * c->plane_elems * sizeof(int16_t)));
     for (int i = 0; i < 2; i++) {
         HF_TRY(hipMalloc((void**)&c->blurred[i], 2 * c->plane_elems * sizeof(int16_t)));
         HF_TRY(hipMemsetAsync(c->blurred[i], 0, 2 * c->plane_elems * sizeof(int16_t), c->stream));
@@ -397,9 +421,10 @@ void hf_destroy(hf_ctx* c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);  // clFinish (opticalFlowCalcSDR.cpp:186)
     for (auto& kv : c->graphs) hipGraphExecDestroy(kv.second);
-    for (int i = 0; i < 3; i++) { if (c->ring[i]) hipFree(c->ring[i]); if (c->grid[i]) hipFree(c->grid[i]); }
+    for (int i = 0; i < 3; i++) { if (c->ring[i]) hipFree(c->ring[i]); if (c->py[i]) hipFree(c->py[i]); if (c->puv[i]) hipFree(c->puv[i]); }
+    if (c->tables) hipFree(c->tables);
+    if (c->off_view) hipFree(c->off_view);
     if (c->out_frame) hipFree(c->out_frame);
-    for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++) if (c->off[a][b]) hipFree(c->off[a][b]);
     for (int i = 0; i < 2; i++) { if (c->blurred[i]) hipFree(c->blurred[i]); if (c->blurred_xy[i]) hipFree(c->blurred_xy[i]); }
     if (c->sums) hipFree(c->sums);
     if (c->d_total_delta) hipFree(c->d_total_delta);
@@ -457,13 +482,10 @@ int hf_calculate_optical_flow(hf_ctx* c) {
             it = c->graphs.emplace(key, exec).first;
         } else {
             // replay path: recompute the bookkeeping enqueue_flow_chain() would have set
-            int window = initial_window(c->g.lw, c->g.lh);
-            int iters = ilog2(window);
-            if (c->cfg.iterations > 0 && c->cfg.iterations < iters) iters = c->cfg.iterations;
-            c->initial_window = window;
+            const int iters = effective_iterations(c);
+            c->initial_window = initial_window(c->g.lw, c->g.lh);
             c->last_iterations = iters;
-            c->off_cur[0] = iters & 1;
-            c->off_cur[1] = iters & 1;
+            c->last_level = iters ? c->levels[iters - 1] : hf::FlowLevel{};
         }
         span = span_begin(c, 2);
         HF_HIP(c, hipGraphLaunch(it->second, c->stream));
@@ -611,9 +633,9 @@ int hf_read_offsets(hf_ctx* c, int16_t* host_out) {
     if (!host_out) return fail(c, HF_ERR_INVALID_ARGUMENT, "hf_read_offsets: null");
     if (int rc = set_device(c)) return rc;
     if (int rc = sync_ctx(c)) return rc;
-    const size_t pb = c->plane_elems * sizeof(int16_t);
-    HF_HIP(c, hipMemcpy(host_out, c->off[0][c->off_cur[0]], pb, hipMemcpyDeviceToHost));
-    HF_HIP(c, hipMemcpy(host_out + c->plane_elems, c->off[1][c->off_cur[1]], pb, hipMemcpyDeviceToHost));
+    hf::launch_expand_offsets(c->g, c->last_level, c->off_view, c->stream);
+    HF_HIP(c, hipStreamSynchronize(c->stream));
+    HF_HIP(c, hipMemcpy(host_out, c->off_view, 2 * c->plane_elems * sizeof(int16_t), hipMemcpyDeviceToHost));
     return HF_OK;
 }
 

@@ -1,0 +1,504 @@
+// hopperrender_amd/csrc/hf_flow.hip -- the refinement chain of calculateOpticalFlow on gfx950.
+//
+// Replaces (reference HopperRender/): calcDeltaSumsKernel{SDR,HDR}.h:36-191,
+// determineLowestLayerKernelSDR.h:4-28, adjustOffsetArrayKernelSDR.h:4-21 and the fills of
+// opticalFlowCalcSDR.cpp:68-76.  Same results, different organisation (DESIGN.md "flow chain"):
+//
+//  1. PHASE PLANES.  A candidate samples frame N-1 at full-resolution x = (cx << rs) + offset, i.e.
+//     every 2^rs-th element starting at an arbitrary phase: 1 useful sample per 8-16 bytes.  At upload
+//     each frame is re-laid out once as top-8-bit phase planes
+//         PY [y ][ph ][j] = top8(Y [y ][mirror((j << rs) + ph)])
+//         PUV[y'][ph2][j] = top8 pair (U,V) at UV[y'][mirror((j << rs) + 2*ph2) & ~1]
+//     with j running over [-MX, lw + MX) so the reference's edge reflection
+//     (calcDeltaSumsKernelSDR.h:86-95) is baked in.  Offsets are constant inside a window (below), so
+//     the samples of a run of grid pixels are CONSECUTIVE bytes of one phase row: a lane fetches the
+//     4 luma bytes of 4 pixels with one dword load and their 4 chroma pairs with one dwordx2 load,
+//     and scores them with three v_sad_u8.  The grid samples of frame N are phase 0 of its own planes.
+//  2. PER-WINDOW STATE.  The chain starts from zero offsets (opticalFlowCalcSDR.cpp:68-69) and every
+//     update adds one value per window of a size the current size divides, so offsets, the offset bias
+//     (:105-109) and the neighbour bias (:112-144) are per-window constants:
+//         sum_w(cost) = (sum_w SAD) << deltaScalar + npix_w * (offsetBias + neighborBias)   (mod 2^32)
+//     Offsets therefore live in one small table per level (window size) instead of per pixel.
+//  3. FUSED STEPS.  For windows <= 32 one workgroup (or lane group) owns a window, and the Y step of a
+//     level only needs the window's own new X offset plus LAST level's Y offsets of its neighbours, so X
+//     and Y of a level run in ONE launch (5 launches for levels 32..2).  Larger windows take two
+//     launches per axis (partial sums with one atomic per candidate per workgroup, then a tiny argmin).
+#include "hf_kernels.h"
+
+namespace hf {
+
+namespace {
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
+
+// sgn(d)*d*d, d = layer - R/2 (calcDeltaSumsKernelSDR.h:70-74)
+__device__ __forceinline__ int rel_offset(int layer, int R) {
+    const int d = layer - (R >> 1);
+    return d > 0 ? d * d : -(d * d);
+}
+
+// single reflection of calcDeltaSumsKernelSDR.h:86-95; the clamp only acts where the reference would
+// index outside the frame (offsets larger than the frame) and keeps everything memory-safe
+__device__ __forceinline__ int mirror_clamp(int p, int dim) {
+    if (p >= dim) p = 2 * dim - p - 1; else if (p < 0) p = -p - 1;
+    return clampi(p, 0, dim - 1);
+}
+
+template <typename E> __device__ __forceinline__ unsigned top8(E v);
+template <> __device__ __forceinline__ unsigned top8<uint8_t>(uint8_t v) { return v; }
+template <> __device__ __forceinline__ unsigned top8<uint16_t>(uint16_t v) { return (unsigned)(v >> 8); }  // calcDeltaSumsKernelHDR.h:98
+
+// ------------------------------------------------------------------------------------------
+// phase planes
+// ------------------------------------------------------------------------------------------
+template <typename E>
+__global__ __launch_bounds__(256) void prep_phase_kernel(const E* __restrict__ f, uint8_t* __restrict__ py,
+                                                          uint16_t* __restrict__ puv, int H, int W, int S,
+                                                          PhaseLayout pl) {
+    const int row = blockIdx.y;                        // luma rows, then chroma rows
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int step = 1 << pl.rs;
+    if (row < H) {
+        const int chunks = pl.lwp >> 2;                // 4 outputs (one dword) per thread
+        if (t >= pl.nph * chunks) return;
+        const int ph = t / chunks, jc = t - ph * chunks;
+        const E* __restrict__ src = f + (size_t)row * S;
+        uint32_t v = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int j = jc * 4 + i - pl.mx;
+            v |= top8<E>(src[mirror_clamp(j * step + ph, W)]) << (8 * i);
+        }
+        *(uint32_t*)(py + ((size_t)row * pl.nph + ph) * pl.lwp + jc * 4) = v;
+    } else {
+        const int yc = row - H;
+        const int chunks = pl.lwp >> 1;                // 2 outputs (one dword) per thread
+        if (t >= pl.nph2 * chunks) return;
+        const int ph2 = t / chunks, jc = t - ph2 * chunks;
+        const E* __restrict__ src = f + (size_t)H * S + (size_t)yc * S;
+        uint32_t v = 0;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int j = jc * 2 + i - pl.mx;
+            const int x = mirror_clamp(j * step + 2 * ph2, W) & ~1;
+            v |= (top8<E>(src[x]) | (top8<E>(src[x + 1]) << 8)) << (16 * i);
+        }
+        *(uint32_t*)(puv + ((size_t)yc * pl.nph2 + ph2) * pl.lwp + jc * 2) = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// per-window constants
+// ------------------------------------------------------------------------------------------
+struct WinConst {
+    int ox, oy;                 // offsets of this window before the level's update
+    int nbx[4], nby[4];         // neighbour offsets (previous level) for the X and the Y step
+    uint32_t npix;              // grid pixels of the window that lie inside the grid
+};
+
+__device__ __forceinline__ int table_at(const int16_t* __restrict__ t, const FlowLevel& L, int px, int py) {
+    return t[(py >> L.log2w) * L.nwx + (px >> L.log2w)];
+}
+
+// Level `cur`, window (wx, wy).  prev.tx == nullptr <=> first level (all offsets zero).
+// use_cur_x: the X offset of this level has already been written (separate Y launch of a large window).
+__device__ __forceinline__ WinConst load_win_const(const Geom& g, const FlowStep& a, int wx, int wy, bool use_cur_x) {
+    WinConst w;
+    const int ws = a.cur.window;
+    const int x0 = wx << a.cur.log2w, y0 = wy << a.cur.log2w;
+    w.ox = w.oy = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { w.nbx[i] = 0; w.nby[i] = 0; }
+    if (a.prev.tx) {
+        w.ox = table_at(a.prev.tx, a.prev, x0, y0);
+        w.oy = table_at(a.prev.ty, a.prev, x0, y0);
+        if (a.use_neighbors) {  // calcDeltaSumsKernelSDR.h:112-131: neighbours at +-2*window, clamped to the grid;
+                                // the clamped neighbour of every pixel of a window falls into one previous-level window
+            const int d = 2 * ws;
+            const int xl = max(x0 - d, 0), xr = min(x0 + d, g.lw - 1);
+            const int yu = max(y0 - d, 0), yd = min(y0 + d, g.lh - 1);
+            w.nbx[0] = table_at(a.prev.tx, a.prev, x0, yd); w.nby[0] = table_at(a.prev.ty, a.prev, x0, yd);
+            w.nbx[1] = table_at(a.prev.tx, a.prev, xr, y0); w.nby[1] = table_at(a.prev.ty, a.prev, xr, y0);
+            w.nbx[2] = table_at(a.prev.tx, a.prev, xl, y0); w.nby[2] = table_at(a.prev.ty, a.prev, xl, y0);
+            w.nbx[3] = table_at(a.prev.tx, a.prev, x0, yu); w.nby[3] = table_at(a.prev.ty, a.prev, x0, yu);
+        }
+    }
+    if (use_cur_x) w.ox = a.cur.tx[wy * a.cur.nwx + wx];
+    w.npix = (uint32_t)((min(g.lw, x0 + ws) - x0) * (min(g.lh, y0 + ws) - y0));
+    return w;
+}
+
+// Per-window constant part of the cost of candidate offset `cand` (short arithmetic as in the reference).
+__device__ __forceinline__ uint32_t window_bias(int cand, bool use_nb, const int* nb, int nshift) {
+    uint32_t c = (uint32_t)(cand < 0 ? -cand : cand) & 0xFFFFu;                   // offsetBias, :105-109
+    if (use_nb) {
+        const uint32_t nbias = ((uint32_t)abs(nb[0] - cand) & 0xFFFFu) + ((uint32_t)abs(nb[1] - cand) & 0xFFFFu) +
+                               ((uint32_t)abs(nb[2] - cand) & 0xFFFFu) + ((uint32_t)abs(nb[3] - cand) & 0xFFFFu);
+        c += nbias << nshift;                                                     // :143
+    }
+    return c;
+}
+
+// ------------------------------------------------------------------------------------------
+// strip SADs: PX consecutive grid pixels of one row, all candidates of one axis
+// ------------------------------------------------------------------------------------------
+template <int PX> struct StripTypes;
+template <> struct StripTypes<4> { using Y = uint32_t; using UV = uint64_t; };
+template <> struct StripTypes<2> { using Y = uint16_t; using UV = uint32_t; };
+
+template <typename T>
+__device__ __forceinline__ T load_unaligned(const void* p) {
+    T v;
+    __builtin_memcpy(&v, p, sizeof(T));
+    return v;
+}
+
+template <int PX>
+struct Strip {
+    typename StripTypes<PX>::Y y2;    // frame-N luma bytes of the strip (masked)
+    typename StripTypes<PX>::UV uv2;  // frame-N chroma pairs of the strip (masked)
+    typename StripTypes<PX>::Y ymask;
+    typename StripTypes<PX>::UV uvmask;
+    int cx0, cy;
+    bool any;                         // at least one pixel inside the grid
+};
+
+template <int PX>
+__device__ __forceinline__ Strip<PX> load_strip(const Geom& g, const FlowStep& a, int cx0, int cy) {
+    using TY = typename StripTypes<PX>::Y;
+    using TUV = typename StripTypes<PX>::UV;
+    Strip<PX> s;
+    s.cx0 = cx0; s.cy = cy;
+    const int n = cy < g.lh ? clampi(g.lw - cx0, 0, PX) : 0;
+    s.any = n > 0;
+    s.ymask = n >= PX ? (TY)~(TY)0 : (TY)(((TY)1 << (8 * n)) - 1);
+    s.uvmask = n >= PX ? (TUV)~(TUV)0 : (TUV)(((TUV)1 << (16 * n)) - 1);
+    s.y2 = 0; s.uv2 = 0;
+    if (s.any) {
+        const PhaseLayout& pl = a.pl;
+        const int sy = cy << g.rs;   // grid samples of frame N = phase 0 of its own planes (:98-100, frame2 operands)
+        s.y2 = load_unaligned<TY>(a.py2 + (size_t)sy * pl.nph * pl.lwp + pl.mx + cx0) & s.ymask;
+        s.uv2 = load_unaligned<TUV>(a.puv2 + (size_t)(sy >> 1) * pl.nph2 * pl.lwp + pl.mx + cx0) & s.uvmask;
+    }
+    return s;
+}
+
+__device__ __forceinline__ uint32_t sad_strip(uint32_t y1, uint32_t y2, uint64_t uv1, uint64_t uv2) {
+    uint32_t s = __builtin_amdgcn_sad_u8(y1, y2, 0u);
+    s = __builtin_amdgcn_sad_u8((uint32_t)uv1, (uint32_t)uv2, s);
+    return __builtin_amdgcn_sad_u8((uint32_t)(uv1 >> 32), (uint32_t)(uv2 >> 32), s);
+}
+__device__ __forceinline__ uint32_t sad_strip(uint16_t y1, uint16_t y2, uint32_t uv1, uint32_t uv2) {
+    return __builtin_amdgcn_sad_u8(uv1, uv2, __builtin_amdgcn_sad_u8((uint32_t)y1, (uint32_t)y2, 0u));
+}
+
+// sad[cz] = sum over the strip of |dY| + |dU| + |dV| for candidate cz of `axis` (0 for cz >= R)
+template <int PX>
+__device__ __forceinline__ void strip_sads(uint32_t* sad, const Geom& g, const FlowStep& a, const Strip<PX>& s,
+                                           int ox, int oy, int axis) {
+    using TY = typename StripTypes<PX>::Y;
+    using TUV = typename StripTypes<PX>::UV;
+    const PhaseLayout& pl = a.pl;
+    const int sx = s.cx0 << g.rs, sy = s.cy << g.rs;
+    const int searched0 = axis ? oy : ox;
+    TY y1[16];
+    TUV uv1[16];
+#pragma unroll
+    for (int cz = 0; cz < 16; cz++) {
+        y1[cz] = 0; uv1[cz] = 0;
+        if (cz < a.R && s.any) {                                  // R is uniform
+            const int cand = (int)(int16_t)(searched0 + rel_offset(cz, a.R));  // short arithmetic, :75-76
+            const int nx = sx + (axis ? ox : cand);
+            const int ny = mirror_clamp(sy + (axis ? cand : oy), g.H);
+            const int j = clampi(nx >> g.rs, -pl.mx, g.lw + pl.mx);            // never clamps: |offset| <= margin by construction
+            const int ph = nx & (pl.nph - 1);
+            y1[cz] = load_unaligned<TY>(a.py1 + ((size_t)ny * pl.nph + ph) * pl.lwp + pl.mx + j);
+            uv1[cz] = load_unaligned<TUV>(a.puv1 + ((size_t)(ny >> 1) * pl.nph2 + (ph >> 1)) * pl.lwp + pl.mx + j);
+        }
+    }
+#pragma unroll
+    for (int cz = 0; cz < 16; cz++)
+        sad[cz] = (cz < a.R && s.any) ? sad_strip((TY)(y1[cz] & s.ymask), s.y2, (TUV)(uv1[cz] & s.uvmask), s.uv2) : 0u;
+}
+
+// ------------------------------------------------------------------------------------------
+// cross-lane reduction
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t shfl_xor_u32(uint32_t v, int m) { return (uint32_t)__shfl_xor((int)v, m, 64); }
+
+// One butterfly level: lanes l and l^M exchange halves of their NV values; afterwards each lane
+// holds NV/2 values, each the pair-sum of one candidate.  Lanes with bit M set keep the upper half.
+template <int NV, int M>
+__device__ __forceinline__ void butterfly_level(uint32_t* v, int lane) {
+    const bool hi = (lane & M) != 0;
+#pragma unroll
+    for (int k = 0; k < NV / 2; k++) {
+        const uint32_t send = hi ? v[k] : v[k + NV / 2];
+        const uint32_t keep = hi ? v[k + NV / 2] : v[k];
+        v[k] = keep + shfl_xor_u32(send, M);
+    }
+}
+
+struct Best { uint32_t sum; int cz; };
+__device__ __forceinline__ void best_min(Best& b, uint32_t s, int cz) {   // first minimum wins (strict '<', determineLowestLayerKernelSDR.h:19-24)
+    if (s < b.sum || (s == b.sum && cz < b.cz)) { b.sum = s; b.cz = cz; }
+}
+__device__ __forceinline__ void best_xor(Best& b, int m) {
+    const uint32_t s = shfl_xor_u32(b.sum, m);
+    const int c = __shfl_xor(b.cz, m, 64);
+    best_min(b, s, c);
+}
+
+// Reduces sad[16] over an aligned group of G lanes (G = 2, 4, 16, 64).  Afterwards each lane owns NOWN
+// consecutive candidates starting at `first` with their group totals in sad[0..NOWN).
+template <int G> struct Owned;
+template <> struct Owned<64> { static constexpr int n = 1; };
+template <> struct Owned<16> { static constexpr int n = 1; };
+template <> struct Owned<4> { static constexpr int n = 4; };
+template <> struct Owned<2> { static constexpr int n = 8; };
+
+template <int G>
+__device__ __forceinline__ int group_reduce(uint32_t* sad, int lane) {
+    if (G == 64) {
+        butterfly_level<16, 32>(sad, lane); butterfly_level<8, 16>(sad, lane);
+        butterfly_level<4, 8>(sad, lane);   butterfly_level<2, 4>(sad, lane);
+        sad[0] += shfl_xor_u32(sad[0], 2);
+        sad[0] += shfl_xor_u32(sad[0], 1);
+        return ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+    } else if (G == 16) {
+        butterfly_level<16, 8>(sad, lane); butterfly_level<8, 4>(sad, lane);
+        butterfly_level<4, 2>(sad, lane);  butterfly_level<2, 1>(sad, lane);
+        return ((lane >> 3) & 1) * 8 + ((lane >> 2) & 1) * 4 + ((lane >> 1) & 1) * 2 + (lane & 1);
+    } else if (G == 4) {
+        butterfly_level<16, 2>(sad, lane); butterfly_level<8, 1>(sad, lane);
+        return ((lane >> 1) & 1) * 8 + (lane & 1) * 4;
+    } else {
+        butterfly_level<16, 1>(sad, lane);
+        return (lane & 1) * 8;
+    }
+}
+
+// argmin over all candidates of the group; every lane of the group returns the same winner.
+// `captured` (optional) receives the full cost sum of candidate cap_cz.
+template <int G>
+__device__ __forceinline__ int group_argmin(const uint32_t* tot, int first, const FlowStep& a, int searched0,
+                                            const int* nb, uint32_t npix, int cap_cz, uint32_t* captured) {
+    Best b{0xFFFFFFFFu, 16};
+    uint32_t cap = 0;
+#pragma unroll
+    for (int k = 0; k < Owned<G>::n; k++) {
+        const int cz = first + k;
+        if (cz < a.R) {
+            const int cand = (int)(int16_t)(searched0 + rel_offset(cz, a.R));
+            const uint32_t sum = (tot[k] << a.delta_scalar) + npix * window_bias(cand, a.use_neighbors, nb, a.neighbor_scalar);
+            best_min(b, sum, cz);
+            if (cz == cap_cz) cap = sum;
+        }
+    }
+    if (G == 64) { best_xor(b, 4); best_xor(b, 8); best_xor(b, 16); best_xor(b, 32); }
+    else if (G == 16) { best_xor(b, 1); best_xor(b, 2); best_xor(b, 4); best_xor(b, 8); }
+    else if (G == 4) { best_xor(b, 1); best_xor(b, 2); }
+    else { best_xor(b, 1); }
+    if (captured) {
+        if (G == 64) { cap |= shfl_xor_u32(cap, 4); cap |= shfl_xor_u32(cap, 8); cap |= shfl_xor_u32(cap, 16); cap |= shfl_xor_u32(cap, 32); }
+        else if (G == 16) { cap |= shfl_xor_u32(cap, 1); cap |= shfl_xor_u32(cap, 2); cap |= shfl_xor_u32(cap, 4); cap |= shfl_xor_u32(cap, 8); }
+        else if (G == 4) { cap |= shfl_xor_u32(cap, 1); cap |= shfl_xor_u32(cap, 2); }
+        else { cap |= shfl_xor_u32(cap, 1); }
+        *captured = cap;
+    }
+    return b.cz;
+}
+
+// ------------------------------------------------------------------------------------------
+// lane -> strip mapping: every window of size WS is an aligned, contiguous lane group
+// ------------------------------------------------------------------------------------------
+template <int WS> struct Map;
+template <> struct Map<32> {   // workgroup tile 32x32 = one window; wave = 8 rows
+    static constexpr int PX = 4, G = 64, TW = 32, TH = 32;
+    __device__ static void at(int tid, int& x, int& y) { x = (tid & 7) * 4; y = tid >> 3; }
+};
+template <> struct Map<16> {   // wave = one 16x16 window; workgroup = 2x2 windows
+    static constexpr int PX = 4, G = 64, TW = 32, TH = 32;
+    __device__ static void at(int tid, int& x, int& y) {
+        const int w = tid >> 6, l = tid & 63;
+        x = (w & 1) * 16 + (l & 3) * 4; y = (w >> 1) * 16 + (l >> 2);
+    }
+};
+template <> struct Map<8> {    // 16 lanes = one 8x8 window; wave = 2x2 windows
+    static constexpr int PX = 4, G = 16, TW = 32, TH = 32;
+    __device__ static void at(int tid, int& x, int& y) {
+        const int w = tid >> 6, l = tid & 63, gi = l >> 4, i = l & 15;
+        x = (w & 1) * 16 + (gi & 1) * 8 + (i & 1) * 4; y = (w >> 1) * 16 + (gi >> 1) * 8 + (i >> 1);
+    }
+};
+template <> struct Map<4> {    // 4 lanes = one 4x4 window; wave = 4x4 windows
+    static constexpr int PX = 4, G = 4, TW = 32, TH = 32;
+    __device__ static void at(int tid, int& x, int& y) {
+        const int w = tid >> 6, l = tid & 63, gi = l >> 2;
+        x = (w & 1) * 16 + (gi & 3) * 4; y = (w >> 1) * 16 + (gi >> 2) * 4 + (l & 3);
+    }
+};
+template <> struct Map<2> {    // 2 lanes = one 2x2 window; wave = 8x4 windows; workgroup tile 16x32
+    static constexpr int PX = 2, G = 2, TW = 16, TH = 32;
+    __device__ static void at(int tid, int& x, int& y) {
+        const int w = tid >> 6, l = tid & 63, gi = l >> 1;
+        x = (gi & 7) * 2; y = w * 8 + (gi >> 3) * 2 + (l & 1);
+    }
+};
+
+// One level, X step then Y step, windows <= 32.
+template <int WS>
+__global__ __launch_bounds__(256) void flow_level_small_kernel(const Geom g, const FlowStep a) {
+    using M = Map<WS>;
+    constexpr int PX = M::PX, G = M::G;
+    __shared__ uint32_t s_part[2][4][16];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    int lx, ly;
+    M::at(tid, lx, ly);
+    const int cx0 = blockIdx.x * M::TW + lx, cy = blockIdx.y * M::TH + ly;
+    const int wx = cx0 >> a.cur.log2w, wy = cy >> a.cur.log2w;
+    const bool win_in = (wx << a.cur.log2w) < g.lw && (wy << a.cur.log2w) < g.lh;   // whole lane group agrees
+
+    WinConst wc{};
+    if (win_in) wc = load_win_const(g, a, wx, wy, false);
+    const Strip<PX> strip = load_strip<PX>(g, a, cx0, cy);
+    const int cap_cz = (a.R >> 1) - 1;
+    uint32_t captured = 0;
+    int off[2] = {wc.ox, wc.oy};
+
+#pragma unroll
+    for (int axis = 0; axis < 2; axis++) {
+        uint32_t sad[16];
+        strip_sads<PX>(sad, g, a, strip, off[0], off[1], axis);
+        int first = group_reduce<G>(sad, lane);
+        if (WS == 32) {   // four waves share the window
+            if ((lane & 3) == 0) s_part[axis][wave][first] = sad[0];
+            __syncthreads();
+            sad[0] = s_part[axis][0][first] + s_part[axis][1][first] + s_part[axis][2][first] + s_part[axis][3][first];
+        }
+        const int best = group_argmin<G>(sad, first, a, off[axis], axis ? wc.nby : wc.nbx, wc.npix, cap_cz,
+                                         (axis == 0 && a.capture_delta) ? &captured : nullptr);
+        off[axis] = (int)(int16_t)(off[axis] + rel_offset(best, a.R));   // adjustOffsetArrayKernelSDR.h:13-19
+    }
+
+    const bool leader = WS == 32 ? tid == 0 : (lane & (G - 1)) == 0;
+    if (win_in && leader) {
+        a.cur.tx[wy * a.cur.nwx + wx] = (int16_t)off[0];
+        a.cur.ty[wy * a.cur.nwx + wx] = (int16_t)off[1];
+        if (a.capture_delta && wx == 0 && wy == 0) *a.total_delta = captured / a.delta_divisor;   // opticalFlowCalcSDR.cpp:91-94
+    }
+}
+
+// Windows > 32, one axis: raw SAD sums of a 32x32 tile -> one atomic per candidate.
+__global__ __launch_bounds__(256) void flow_big_partial_kernel(const Geom g, const FlowStep a) {
+    using M = Map<32>;
+    __shared__ uint32_t s_part[4][16];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    int lx, ly;
+    M::at(tid, lx, ly);
+    const int cx0 = blockIdx.x * 32 + lx, cy = blockIdx.y * 32 + ly;
+    const int wx = (blockIdx.x * 32) >> a.cur.log2w, wy = (blockIdx.y * 32) >> a.cur.log2w;   // tile lies in one window
+    int ox = 0, oy = 0;
+    if (a.prev.tx) {
+        ox = table_at(a.prev.tx, a.prev, wx << a.cur.log2w, wy << a.cur.log2w);
+        oy = table_at(a.prev.ty, a.prev, wx << a.cur.log2w, wy << a.cur.log2w);
+    }
+    if (a.axis == 1) ox = a.cur.tx[wy * a.cur.nwx + wx];
+    const Strip<4> strip = load_strip<4>(g, a, cx0, cy);
+    uint32_t sad[16];
+    strip_sads<4>(sad, g, a, strip, ox, oy, a.axis);
+    const int first = group_reduce<64>(sad, lane);
+    if ((lane & 3) == 0) s_part[wave][first] = sad[0];
+    __syncthreads();
+    if (tid < a.R)
+        atomicAdd(&a.sums[(wy * a.cur.nwx + wx) * 16 + tid], s_part[0][tid] + s_part[1][tid] + s_part[2][tid] + s_part[3][tid]);
+}
+
+// Windows > 32, one axis: 16 lanes per window finish the sums, pick the winner, update the table.
+__global__ __launch_bounds__(256) void flow_big_argmin_kernel(const Geom g, const FlowStep a) {
+    const int lane16 = threadIdx.x & 15;
+    const int nwin = a.cur.nwx * a.cur.nwy;
+    for (int w = blockIdx.x * 16 + (threadIdx.x >> 4); w < nwin; w += gridDim.x * 16) {
+        const int wy = w / a.cur.nwx, wx = w - wy * a.cur.nwx;
+        const WinConst wc = load_win_const(g, a, wx, wy, a.axis == 1);
+        const int searched0 = a.axis ? wc.oy : wc.ox;
+        Best b{0xFFFFFFFFu, 16};
+        uint32_t mine = 0;
+        if (lane16 < a.R) {
+            const int cand = (int)(int16_t)(searched0 + rel_offset(lane16, a.R));
+            mine = (a.sums[w * 16 + lane16] << a.delta_scalar) +
+                   wc.npix * window_bias(cand, a.use_neighbors, a.axis ? wc.nby : wc.nbx, a.neighbor_scalar);
+            b.sum = mine; b.cz = lane16;
+        }
+        best_xor(b, 1); best_xor(b, 2); best_xor(b, 4); best_xor(b, 8);
+        if (lane16 == 0) {
+            int16_t* t = a.axis ? a.cur.ty : a.cur.tx;
+            t[w] = (int16_t)(searched0 + rel_offset(b.cz, a.R));
+        }
+        if (a.capture_delta && w == 0 && lane16 == (a.R >> 1) - 1) *a.total_delta = mine / a.delta_divisor;
+    }
+}
+
+// m_offsetArray view of the last level: int16 [2][lh][lw]
+__global__ void expand_offsets_kernel(const Geom g, const FlowLevel L, int16_t* __restrict__ out) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= g.lw || y >= g.lh) return;
+    const size_t p = (size_t)y * g.lw + x, N = (size_t)g.lw * g.lh;
+    out[p] = L.tx ? (int16_t)table_at(L.tx, L, x, y) : (int16_t)0;
+    out[N + p] = L.ty ? (int16_t)table_at(L.ty, L, x, y) : (int16_t)0;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+PhaseLayout make_phase_layout(const Geom& g, int max_iterations) {
+    PhaseLayout pl{};
+    pl.rs = g.rs;
+    pl.nph = 1 << g.rs;
+    pl.nph2 = pl.nph > 1 ? pl.nph / 2 : 1;
+    const int reach = (max_iterations + 1) * 64 + 8;   // |offset| <= iterations * (R/2)^2, + one candidate, R <= 16
+    pl.mx = (reach >> g.rs) + 2;
+    pl.lwp = ((g.lw + 2 * pl.mx + 8 + 15) / 16) * 16;
+    pl.py_bytes = (size_t)g.H * pl.nph * pl.lwp;
+    pl.puv_bytes = (size_t)(g.H / 2) * pl.nph2 * pl.lwp * sizeof(uint16_t);
+    return pl;
+}
+
+void launch_prep_frame(const Geom& g, const PhaseLayout& pl, const void* frame, uint8_t* py, uint16_t* puv, hipStream_t stream) {
+    const int per_row = pl.nph * (pl.lwp >> 2) > pl.nph2 * (pl.lwp >> 1) ? pl.nph * (pl.lwp >> 2) : pl.nph2 * (pl.lwp >> 1);
+    const dim3 grd((per_row + 255) / 256, g.H + g.H / 2);
+    if (g.hdr) prep_phase_kernel<uint16_t><<<grd, 256, 0, stream>>>((const uint16_t*)frame, py, puv, g.H, g.W, g.in_stride, pl);
+    else prep_phase_kernel<uint8_t><<<grd, 256, 0, stream>>>((const uint8_t*)frame, py, puv, g.H, g.W, g.in_stride, pl);
+}
+
+void launch_flow_level_small(const Geom& g, const FlowStep& a, hipStream_t stream) {
+    const int ws = a.cur.window;
+    const int tw = ws == 2 ? 16 : 32;
+    const dim3 grd((g.lw + tw - 1) / tw, (g.lh + 31) / 32);
+    switch (ws) {
+        case 32: flow_level_small_kernel<32><<<grd, 256, 0, stream>>>(g, a); break;
+        case 16: flow_level_small_kernel<16><<<grd, 256, 0, stream>>>(g, a); break;
+        case 8: flow_level_small_kernel<8><<<grd, 256, 0, stream>>>(g, a); break;
+        case 4: flow_level_small_kernel<4><<<grd, 256, 0, stream>>>(g, a); break;
+        default: flow_level_small_kernel<2><<<grd, 256, 0, stream>>>(g, a); break;
+    }
+}
+
+void launch_flow_big_partial(const Geom& g, const FlowStep& a, hipStream_t stream) {
+    const dim3 grd((g.lw + 31) / 32, (g.lh + 31) / 32);
+    flow_big_partial_kernel<<<grd, 256, 0, stream>>>(g, a);
+}
+
+void launch_flow_big_argmin(const Geom& g, const FlowStep& a, hipStream_t stream) {
+    const int nwin = a.cur.nwx * a.cur.nwy;
+    flow_big_argmin_kernel<<<(nwin + 15) / 16, 256, 0, stream>>>(g, a);
+}
+
+void launch_expand_offsets(const Geom& g, const FlowLevel& last, int16_t* out, hipStream_t stream) {
+    const dim3 grd((g.lw + 63) / 64, (g.lh + 3) / 4);
+    expand_offsets_kernel<<<grd, 256, 0, stream>>>(g, last, out);
+}
+
+}  // namespace hf

@@ -19,35 +19,54 @@ struct Geom {
     int lw, lh;          // low-res grid
 };
 
-// One refinement step = one candidate axis at one window size
+// Phase-plane layout of a frame (hf_flow.hip): PY[y][ph][j], PUV[y/2][ph/2][j], j in [-mx, lwp - mx).
+struct PhaseLayout {
+    int rs, nph, nph2;       // 2^rs luma phases, max(1, nph/2) chroma phases
+    int mx;                  // left margin in grid units (covers every reachable offset, reflection baked in)
+    int lwp;                 // row pitch in elements (multiple of 16)
+    size_t py_bytes, puv_bytes;
+};
+PhaseLayout make_phase_layout(const Geom& g, int max_iterations);
+
+// Offsets of one refinement level: one (x, y) pair per window of size `window`.
+struct FlowLevel {
+    int window, log2w;       // window size (power of two >= 2)
+    int nwx, nwy;            // windows per grid row / column
+    int16_t* tx;             // [nwy][nwx] X offsets after this level (nullptr: level does not exist = all zero)
+    int16_t* ty;             // [nwy][nwx] Y offsets after this level
+};
+
+// One level (or one axis of a level for windows > 32) of the refinement chain
 // (calcDeltaSums + determineLowestLayer + adjustOffsetArray of the reference).
-struct StepArgs {
-    const void* frame1;      // frame N-1, full resolution (candidates are sampled here)
-    const uint32_t* grid2;   // frame N decimated to the flow grid: Y | U<<8 | V<<16 | valid<<24
-    const int16_t* off_x;    // current X offsets [lh][lw]
-    const int16_t* off_y;    // current Y offsets [lh][lw]
-    int16_t* off_out;        // new offsets of the searched axis [lh][lw] (ping-pong partner)
-    uint32_t* sums;          // [n_windows][16] window cost sums (windows larger than a workgroup)
+struct FlowStep {
+    const uint8_t* py1;      // frame N-1 phase planes (candidates are sampled here)
+    const uint16_t* puv1;
+    const uint8_t* py2;      // frame N phase planes (its phase 0 = the grid samples)
+    const uint16_t* puv2;
+    PhaseLayout pl;
+    FlowLevel cur, prev;     // prev.tx == nullptr on the first level
+    uint32_t* sums;          // [n_windows][16] raw SAD sums (windows > 32 only)
     uint32_t* total_delta;   // device slot of m_totalFrameDelta
-    int window;              // window size (power of two >= 2)
-    int window_log2;
-    int n_win_x;             // windows per grid row
-    int R;                   // search radius = candidate count (5..16)
-    int step;                // 0: search X, 1: search Y
+    int axis;                // windows > 32: 0 = X step, 1 = Y step
+    int R;                   // search radius = candidate count (2..16)
     int use_neighbors;       // iteration >= 4 (calcDeltaSumsKernelSDR.h:3,112)
     int delta_scalar, neighbor_scalar;
     int capture_delta;       // first step of the chain: emit m_totalFrameDelta
     uint32_t delta_divisor;  // lh*lw*10 (SDR) / lh*lw*6 (HDR)
 };
 
-void launch_decimate(const Geom& g, const void* frame, uint32_t* grid, hipStream_t stream);
-// Cost + window reduction; for windows <= 16 also argmin + offset update (single launch per step).
-void launch_flow_step(const Geom& g, const StepArgs& a, hipStream_t stream);
-// Windows > 16: argmin over the summed costs + offset update of every pixel of the window.
-void launch_argmin_adjust(const Geom& g, const StepArgs& a, hipStream_t stream);
-// blurFlowKernel with a runtime radius (4 == reference); in: two planes, out: [2][lh][lw].
+// Re-lay a freshly uploaded frame as phase planes (once per frame).
+void launch_prep_frame(const Geom& g, const PhaseLayout& pl, const void* frame, uint8_t* py, uint16_t* puv, hipStream_t stream);
+// Windows <= 32: X and Y step of one level in a single launch.
+void launch_flow_level_small(const Geom& g, const FlowStep& a, hipStream_t stream);
+// Windows > 32, one axis: partial SAD sums (atomics), then argmin + table update.
+void launch_flow_big_partial(const Geom& g, const FlowStep& a, hipStream_t stream);
+void launch_flow_big_argmin(const Geom& g, const FlowStep& a, hipStream_t stream);
+// m_offsetArray view ([2][lh][lw] int16) of the last level, for parity taps.
+void launch_expand_offsets(const Geom& g, const FlowLevel& last, int16_t* out, hipStream_t stream);
+// blurFlowKernel with a runtime radius (4 == reference); in: offsets of the last level, out: [2][lh][lw].
 // Also writes `packed` = x | y << 16 per grid point (what the fast warp kernel reads).
-void launch_blur_flow(const Geom& g, const int16_t* off_x, const int16_t* off_y, int16_t* blurred, uint32_t* packed,
+void launch_blur_flow(const Geom& g, const FlowLevel& last, int16_t* blurred, uint32_t* packed,
                       int radius, hipStream_t stream);
 void launch_pack_flow(const Geom& g, const int16_t* flow, uint32_t* packed, hipStream_t stream);
 // warpFrameKernel, both planes in one launch.  black/white already scaled for HDR.

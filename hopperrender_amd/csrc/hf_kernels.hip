@@ -3,13 +3,7 @@
 // only fused operations are the ones written explicitly (see "fp32 flavour" below).
 //
 // What each kernel replaces (reference HopperRender/):
-//   decimate_kernel      - the frame2 half of calcDeltaSumsKernel{SDR,HDR}.h:98-100, hoisted: the
-//                          grid samples of frame N are candidate-independent, so they are gathered
-//                          ONCE per frame instead of 16 steps x R candidates times.
-//   flow_step_kernel     - calcDeltaSumsKernel{SDR,HDR}.h:36-191; for windows <= 16 also
-//                          determineLowestLayerKernelSDR.h:4-28 + adjustOffsetArrayKernelSDR.h:4-21
-//                          (one launch per step, no sums buffer, no fills, no atomics).
-//   argmin_adjust_kernel - determineLowestLayer + adjustOffsetArray for windows > 16.
+//   (the refinement chain -- calcDeltaSums / determineLowestLayer / adjustOffsetArray -- is hf_flow.hip)
 //   blur_flow_kernel     - blurFlowKernelSDR.h:17-92, separable through LDS, runtime radius.
 //   warp_kernel          - warpFrameKernel{SDR,HDR}.h:116-184 (all 7 modes), both planes, one launch.
 //   copy_kernel          - copyFrameKernel{SDR,HDR}.h:12-25, both planes, one launch.
@@ -51,281 +45,6 @@ __device__ __forceinline__ int rel_offset(int layer, int R) {
 }
 
 // ------------------------------------------------------------------------------------------
-// decimate: frame N -> packed grid samples
-// ------------------------------------------------------------------------------------------
-template <typename E>
-__global__ __launch_bounds__(256) void decimate_kernel(const E* __restrict__ f, uint32_t* __restrict__ grid,
-                                                        int H, int W, int S, int rs, int lw, int lh) {
-    using T = ElemTraits<E>;
-    const int cx = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int cy = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (cx >= lw || cy >= lh) return;
-    const int sx = cx << rs, sy = cy << rs;
-    uint32_t p = 0;
-    if (sx < W && sy < H) {  // calcDeltaSumsKernelSDR.h:82 (always true for lw = ceil(W / 2^rs))
-        const E* uv = f + (size_t)H * S + (size_t)(sy >> 1) * S + (sx & ~1);
-        p = T::top8(f[(size_t)sy * S + sx]) | (T::top8(uv[0]) << 8) | (T::top8(uv[1]) << 16) | (1u << 24);
-    }
-    grid[(size_t)cy * lw + cx] = p;
-}
-
-// ------------------------------------------------------------------------------------------
-// flow step
-// ------------------------------------------------------------------------------------------
-//
-// Structure exploited (all exact, see DESIGN.md "flow step"):
-//  * Inside one chain the offsets are constant over every window of the CURRENT size: the chain
-//    starts from zero (opticalFlowCalcSDR.cpp:68-69) and every update adds one value per window of a
-//    size that the current size divides.  Hence the candidate offset, the offset bias
-//    (calcDeltaSumsKernelSDR.h:105-109) and the neighbour bias (:112-144; the clamped neighbour of
-//    every pixel of a window falls into ONE window) are per-window constants, and
-//        sum_w(cost) = (sum_w SAD) << deltaScalar  +  npix_w * (offsetBias + neighborBias)   (mod 2^32)
-//    so the per-pixel work is just the 3-sample SAD, done with v_sad_u8 on packed (Y,U,V) bytes.
-//  * All R candidates of a pixel are issued before any is consumed (2 loads each in flight) and the
-//    16 per-lane partial sums are reduced with a transposing butterfly: 17 cross-lane moves for a
-//    64-lane window instead of 16 x 6.
-
-// Lane -> pixel inside the workgroup's 16x16 grid tile, chosen so that every window of the
-// current size is a contiguous, aligned lane group (64, 64, 16 or 4 lanes).
-__device__ __forceinline__ void lane_to_tile_xy(int window, int wave, int lane, int& lx, int& ly) {
-    if (window >= 16) {            // tile = (part of) one window; wave = 16x4 strip
-        lx = lane & 15;
-        ly = wave * 4 + (lane >> 4);
-    } else {
-        int gx, gy, ix, iy;
-        if (window == 8) {         // wave = one 8x8 window
-            gx = 0; gy = 0; ix = lane & 7; iy = lane >> 3;
-        } else if (window == 4) {  // 16 lanes = one 4x4 window
-            const int g = lane >> 4, i = lane & 15;
-            gx = (g & 1) * 4; gy = (g >> 1) * 4; ix = i & 3; iy = i >> 2;
-        } else {                   // 4 lanes = one 2x2 window
-            const int g = lane >> 2, i = lane & 3;
-            gx = (g & 3) * 2; gy = (g >> 2) * 2; ix = i & 1; iy = i >> 1;
-        }
-        lx = (wave & 1) * 8 + gx + ix;
-        ly = (wave >> 1) * 8 + gy + iy;
-    }
-}
-
-__device__ __forceinline__ uint32_t shfl_xor_u32(uint32_t v, int m) { return (uint32_t)__shfl_xor((int)v, m, 64); }
-
-// One butterfly level: lanes l and l^M exchange halves of their NV values; afterwards each lane
-// holds NV/2 values, each the pair-sum of one candidate.  Lanes with bit M set keep the upper half.
-template <int NV, int M>
-__device__ __forceinline__ void butterfly_level(uint32_t* v, int lane) {
-    const bool hi = (lane & M) != 0;
-#pragma unroll
-    for (int k = 0; k < NV / 2; k++) {
-        const uint32_t send = hi ? v[k] : v[k + NV / 2];
-        const uint32_t keep = hi ? v[k + NV / 2] : v[k];
-        v[k] = keep + shfl_xor_u32(send, M);
-    }
-}
-
-struct Best { uint32_t sum; int cz; };
-__device__ __forceinline__ void best_min(Best& b, uint32_t s, int cz) {   // first minimum wins (strict '<')
-    if (s < b.sum || (s == b.sum && cz < b.cz)) { b.sum = s; b.cz = cz; }
-}
-__device__ __forceinline__ void best_xor(Best& b, int m) {
-    const uint32_t s = shfl_xor_u32(b.sum, m);
-    const int c = __shfl_xor(b.cz, m, 64);
-    best_min(b, s, c);
-}
-
-// Per-window constant part of the cost of candidate offset `cand` (short arithmetic as in the reference).
-__device__ __forceinline__ uint32_t window_bias(int cand, bool use_nb, int nb0, int nb1, int nb2, int nb3, int nshift) {
-    uint32_t c = (uint32_t)(cand < 0 ? -cand : cand) & 0xFFFFu;                   // offsetBias, :105-109
-    if (use_nb) {
-        const uint32_t nbias = ((uint32_t)abs(nb0 - cand) & 0xFFFFu) + ((uint32_t)abs(nb1 - cand) & 0xFFFFu) +
-                               ((uint32_t)abs(nb2 - cand) & 0xFFFFu) + ((uint32_t)abs(nb3 - cand) & 0xFFFFu);
-        c += nbias << nshift;                                                     // :143
-    }
-    return c;
-}
-
-// Window-constant inputs, read at the window origin (always inside the grid).
-struct WindowConst { int ox, oy, nb0, nb1, nb2, nb3; uint32_t npix; };
-__device__ __forceinline__ WindowConst load_window_const(const Geom& g, const StepArgs& a, int wx0, int wy0) {
-    WindowConst w;
-    const size_t p = (size_t)wy0 * g.lw + wx0;
-    w.ox = a.off_x[p];
-    w.oy = a.off_y[p];
-    w.nb0 = w.nb1 = w.nb2 = w.nb3 = 0;
-    if (a.use_neighbors) {  // :112-131 ; the clamped neighbour of every pixel of the window lies in one window
-        const int16_t* __restrict__ plane = a.step ? a.off_y : a.off_x;
-        const int d = 2 * a.window;
-        const int xl = max(wx0 - d, 0), xr = min(wx0 + d, g.lw - 1);
-        const int yu = max(wy0 - d, 0), yd = min(wy0 + d, g.lh - 1);
-        w.nb0 = plane[(size_t)yd * g.lw + wx0];
-        w.nb1 = plane[(size_t)wy0 * g.lw + xr];
-        w.nb2 = plane[(size_t)wy0 * g.lw + xl];
-        w.nb3 = plane[(size_t)yu * g.lw + wx0];
-    }
-    w.npix = (uint32_t)((min(g.lw, wx0 + a.window) - wx0) * (min(g.lh, wy0 + a.window) - wy0));
-    return w;
-}
-
-template <typename E>
-__global__ __launch_bounds__(256) void flow_step_kernel(const Geom g, const StepArgs a) {
-    using T = ElemTraits<E>;
-    __shared__ uint32_t s_part[4][16];
-
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    int lx, ly;
-    lane_to_tile_xy(a.window, wave, lane, lx, ly);
-    const int cx = blockIdx.x * 16 + lx, cy = blockIdx.y * 16 + ly;
-    const bool in = cx < g.lw && cy < g.lh;
-    const E* __restrict__ f1 = (const E*)a.frame1;
-    const int W = g.W, H = g.H, S = g.in_stride, R = a.R;
-    const size_t uv_base = (size_t)H * S;
-    const int wx0 = (cx >> a.window_log2) << a.window_log2, wy0 = (cy >> a.window_log2) << a.window_log2;
-    const bool win_in = wx0 < g.lw && wy0 < g.lh;   // false only for lanes of windows entirely outside the grid
-
-    WindowConst wc{};
-    if (win_in) wc = load_window_const(g, a, wx0, wy0);
-    uint32_t p2 = 0;
-    if (in) p2 = a.grid2[(size_t)cy * g.lw + cx];
-    const bool valid = in && (p2 >> 24) != 0;       // calcDeltaSumsKernelSDR.h:82
-    p2 &= 0x00FFFFFFu;
-    const int sx = cx << g.rs, sy = cy << g.rs;
-    const int searched0 = a.step ? wc.oy : wc.ox;
-
-    // ---- 1. all candidates: addresses, loads, SAD --------------------------------------------
-    uint32_t sad[16];
-    {
-        unsigned y1[16], uv1a[16], uv1b[16];
-#pragma unroll
-        for (int cz = 0; cz < 16; cz++) {
-            y1[cz] = 0; uv1a[cz] = 0; uv1b[cz] = 0;
-            if (cz < R && valid) {                  // R is wave-uniform
-                const int cand = (int)(int16_t)(searched0 + rel_offset(cz, R));  // short arithmetic, :75-76
-                int nx = sx + (a.step ? wc.ox : cand);
-                int ny = sy + (a.step ? cand : wc.oy);
-                // single reflection (:86-95); the final clamp only acts where the reference indexes
-                // outside the frame (offsets larger than the frame), keeping the kernel memory-safe
-                if (nx >= W) nx = 2 * W - nx - 1; else if (nx < 0) nx = -nx - 1;
-                if (ny >= H) ny = 2 * H - ny - 1; else if (ny < 0) ny = -ny - 1;
-                nx = clampi(nx, 0, W - 1);
-                ny = clampi(ny, 0, H - 1);
-                const E* uv = f1 + uv_base + (size_t)(ny >> 1) * S + (nx & ~1);
-                y1[cz] = f1[(size_t)ny * S + nx];
-                uv1a[cz] = uv[0];
-                uv1b[cz] = uv[1];
-            }
-        }
-#pragma unroll
-        for (int cz = 0; cz < 16; cz++) {
-            const uint32_t p1 = T::top8((E)y1[cz]) | (T::top8((E)uv1a[cz]) << 8) | (T::top8((E)uv1b[cz]) << 16);
-            sad[cz] = (cz < R && valid) ? __builtin_amdgcn_sad_u8(p1, p2, 0u) : 0u;   // |dY| + |dU| + |dV|, :98-100
-        }
-    }
-
-    // ---- 2. window reduction -------------------------------------------------------------------
-    // after the butterfly each lane owns ONE candidate `my_cz` and holds its sum over the lane group
-    int my_cz;
-    uint32_t tot;
-    if (a.window >= 8) {
-        butterfly_level<16, 32>(sad, lane); butterfly_level<8, 16>(sad, lane);
-        butterfly_level<4, 8>(sad, lane);   butterfly_level<2, 4>(sad, lane);
-        tot = sad[0];
-        tot += shfl_xor_u32(tot, 2);
-        tot += shfl_xor_u32(tot, 1);
-        my_cz = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
-    } else if (a.window == 4) {
-        butterfly_level<16, 8>(sad, lane); butterfly_level<8, 4>(sad, lane);
-        butterfly_level<4, 2>(sad, lane);  butterfly_level<2, 1>(sad, lane);
-        tot = sad[0];
-        my_cz = ((lane >> 3) & 1) * 8 + ((lane >> 2) & 1) * 4 + ((lane >> 1) & 1) * 2 + (lane & 1);
-    } else {
-        butterfly_level<16, 2>(sad, lane); butterfly_level<8, 1>(sad, lane);
-        tot = 0;  // four candidates per lane, handled below
-        my_cz = ((lane >> 1) & 1) * 8 + (lane & 1) * 4;
-    }
-
-    if (a.window >= 16) {
-        if ((lane & 3) == 0) s_part[wave][my_cz] = tot;
-        __syncthreads();
-        if (a.window > 16) {   // window spans many workgroups: one atomic per candidate per workgroup (raw SAD sums)
-            if (tid < R) {
-                const uint32_t s = s_part[0][tid] + s_part[1][tid] + s_part[2][tid] + s_part[3][tid];
-                const int win = ((blockIdx.y * 16) >> a.window_log2) * a.n_win_x + ((blockIdx.x * 16) >> a.window_log2);
-                atomicAdd(&a.sums[win * 16 + tid], s);
-            }
-            return;
-        }
-        tot = s_part[0][my_cz] + s_part[1][my_cz] + s_part[2][my_cz] + s_part[3][my_cz];
-    }
-
-    // ---- 3. argmin over candidates + offset update (windows <= 16) -------------------------------
-    Best b{0xFFFFFFFFu, 16};
-    uint32_t captured = 0;
-    const int cap_cz = (R >> 1) - 1;
-    if (a.window >= 4) {
-        if (my_cz < R) {
-            const int cand = (int)(int16_t)(searched0 + rel_offset(my_cz, R));
-            b.sum = (tot << a.delta_scalar) + wc.npix * window_bias(cand, a.use_neighbors, wc.nb0, wc.nb1, wc.nb2, wc.nb3, a.neighbor_scalar);
-            b.cz = my_cz;
-        }
-        if (a.capture_delta) { captured = (my_cz == cap_cz) ? b.sum : 0u; }
-        if (a.window >= 8) { best_xor(b, 4); best_xor(b, 8); best_xor(b, 16); best_xor(b, 32); }
-        else { best_xor(b, 1); best_xor(b, 2); best_xor(b, 4); best_xor(b, 8); }
-        if (a.capture_delta) {  // only window (0,0) of a first step is captured: bring its candidate sum to lane 0
-            if (a.window >= 8) { captured |= shfl_xor_u32(captured, 4); captured |= shfl_xor_u32(captured, 8); captured |= shfl_xor_u32(captured, 16); captured |= shfl_xor_u32(captured, 32); }
-            else { captured |= shfl_xor_u32(captured, 1); captured |= shfl_xor_u32(captured, 2); captured |= shfl_xor_u32(captured, 4); captured |= shfl_xor_u32(captured, 8); }
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int cz = my_cz + k;
-            if (cz < R) {
-                const int cand = (int)(int16_t)(searched0 + rel_offset(cz, R));
-                const uint32_t sum = (sad[k] << a.delta_scalar) + wc.npix * window_bias(cand, a.use_neighbors, wc.nb0, wc.nb1, wc.nb2, wc.nb3, a.neighbor_scalar);
-                best_min(b, sum, cz);
-                if (a.capture_delta && cz == cap_cz) captured = sum;
-            }
-        }
-        best_xor(b, 1); best_xor(b, 2);
-        if (a.capture_delta) { captured |= shfl_xor_u32(captured, 1); captured |= shfl_xor_u32(captured, 2); }
-    }
-
-    if (in) {
-        a.off_out[(size_t)cy * g.lw + cx] = (int16_t)(searched0 + rel_offset(b.cz, R));   // adjustOffsetArrayKernelSDR.h:13-19
-        if (a.capture_delta && cx == 0 && cy == 0) *a.total_delta = captured / a.delta_divisor;
-    }
-}
-
-// Windows > 16: every 16x16 tile lies inside one window; sums hold the raw SAD sums per candidate.
-__global__ __launch_bounds__(256) void argmin_adjust_kernel(const Geom g, const StepArgs a) {
-    __shared__ int s_rel;
-    const int tid = threadIdx.x;
-    const int wix = (blockIdx.x * 16) >> a.window_log2, wiy = (blockIdx.y * 16) >> a.window_log2;
-    const int win = wiy * a.n_win_x + wix;
-    if (tid < 64) {
-        const WindowConst wc = load_window_const(g, a, wix << a.window_log2, wiy << a.window_log2);
-        const int searched0 = a.step ? wc.oy : wc.ox;
-        Best b{0xFFFFFFFFu, 16};
-        uint32_t mine = 0;
-        if (tid < a.R) {
-            const int cand = (int)(int16_t)(searched0 + rel_offset(tid, a.R));
-            mine = (a.sums[win * 16 + tid] << a.delta_scalar) +
-                   wc.npix * window_bias(cand, a.use_neighbors, wc.nb0, wc.nb1, wc.nb2, wc.nb3, a.neighbor_scalar);
-            b.sum = mine; b.cz = tid;
-        }
-        best_xor(b, 1); best_xor(b, 2); best_xor(b, 4); best_xor(b, 8);   // determineLowestLayerKernelSDR.h:19-24
-        if (tid == 0) s_rel = rel_offset(b.cz, a.R);
-        if (a.capture_delta && blockIdx.x == 0 && blockIdx.y == 0 && tid == (a.R >> 1) - 1)
-            *a.total_delta = mine / a.delta_divisor;                        // opticalFlowCalcSDR.cpp:91-94
-    }
-    __syncthreads();
-    const int cx = blockIdx.x * 16 + (tid & 15), cy = blockIdx.y * 16 + (tid >> 4);
-    if (cx < g.lw && cy < g.lh) {
-        const size_t p = (size_t)cy * g.lw + cx;
-        const int16_t* __restrict__ src = a.step ? a.off_y : a.off_x;
-        a.off_out[p] = (int16_t)(src[p] + s_rel);  // adjustOffsetArrayKernelSDR.h:19
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // blur
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ int mirror_flow(int pos, int dim) {  // blurFlowKernelSDR.h:7-14 (+ safety clamp)
@@ -335,9 +54,8 @@ __device__ __forceinline__ int mirror_flow(int pos, int dim) {  // blurFlowKerne
 
 // Both planes per workgroup (sequentially through the same LDS tile) so that the kernel can also
 // emit the packed (x | y << 16) copy of the blurred flow that warp_fast_kernel reads with one load.
-__global__ __launch_bounds__(256) void blur_flow_kernel(const int16_t* __restrict__ off_x, const int16_t* __restrict__ off_y,
-                                                         int16_t* __restrict__ blurred, uint32_t* __restrict__ packed,
-                                                         int lw, int lh, int r) {
+__global__ __launch_bounds__(256) void blur_flow_kernel(const FlowLevel L, int16_t* __restrict__ blurred,
+                                                         uint32_t* __restrict__ packed, int lw, int lh, int r) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int T = 16 + 2 * r;                     // tile edge
     int* rows = (int*)smem;                       // [T][16] horizontal sums
@@ -348,11 +66,11 @@ __global__ __launch_bounds__(256) void blur_flow_kernel(const int16_t* __restric
     const int gx = blockIdx.x * 16 + tx, gy = blockIdx.y * 16 + ty;
     int res[2] = {0, 0};
     for (int z = 0; z < 2; z++) {
-        const int16_t* __restrict__ src = z ? off_y : off_x;
+        const int16_t* __restrict__ src = z ? L.ty : L.tx;   // offsets are stored per window of the last level
         if (z) __syncthreads();
         for (int i = tid; i < T * T; i += 256) {
             const int py = i / T, px = i - py * T;
-            tile[i] = src[(size_t)mirror_flow(y0 + py, lh) * lw + mirror_flow(x0 + px, lw)];
+            tile[i] = src ? src[(mirror_flow(y0 + py, lh) >> L.log2w) * L.nwx + (mirror_flow(x0 + px, lw) >> L.log2w)] : (int16_t)0;
         }
         __syncthreads();
         for (int i = tid; i < T * 16; i += 256) {     // taps -r .. r-1 (blurFlowKernelSDR.h:82-83)
@@ -716,29 +434,12 @@ __global__ void rcp_probe_kernel(const float* in, float* out, int n) {
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-void launch_decimate(const Geom& g, const void* frame, uint32_t* grid, hipStream_t stream) {
-    const dim3 grd((g.lw + 63) / 64, (g.lh + 3) / 4);
-    if (g.hdr) decimate_kernel<uint16_t><<<grd, 256, 0, stream>>>((const uint16_t*)frame, grid, g.H, g.W, g.in_stride, g.rs, g.lw, g.lh);
-    else decimate_kernel<uint8_t><<<grd, 256, 0, stream>>>((const uint8_t*)frame, grid, g.H, g.W, g.in_stride, g.rs, g.lw, g.lh);
-}
-
-void launch_flow_step(const Geom& g, const StepArgs& a, hipStream_t stream) {
-    const dim3 grd((g.lw + 15) / 16, (g.lh + 15) / 16);
-    if (g.hdr) flow_step_kernel<uint16_t><<<grd, 256, 0, stream>>>(g, a);
-    else flow_step_kernel<uint8_t><<<grd, 256, 0, stream>>>(g, a);
-}
-
-void launch_argmin_adjust(const Geom& g, const StepArgs& a, hipStream_t stream) {
-    const dim3 grd((g.lw + 15) / 16, (g.lh + 15) / 16);
-    argmin_adjust_kernel<<<grd, 256, 0, stream>>>(g, a);
-}
-
-void launch_blur_flow(const Geom& g, const int16_t* off_x, const int16_t* off_y, int16_t* blurred, uint32_t* packed,
+void launch_blur_flow(const Geom& g, const FlowLevel& last, int16_t* blurred, uint32_t* packed,
                       int radius, hipStream_t stream) {
     const dim3 grd((g.lw + 15) / 16, (g.lh + 15) / 16, 1);
     const int T = 16 + 2 * radius;
     const size_t smem = (size_t)T * 16 * sizeof(int) + (size_t)T * T * sizeof(int16_t);
-    blur_flow_kernel<<<grd, 256, smem, stream>>>(off_x, off_y, blurred, packed, g.lw, g.lh, radius);
+    blur_flow_kernel<<<grd, 256, smem, stream>>>(last, blurred, packed, g.lw, g.lh, radius);
 }
 
 void launch_pack_flow(const Geom& g, const int16_t* flow, uint32_t* packed, hipStream_t stream) {

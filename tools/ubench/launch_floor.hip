@@ -12,7 +12,7 @@ __global__ void k_chain(const int* __restrict__ in, int* __restrict__ out, int d
 }
 int main() {
     hipStream_t s; CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-    int *a, *b; CK(hipMalloc(&a, 1 << 20)); CK(hipMalloc(&b, 1 << 20)); CK(hipMemset(a, 0, 1 << 20));
+    int *a, *b; CK(hipMalloc(&a, 8 << 20)); CK(hipMalloc(&b, 8 << 20)); CK(hipMemset(a, 0, 8 << 20));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int N = 32;
     for (int wgs : {1, 510, 2040}) for (int depth : {-1, 1, 3}) {
