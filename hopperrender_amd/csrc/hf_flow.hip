@@ -51,39 +51,54 @@ template <> __device__ __forceinline__ unsigned top8<uint16_t>(uint16_t v) { ret
 // ------------------------------------------------------------------------------------------
 // phase planes
 // ------------------------------------------------------------------------------------------
+// One workgroup per full-resolution row (luma rows, then chroma rows): the row is read once with
+// coalesced 16-byte loads, reduced to its top 8 bits in LDS, and written back as nph (nph2) phase rows
+// including the mirrored margins.
 template <typename E>
 __global__ __launch_bounds__(256) void prep_phase_kernel(const E* __restrict__ f, uint8_t* __restrict__ py,
                                                           uint16_t* __restrict__ puv, int H, int W, int S,
                                                           PhaseLayout pl) {
-    const int row = blockIdx.y;                        // luma rows, then chroma rows
-    const int t = blockIdx.x * 256 + threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) uint8_t row8[];   // W bytes: top 8 bits of the row
+    constexpr int VEC = 16 / sizeof(E);
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const bool luma = row < H;
+    const E* __restrict__ src = luma ? f + (size_t)row * S : f + (size_t)H * S + (size_t)(row - H) * S;
+    const bool aligned = (((uintptr_t)src) & 15) == 0;
+    for (int i = tid * VEC; i < W; i += 256 * VEC) {
+        if (aligned && i + VEC <= W) {
+            __attribute__((aligned(16))) E v[VEC];
+            *(uint4*)v = *(const uint4*)(src + i);
+#pragma unroll
+            for (int k = 0; k < VEC; k++) row8[i + k] = (uint8_t)top8<E>(v[k]);
+        } else {
+            for (int k = 0; k < VEC && i + k < W; k++) row8[i + k] = (uint8_t)top8<E>(src[i + k]);
+        }
+    }
+    __syncthreads();
     const int step = 1 << pl.rs;
-    if (row < H) {
-        const int chunks = pl.lwp >> 2;                // 4 outputs (one dword) per thread
-        if (t >= pl.nph * chunks) return;
-        const int ph = t / chunks, jc = t - ph * chunks;
-        const E* __restrict__ src = f + (size_t)row * S;
-        uint32_t v = 0;
+    if (luma) {
+        const int chunks = pl.lwp >> 2;                // 4 outputs (one dword) per item
+        uint32_t* __restrict__ dst = (uint32_t*)(py + (size_t)row * pl.nph * pl.lwp);
+        for (int t = tid; t < pl.nph * chunks; t += 256) {
+            const int ph = t / chunks, jc = t - ph * chunks;
+            uint32_t v = 0;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int j = jc * 4 + i - pl.mx;
-            v |= top8<E>(src[mirror_clamp(j * step + ph, W)]) << (8 * i);
+            for (int i = 0; i < 4; i++) v |= (uint32_t)row8[mirror_clamp((jc * 4 + i - pl.mx) * step + ph, W)] << (8 * i);
+            dst[t] = v;
         }
-        *(uint32_t*)(py + ((size_t)row * pl.nph + ph) * pl.lwp + jc * 4) = v;
     } else {
-        const int yc = row - H;
-        const int chunks = pl.lwp >> 1;                // 2 outputs (one dword) per thread
-        if (t >= pl.nph2 * chunks) return;
-        const int ph2 = t / chunks, jc = t - ph2 * chunks;
-        const E* __restrict__ src = f + (size_t)H * S + (size_t)yc * S;
-        uint32_t v = 0;
+        const int chunks = pl.lwp >> 1;                // 2 outputs (one dword) per item
+        uint32_t* __restrict__ dst = (uint32_t*)(puv + (size_t)(row - H) * pl.nph2 * pl.lwp);
+        for (int t = tid; t < pl.nph2 * chunks; t += 256) {
+            const int ph2 = t / chunks, jc = t - ph2 * chunks;
+            uint32_t v = 0;
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const int j = jc * 2 + i - pl.mx;
-            const int x = mirror_clamp(j * step + 2 * ph2, W) & ~1;
-            v |= (top8<E>(src[x]) | (top8<E>(src[x + 1]) << 8)) << (16 * i);
+            for (int i = 0; i < 2; i++) {
+                const int x = mirror_clamp((jc * 2 + i - pl.mx) * step + 2 * ph2, W) & ~1;
+                v |= (uint32_t)(*(const uint16_t*)(row8 + x)) << (16 * i);
+            }
+            dst[t] = v;
         }
-        *(uint32_t*)(puv + ((size_t)yc * pl.nph2 + ph2) * pl.lwp + jc * 2) = v;
     }
 }
 
@@ -467,10 +482,10 @@ PhaseLayout make_phase_layout(const Geom& g, int max_iterations) {
 }
 
 void launch_prep_frame(const Geom& g, const PhaseLayout& pl, const void* frame, uint8_t* py, uint16_t* puv, hipStream_t stream) {
-    const int per_row = pl.nph * (pl.lwp >> 2) > pl.nph2 * (pl.lwp >> 1) ? pl.nph * (pl.lwp >> 2) : pl.nph2 * (pl.lwp >> 1);
-    const dim3 grd((per_row + 255) / 256, g.H + g.H / 2);
-    if (g.hdr) prep_phase_kernel<uint16_t><<<grd, 256, 0, stream>>>((const uint16_t*)frame, py, puv, g.H, g.W, g.in_stride, pl);
-    else prep_phase_kernel<uint8_t><<<grd, 256, 0, stream>>>((const uint8_t*)frame, py, puv, g.H, g.W, g.in_stride, pl);
+    const int rows = g.H + g.H / 2;
+    const size_t smem = (size_t)((g.W + 15) / 16) * 16 + 16;
+    if (g.hdr) prep_phase_kernel<uint16_t><<<rows, 256, smem, stream>>>((const uint16_t*)frame, py, puv, g.H, g.W, g.in_stride, pl);
+    else prep_phase_kernel<uint8_t><<<rows, 256, smem, stream>>>((const uint8_t*)frame, py, puv, g.H, g.W, g.in_stride, pl);
 }
 
 void launch_flow_level_small(const Geom& g, const FlowStep& a, hipStream_t stream) {

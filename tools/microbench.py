@@ -44,3 +44,10 @@ z[0] = 16; z[1] = -8
 c.writeBlurredFlow(0, z); t_warp("warp mode 2 const flow (16,-8) t=.5", 2, 0.5)
 c.writeBlurredFlow(0, real)
 t_flow()
+# update (device-resident): D2D copy + prep_phase
+from hopperrender_amd.calc import DeviceBuffer
+db = DeviceBuffer(fr[0].nbytes); db.upload(fr[0])
+for _ in range(3): c.updateFrameDevice(db.ptr)
+c.sync(); c.timerBegin()
+for _ in range(a.n): c.updateFrameDevice(db.ptr)
+print(f"{'updateFrameDevice (D2D + prep)':34s} {1e3*c.timerEnd()/a.n:8.2f} us")
