@@ -47,6 +47,8 @@ def parse_args():
     ap.add_argument("--blur-radius", type=int, default=4)
     ap.add_argument("--streams", type=int, default=4, help="independent frame-pair streams per GPU")
     ap.add_argument("--pool", type=int, default=6, help="distinct synthetic source frames resident in HBM")
+    ap.add_argument("--copy-in", action="store_true",
+                    help="updateFrame copies the device-resident source frame into the ring (default: zero-copy reference)")
     ap.add_argument("--no-profile", action="store_true", help="no per-kernel HIP events in the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference", action="store_true")
@@ -133,6 +135,12 @@ def main():
         b.upload(f)
         pool.append(b)
 
+    def update(c, ptr):
+        if a.copy_in:
+            c.updateFrameDevice(ptr)
+        else:
+            c.updateFrameDeviceRef(ptr)
+
     flags = capi.HF_FLAG_ASYNC | (0 if a.no_profile else capi.HF_FLAG_PROFILE)
     cls = OpticalFlowCalcHDR if hdr else OpticalFlowCalcSDR
     calcs, outbufs, plans = [], [], []
@@ -145,14 +153,14 @@ def main():
         outbufs.append([DeviceBuffer(c.output_frame_bytes, dev) for _ in range(max_out)])
         plans.append(BlendSchedule(SOURCE_24, target).plan(total_steps + 3)[3:])
         for k in range(3):  # prime the 3-frame ring and the previous-flow slot (m_frameCount >= 3)
-            c.updateFrameDevice(pool[(s + k) % a.pool].ptr)
+            update(c, pool[(s + k) % a.pool].ptr)
         c.calculateOpticalFlow()
         c.sync()
 
     def run_step(i):
         n = 0
         for s, c in enumerate(calcs):
-            c.updateFrameDevice(pool[(s + 3 + i) % a.pool].ptr)
+            update(c, pool[(s + 3 + i) % a.pool].ptr)
             c.calculateOpticalFlow()
             for j, t in enumerate(plans[s][i]):
                 c.setOutputBuffer(outbufs[s][j].ptr)
@@ -231,7 +239,7 @@ def main():
             "dtype": "u16" if hdr else "u8", "data": "synthetic",
             "config": {"workload": a.workload, "description": desc, "search_radius": a.radius,
                        "delta_scalar": 8, "neighbor_scalar": a.neighbor, "blur_radius": a.blur_radius,
-                       "pair_streams_per_gpu": a.streams, "source_periods_per_step": a.streams,
+                       "pair_streams_per_gpu": a.streams, "source_frames": "copied into the ring" if a.copy_in else "referenced in place (zero-copy)", "source_periods_per_step": a.streams,
                        "output_frames_total": int(frames_total), "parallelism": f"pair-sharded x{n_gpus}, no collective",
                        "frame_bytes": F, "flow_grid": [st["low_width"], st["low_height"]], "res_scalar": st["res_scalar"]},
             "ms_per_flow_calc": round(prof["flow_ms"] / prof["flow_chains"], 4) if prof["flow_chains"] else None,

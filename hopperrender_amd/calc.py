@@ -123,6 +123,10 @@ class OpticalFlowCalc:
     def updateFrameDevice(self, dev_ptr):
         capi.check(self._lib.hf_update_frame_device(self._ctx, C.c_void_p(dev_ptr)), self._ctx)
 
+    def updateFrameDeviceRef(self, dev_ptr):
+        """Zero-copy: the ring references the caller's device frame (valid until 3 more updates)."""
+        capi.check(self._lib.hf_update_frame_device_ref(self._ctx, C.c_void_p(dev_ptr)), self._ctx)
+
     def downloadFrameDevice(self, dev_ptr):
         capi.check(self._lib.hf_download_frame_device(self._ctx, C.c_void_p(dev_ptr)), self._ctx)
 

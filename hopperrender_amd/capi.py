@@ -59,6 +59,7 @@ SIGNATURES = {
     "hf_set_params": (_i, [_vp, C.POINTER(HfParams)]),
     "hf_get_stats": (_i, [_vp, C.POINTER(HfStats)]),
     "hf_update_frame_device": (_i, [_vp, _vp]),
+    "hf_update_frame_device_ref": (_i, [_vp, _vp]),
     "hf_download_frame_device": (_i, [_vp, _vp]),
     "hf_set_output_buffer": (_i, [_vp, _vp]),
     "hf_sync": (_i, [_vp]),

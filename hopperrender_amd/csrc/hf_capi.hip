@@ -54,7 +54,8 @@ struct hf_ctx {
 
     // device memory (reference buffers: opticalFlowCalcSDR.cpp:272-280)
     size_t in_bytes = 0, out_bytes = 0, plane_elems = 0;
-    void* ring[3] = {nullptr, nullptr, nullptr};       // m_inputFrameArray, ring[2] = newest
+    void* ring[3] = {nullptr, nullptr, nullptr};       // m_inputFrameArray, ring[2] = newest (may point at caller memory)
+    void* ring_store[3] = {nullptr, nullptr, nullptr}; // the context's own frame buffers, rotating with the ring
     uint8_t* py[3] = {nullptr, nullptr, nullptr};      // luma phase planes of each ring frame (hf_flow.hip)
     uint16_t* puv[3] = {nullptr, nullptr, nullptr};    // chroma phase planes of each ring frame
     hf::PhaseLayout pl{};
@@ -261,6 +262,8 @@ int sync_ctx(hf_ctx* c) {
 int rotate_after_upload(hf_ctx* c) {
     // opticalFlowCalcSDR.cpp:22-28 : [0] <- [1] <- [2] <- new ; frame_count++
     void* f = c->ring[0];
+    void* fs = c->ring_store[0];
+    c->ring_store[0] = c->ring_store[1]; c->ring_store[1] = c->ring_store[2]; c->ring_store[2] = fs;
     uint8_t* y = c->py[0];
     uint16_t* uv = c->puv[0];
     c->ring[0] = c->ring[1]; c->py[0] = c->py[1]; c->puv[0] = c->puv[1];
@@ -271,11 +274,17 @@ int rotate_after_upload(hf_ctx* c) {
     return HF_OK;
 }
 
-int update_common(hf_ctx* c, const void* src, hipMemcpyKind kind) {
+// by_reference: the ring slot points at the caller's device frame instead of receiving a copy
+int update_common(hf_ctx* c, const void* src, hipMemcpyKind kind, bool by_reference = false) {
     if (int rc = set_device(c)) return rc;
     HF_HIP(c, hipEventRecord(c->ev_upload, c->stream));  // m_ofcStartedEvent (:20)
     c->upload_recorded = true;
-    HF_HIP(c, hipMemcpyAsync(c->ring[0], src, c->in_bytes, kind, c->stream));
+    if (by_reference) {
+        c->ring[0] = const_cast<void*>(src);
+    } else {
+        c->ring[0] = c->ring_store[0];
+        HF_HIP(c, hipMemcpyAsync(c->ring[0], src, c->in_bytes, kind, c->stream));
+    }
     hf::launch_prep_frame(c->g, c->pl, c->ring[0], c->py[0], c->puv[0], c->stream);
     HF_HIP(c, hipGetLastError());
     rotate_after_upload(c);
@@ -372,7 +381,8 @@ int hf_create(const hf_config* cfg, hf_ctx** out_ctx) {
         return bail(_e == hipErrorOutOfMemory ? HF_ERR_OUT_OF_MEMORY : HF_ERR_HIP); } } while (0)
     HF_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (int i = 0; i < 3; i++) {
-        HF_TRY(hipMalloc(&c->ring[i], c->in_bytes));
+        HF_TRY(hipMalloc(&c->ring_store[i], c->in_bytes));
+        c->ring[i] = c->ring_store[i];
         HF_TRY(hipMalloc((void**)&c->py[i], c->pl.py_bytes));
         HF_TRY(hipMalloc((void**)&c->puv[i], c->pl.puv_bytes));
         HF_TRY(hipMemsetAsync(c->ring[i], 0, c->in_bytes, c->stream));
@@ -421,7 +431,7 @@ void hf_destroy(hf_ctx* c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);  // clFinish (opticalFlowCalcSDR.cpp:186)
     for (auto& kv : c->graphs) hipGraphExecDestroy(kv.second);
-    for (int i = 0; i < 3; i++) { if (c->ring[i]) hipFree(c->ring[i]); if (c->py[i]) hipFree(c->py[i]); if (c->puv[i]) hipFree(c->puv[i]); }
+    for (int i = 0; i < 3; i++) { if (c->ring_store[i]) hipFree(c->ring_store[i]); if (c->py[i]) hipFree(c->py[i]); if (c->puv[i]) hipFree(c->puv[i]); }
     if (c->tables) hipFree(c->tables);
     if (c->off_view) hipFree(c->off_view);
     if (c->out_frame) hipFree(c->out_frame);
@@ -448,6 +458,12 @@ int hf_update_frame_device(hf_ctx* c, const void* device_frame) {
     HF_CHECK_CTX(c);
     if (!device_frame) return fail(c, HF_ERR_INVALID_ARGUMENT, "hf_update_frame_device: null frame");
     return update_common(c, device_frame, hipMemcpyDeviceToDevice);
+}
+
+int hf_update_frame_device_ref(hf_ctx* c, const void* device_frame) {
+    HF_CHECK_CTX(c);
+    if (!device_frame) return fail(c, HF_ERR_INVALID_ARGUMENT, "hf_update_frame_device_ref: null frame");
+    return update_common(c, device_frame, hipMemcpyDeviceToDevice, true);
 }
 
 int hf_calculate_optical_flow(hf_ctx* c) {

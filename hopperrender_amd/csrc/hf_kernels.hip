@@ -275,13 +275,14 @@ __device__ __forceinline__ Run<E, GROUP> load_run(const E* __restrict__ p) {
     return r;
 }
 
-// chroma run: out[2k] = src[base + 2k] (U), out[2k+1] = src[base + 2k + 1 + vshift] (V)
+// chroma run starting at x_first = cx + d: element i reads (x & ~1) + (i & 1) with x = x_first + i
+// (warpFrameKernelSDR.h:173).  With e = x_first & ~1 and o = x_first & 1 the even slots are
+// src[e + 2k] and the odd slots src[e + 2o + 2k + 1]: two runs, no lane divergence.
 template <typename E, int GROUP>
 __device__ __forceinline__ Run<E, GROUP> load_run_uv(const E* __restrict__ row, int x_first) {
-    // x_first = cx_g + d ; (x & ~1) + parity per element, warpFrameKernelSDR.h:173
-    if ((x_first & 1) == 0) return load_run<E, GROUP>(row + x_first);
-    const Run<E, GROUP> lo = load_run<E, GROUP>(row + x_first - 1);   // even slots (U)
-    const Run<E, GROUP> hi = load_run<E, GROUP>(row + x_first + 1);   // odd slots (V)
+    const int e = x_first & ~1, o = x_first & 1;
+    const Run<E, GROUP> lo = load_run<E, GROUP>(row + e);           // even slots (U)
+    const Run<E, GROUP> hi = load_run<E, GROUP>(row + e + 2 * o);   // odd slots (V)
     Run<E, GROUP> r;
 #pragma unroll
     for (int i = 0; i < GROUP; i++) r.v[i] = (i & 1) ? hi.v[i] : lo.v[i];
@@ -333,33 +334,59 @@ __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a,
     }
 
     Run<E, GROUP> ra[ROWS][NG], rb[ROWS][NG];
+    // mirrorCoordinate is the identity on [1, W-2]: a run that stays inside is contiguous.  The test is
+    // made wave-uniform so that interior waves (all but the first/last of a row) carry no edge code.
+    bool interior = true;
 #pragma unroll
-    for (int r = 0; r < ROWS; r++) {
-        const int cy = min(cy0 + r, dim_y - 1);               // rows past the plane end re-read the last row (not stored)
+    for (int k = 0; k < NG; k++) {
+        if (need_a) interior = interior && xa[k] >= 1 && xa[k] + GROUP - 1 <= W - 2;
+        if (need_b) interior = interior && xb[k] >= 1 && xb[k] + GROUP - 1 <= W - 2;
+    }
+    if (__builtin_amdgcn_ballot_w64(!interior) == 0) {
 #pragma unroll
-        for (int k = 0; k < NG; k++) {
-            // mirrorCoordinate is the identity on [1, W-2]: contiguous run; else per-element gathers
-            if (need_a) {
-                const E* rowp = A + (size_t)mirror_warp(cy + dya[k], dim_y) * Si;
-                if (xa[k] >= 1 && xa[k] + GROUP - 1 <= W - 2) {
+        for (int r = 0; r < ROWS; r++) {
+            const int cy = min(cy0 + r, dim_y - 1);           // rows past the plane end re-read the last row (not stored)
+#pragma unroll
+            for (int k = 0; k < NG; k++) {
+                if (need_a) {
+                    const E* rowp = A + (size_t)mirror_warp(cy + dya[k], dim_y) * Si;
                     ra[r][k] = CZ ? load_run_uv<E, GROUP>(rowp, xa[k]) : load_run<E, GROUP>(rowp + xa[k]);
-                } else {
-#pragma unroll
-                    for (int i = 0; i < GROUP; i++) {
-                        const int x = mirror_warp(xa[k] + i, W);
-                        ra[r][k].v[i] = rowp[CZ ? (x & ~1) + (i & 1) : x];
-                    }
+                }
+                if (need_b) {
+                    const E* rowp = B + (size_t)mirror_warp(cy + dyb[k], dim_y) * Si;
+                    rb[r][k] = CZ ? load_run_uv<E, GROUP>(rowp, xb[k]) : load_run<E, GROUP>(rowp + xb[k]);
                 }
             }
-            if (need_b) {
-                const E* rowp = B + (size_t)mirror_warp(cy + dyb[k], dim_y) * Si;
-                if (xb[k] >= 1 && xb[k] + GROUP - 1 <= W - 2) {
-                    rb[r][k] = CZ ? load_run_uv<E, GROUP>(rowp, xb[k]) : load_run<E, GROUP>(rowp + xb[k]);
-                } else {
+        }
+    } else {   // some lane of this wave touches the mirror zone at the left/right frame edge:
+               // those lanes gather per element, the others keep their contiguous runs
 #pragma unroll
-                    for (int i = 0; i < GROUP; i++) {
-                        const int x = mirror_warp(xb[k] + i, W);
-                        rb[r][k].v[i] = rowp[CZ ? (x & ~1) + (i & 1) : x];
+        for (int r = 0; r < ROWS; r++) {
+            const int cy = min(cy0 + r, dim_y - 1);
+#pragma unroll
+            for (int k = 0; k < NG; k++) {
+                if (need_a) {
+                    const E* rowp = A + (size_t)mirror_warp(cy + dya[k], dim_y) * Si;
+                    if (xa[k] >= 1 && xa[k] + GROUP - 1 <= W - 2) {
+                        ra[r][k] = CZ ? load_run_uv<E, GROUP>(rowp, xa[k]) : load_run<E, GROUP>(rowp + xa[k]);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < GROUP; i++) {
+                            const int x = mirror_warp(xa[k] + i, W);
+                            ra[r][k].v[i] = rowp[CZ ? (x & ~1) + (i & 1) : x];
+                        }
+                    }
+                }
+                if (need_b) {
+                    const E* rowp = B + (size_t)mirror_warp(cy + dyb[k], dim_y) * Si;
+                    if (xb[k] >= 1 && xb[k] + GROUP - 1 <= W - 2) {
+                        rb[r][k] = CZ ? load_run_uv<E, GROUP>(rowp, xb[k]) : load_run<E, GROUP>(rowp + xb[k]);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < GROUP; i++) {
+                            const int x = mirror_warp(xb[k] + i, W);
+                            rb[r][k].v[i] = rowp[CZ ? (x & ~1) + (i & 1) : x];
+                        }
                     }
                 }
             }

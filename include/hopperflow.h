@@ -131,6 +131,10 @@ int hf_get_stats(hf_ctx* ctx, hf_stats* out);
 /* ---- device-resident variants (batch driver / benchmarks: inputs and outputs stay in HBM) ---- */
 /* Same as hf_update_frame but the source is a device pointer on ctx's device (device-to-device). */
 int hf_update_frame_device(hf_ctx* ctx, const void* device_frame);
+/* Zero-copy variant: the ring keeps a REFERENCE to device_frame (e.g. a decoder surface).  The caller must
+ * leave the frame untouched until three further frames have been submitted (it stays in the 3-frame ring
+ * as frame N, N-1 and N-2, opticalFlowCalcSDR.cpp:22-28). */
+int hf_update_frame_device_ref(hf_ctx* ctx, const void* device_frame);
 /* Device-to-device copy of the output frame into caller-owned device memory. */
 int hf_download_frame_device(hf_ctx* ctx, void* device_out);
 /* Redirect warp/copy output into caller-owned device memory (NULL restores the internal buffer). */
