@@ -42,13 +42,15 @@ def _run(cmd):
 
 def build_flow(force=False):
     os.makedirs(LIBDIR, exist_ok=True)
+    extra = os.environ.get("HF_CXXFLAGS", "").split()   # experiments only (e.g. -DHF_EXP=1)
+    force = force or bool(extra)
     srcs = [os.path.join(CSRC, f) for f in ("hf_kernels.hip", "hf_flow.hip", "hf_capi.hip")]
     deps = srcs + [os.path.join(CSRC, "hf_kernels.h"), os.path.join(INCLUDE, "hopperflow.h")]
     if force or _stale(LIB_FLOW, deps):
         objs = []
         for s in srcs:
             o = os.path.join(LIBDIR, os.path.basename(s) + ".o")
-            _run([HIPCC] + HIP_FLAGS + ["-I", INCLUDE, "-c", s, "-o", o])
+            _run([HIPCC] + HIP_FLAGS + extra + ["-I", INCLUDE, "-c", s, "-o", o])
             objs.append(o)
         _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_FLOW] + objs +
              ["-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined"])

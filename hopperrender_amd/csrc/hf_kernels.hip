@@ -277,15 +277,22 @@ __device__ __forceinline__ Run<E, GROUP> load_run(const E* __restrict__ p) {
 
 // chroma run starting at x_first = cx + d: element i reads (x & ~1) + (i & 1) with x = x_first + i
 // (warpFrameKernelSDR.h:173).  With e = x_first & ~1 and o = x_first & 1 the even slots are
-// src[e + 2k] and the odd slots src[e + 2o + 2k + 1]: two runs, no lane divergence.
+// src[e + i] and the odd slots src[e + 2o + i]: one GROUP-wide run at e plus ONE extra pair (the two
+// elements that follow the run when o = 1), no lane divergence.
 template <typename E, int GROUP>
 __device__ __forceinline__ Run<E, GROUP> load_run_uv(const E* __restrict__ row, int x_first) {
+#if defined(HF_EXP) && HF_EXP == 2
+    return load_run<E, GROUP>(row + x_first);                       // timing experiment: single chroma load
+#endif
     const int e = x_first & ~1, o = x_first & 1;
-    const Run<E, GROUP> lo = load_run<E, GROUP>(row + e);           // even slots (U)
-    const Run<E, GROUP> hi = load_run<E, GROUP>(row + e + 2 * o);   // odd slots (V)
+    const Run<E, GROUP> lo = load_run<E, GROUP>(row + e);
+    const Run<E, 2> ext = load_run<E, 2>(row + e + GROUP - 2 + 2 * o);   // o = 0: re-reads the run's tail (unused)
     Run<E, GROUP> r;
 #pragma unroll
-    for (int i = 0; i < GROUP; i++) r.v[i] = (i & 1) ? hi.v[i] : lo.v[i];
+    for (int i = 0; i < GROUP; i++) {
+        if ((i & 1) == 0) r.v[i] = lo.v[i];
+        else r.v[i] = o ? (i + 2 < GROUP ? lo.v[(i + 2) % GROUP] : ext.v[(i + 2) % GROUP % 2]) : lo.v[i];
+    }
     return r;
 }
 
@@ -316,11 +323,19 @@ __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a,
     for (int k = 0; k < NG; k++) {
         const int cx = cx0 + k * GROUP;
         const int lx = CZ ? ((cx >> rs) & ~1) : (cx >> rs);
+#if defined(HF_EXP) && HF_EXP == 3
+        const uint32_t f12 = (uint32_t)(ly + lx) * 0u + 0x00030005u;   // timing experiment: no flow loads at all
+#else
         const uint32_t f12 = a.flow_xy[(size_t)ly * lw + lx];
+#endif
         const int ox12 = (int)(int16_t)(f12 & 0xFFFFu), oy12 = (int)(int16_t)(f12 >> 16);
         const int py = clampi(ly - (oy12 >> rs), 0, lh - 1);
         const int px = clampi(lx - (ox12 >> rs), 0, lw - 1);
+#if defined(HF_EXP) && (HF_EXP == 1 || HF_EXP == 3)
+        const uint32_t f21 = f12 + (uint32_t)(px + py) * 0u;   // timing experiment: no dependent second lookup
+#else
         const uint32_t f21 = a.flow_xy[(size_t)py * lw + px];
+#endif
         const int ox21 = (int)(int16_t)(f21 & 0xFFFFu), oy21 = (int)(int16_t)(f21 >> 16);
         xa[k] = cx + (int)roundf((float)ox12 * a.s12);
         xb[k] = cx - (int)roundf((float)ox21 * a.s21);
