@@ -127,6 +127,13 @@ class OpticalFlowCalc:
         """Zero-copy: the ring references the caller's device frame (valid until 3 more updates)."""
         capi.check(self._lib.hf_update_frame_device_ref(self._ctx, C.c_void_p(dev_ptr)), self._ctx)
 
+    def interpolatePeriod(self, dev_frame_ptr, scalars, out_ptrs, mode=BlendedFrame):
+        """updateFrame(ref) + calculateOpticalFlow + one warpFrames per scalar, in ONE native call."""
+        n = len(scalars)
+        ts = (C.c_float * n)(*[float(x) for x in scalars])
+        outs = (C.c_void_p * n)(*[int(p) for p in out_ptrs[:n]])
+        capi.check(self._lib.hf_interpolate_period(self._ctx, C.c_void_p(dev_frame_ptr or 0), n, ts, outs, int(mode)), self._ctx)
+
     def downloadFrameDevice(self, dev_ptr):
         capi.check(self._lib.hf_download_frame_device(self._ctx, C.c_void_p(dev_ptr)), self._ctx)
 
@@ -149,6 +156,9 @@ class OpticalFlowCalc:
         pr = capi.HfProfile()
         capi.check(self._lib.hf_get_profile(self._ctx, C.byref(pr)), self._ctx)
         return {k: getattr(pr, k) for k, _ in pr._fields_}
+
+    def setProfileInterval(self, warp_every, flow_every):
+        capi.check(self._lib.hf_set_profile_interval(self._ctx, int(warp_every), int(flow_every)), self._ctx)
 
     def resetProfile(self):
         capi.check(self._lib.hf_reset_profile(self._ctx), self._ctx)

@@ -60,6 +60,7 @@ SIGNATURES = {
     "hf_get_stats": (_i, [_vp, C.POINTER(HfStats)]),
     "hf_update_frame_device": (_i, [_vp, _vp]),
     "hf_update_frame_device_ref": (_i, [_vp, _vp]),
+    "hf_interpolate_period": (_i, [_vp, _vp, _i, C.POINTER(C.c_float), C.POINTER(_vp), _i]),
     "hf_download_frame_device": (_i, [_vp, _vp]),
     "hf_set_output_buffer": (_i, [_vp, _vp]),
     "hf_sync": (_i, [_vp]),
@@ -69,6 +70,7 @@ SIGNATURES = {
     "hf_device_rcp": (_i, [_vp, _vp, _vp, _i]),
     "hf_get_profile": (_i, [_vp, C.POINTER(HfProfile)]),
     "hf_reset_profile": (_i, [_vp]),
+    "hf_set_profile_interval": (_i, [_vp, _i, _i]),
     "hf_timer_begin": (_i, [_vp]),
     "hf_timer_end": (_i, [_vp, C.POINTER(C.c_float)]),
     "hf_device_count": (_i, []),

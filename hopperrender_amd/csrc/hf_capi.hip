@@ -93,6 +93,8 @@ struct hf_ctx {
     std::vector<hipEvent_t> ev_pool;
     std::vector<Span> spans;
     hf_profile prof{};
+    int prof_every[3] = {1, 1, 1};   // sampling interval per span kind (warp, copy, flow chain)
+    unsigned prof_seen[3] = {0, 0, 0};
     bool profiling() const { return (cfg.flags & HF_FLAG_PROFILE) != 0; }
 
     bool async() const { return (cfg.flags & HF_FLAG_ASYNC) != 0; }
@@ -228,6 +230,7 @@ hipEvent_t pool_event(hf_ctx* c) {
 // Opens a profiled span on the stream; returns the index of the span or -1.
 int span_begin(hf_ctx* c, int kind) {
     if (!c->profiling()) return -1;
+    if ((c->prof_seen[kind]++ % (unsigned)c->prof_every[kind]) != 0) return -1;
     hf_ctx::Span s{pool_event(c), pool_event(c), kind};
     if (!s.b || !s.e) return -1;
     hipEventRecord(s.b, c->stream);
@@ -552,6 +555,20 @@ int hf_copy_frame(hf_ctx* c) {
     return HF_OK;
 }
 
+int hf_interpolate_period(hf_ctx* c, const void* device_frame, int n_out, const float* t, void* const* device_out, int mode) {
+    HF_CHECK_CTX(c);
+    if (n_out < 0 || (n_out > 0 && (!t || !device_out))) return fail(c, HF_ERR_INVALID_ARGUMENT, "hf_interpolate_period: bad argument");
+    if (device_frame) if (int rc = hf_update_frame_device_ref(c, device_frame)) return rc;
+    if (int rc = hf_calculate_optical_flow(c)) return rc;
+    void* const saved = c->out_target;
+    for (int i = 0; i < n_out; i++) {
+        c->out_target = device_out[i] ? device_out[i] : c->out_frame;
+        if (int rc = hf_warp_frames(c, t[i], mode)) { c->out_target = saved; return rc; }
+    }
+    c->out_target = saved;
+    return HF_OK;
+}
+
 static int download_common(hf_ctx* c, void* dst, hipMemcpyKind kind) {
     if (int rc = set_device(c)) return rc;
     if (c->out_target != dst) HF_HIP(c, hipMemcpyAsync(dst, c->out_target, c->out_bytes, kind, c->stream));
@@ -633,6 +650,14 @@ int hf_get_profile(hf_ctx* c, hf_profile* out) {
     if (int rc = set_device(c)) return rc;
     if (int rc = sync_ctx(c)) return rc;
     *out = c->prof;
+    return HF_OK;
+}
+
+int hf_set_profile_interval(hf_ctx* c, int warp_every, int flow_every) {
+    HF_CHECK_CTX(c);
+    if (warp_every < 1 || flow_every < 1) return fail(c, HF_ERR_INVALID_ARGUMENT, "hf_set_profile_interval: intervals must be >= 1");
+    c->prof_every[0] = c->prof_every[1] = warp_every;
+    c->prof_every[2] = flow_every;
     return HF_OK;
 }
 

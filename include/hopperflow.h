@@ -135,6 +135,10 @@ int hf_update_frame_device(hf_ctx* ctx, const void* device_frame);
  * leave the frame untouched until three further frames have been submitted (it stays in the 3-frame ring
  * as frame N, N-1 and N-2, opticalFlowCalcSDR.cpp:22-28). */
 int hf_update_frame_device_ref(hf_ctx* ctx, const void* device_frame);
+/* One source-frame period in a single call (batch driver): hf_update_frame_device_ref(device_frame) if it is
+ * non-NULL, hf_calculate_optical_flow(), then for i < n_out: hf_warp_frames(t[i], mode) written to
+ * device_out[i].  Same results as the individual calls; only the host overhead differs. */
+int hf_interpolate_period(hf_ctx* ctx, const void* device_frame, int n_out, const float* t, void* const* device_out, int mode);
 /* Device-to-device copy of the output frame into caller-owned device memory. */
 int hf_download_frame_device(hf_ctx* ctx, void* device_out);
 /* Redirect warp/copy output into caller-owned device memory (NULL restores the internal buffer). */
@@ -167,6 +171,9 @@ typedef struct hf_profile {
     double flow_ms;           /* summed device time first kernel start -> blur end */
 } hf_profile;
 int hf_get_profile(hf_ctx* ctx, hf_profile* out); /* synchronises ctx */
+/* Bracket only every n-th warp/copy launch and every m-th flow chain (default 1/1): event records perturb
+ * back-to-back launches, so throughput runs sample instead of bracketing everything. */
+int hf_set_profile_interval(hf_ctx* ctx, int warp_every, int flow_every);
 int hf_reset_profile(hf_ctx* ctx);
 
 /* ---- plain device-memory helpers so non-HIP hosts (ctypes, cgo, JNI) can stage frames ---- */
