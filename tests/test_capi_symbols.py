@@ -1,0 +1,70 @@
+"""CPU: the C-ABI library builds, loads, and exports every symbol include/hopperflow.h declares; the ctypes
+table covers them all; no compute call is made (no GPU here)."""
+import ctypes
+import os
+import re
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "hopperflow.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(hf_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(native_lib):
+    from hopperrender_amd import build, capi
+    syms = declared_symbols()
+    assert len(syms) >= 30
+    nm = subprocess.run(["nm", "-D", "--defined-only", build.LIB_FLOW], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (hf_[a-z0-9_]+)", nm))
+    assert not (set(syms) - exported), f"declared but not exported: {sorted(set(syms) - exported)}"
+    assert not (set(syms) - set(capi.SIGNATURES)), f"not bound in capi.py: {sorted(set(syms) - set(capi.SIGNATURES))}"
+    for s in syms:
+        assert getattr(native_lib, s) is not None
+    assert native_lib.hf_abi_version() == 1
+
+
+def test_struct_layouts_match_the_header(native_lib, tmp_path):
+    """sizeof of the C structs as compiled by gcc == the ctypes mirrors."""
+    from hopperrender_amd import capi
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "hopperflow.h"\nint main(){printf("%zu %zu %zu %zu\\n", sizeof(hf_config), sizeof(hf_params), sizeof(hf_stats), sizeof(hf_profile));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert sizes == [ctypes.sizeof(capi.HfConfig), ctypes.sizeof(capi.HfParams), ctypes.sizeof(capi.HfStats), ctypes.sizeof(capi.HfProfile)]
+
+
+def test_no_device_fails_loudly_not_silently(native_lib):
+    """Without a GPU the product must raise (there is no CPU fallback); with one it must construct."""
+    import pytest
+    from hopperrender_amd.calc import OpticalFlowCalcSDR
+    from hopperrender_amd.capi import HopperFlowError
+    if native_lib.hf_device_count() == 0:
+        with pytest.raises(HopperFlowError, match="detectDevices"):
+            OpticalFlowCalcSDR(180, 320)
+    else:
+        OpticalFlowCalcSDR(180, 320).close()
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under hopperrender_amd/ or include/ may reference it."""
+    bad = []
+    for d in ("hopperrender_amd", "include"):
+        for root, _, files in os.walk(os.path.join(ROOT, d)):
+            for f in files:
+                if f.endswith((".py", ".h", ".hip", ".cpp")):
+                    txt = open(os.path.join(root, f), errors="replace").read()
+                    if re.search(r"(from|import)\s+oracle|hf_oracle|libhf_oracle|oracle/", txt):
+                        bad.append(os.path.join(root, f))
+    assert not bad, bad
+
+
+def test_cpp_adapter_header_is_self_contained(tmp_path):
+    """include/opticalFlowCalc.h compiles with plain g++ (no HIP, no OpenCL, no Windows headers)."""
+    src = tmp_path / "t.cpp"
+    src.write_text('#include "opticalFlowCalc.h"\nint main(){ OpticalFlowCalc* p = nullptr; (void)p; return sizeof(OpticalFlowCalcSDR) > 0 ? 0 : 1; }\n')
+    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"), str(src)])
