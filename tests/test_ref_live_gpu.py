@@ -1,0 +1,54 @@
+"""GPU: the HIP path against THE REFERENCE ITSELF run live on the same MI355X (oracle/_ref: unmodified
+reference host code + OpenCL kernels, driven by ref_runner), on seeds that are not in the golden set.
+Skipped when oracle/_ref or an OpenCL GPU is not available."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("hdr,H,W,si,so,R,delta,nb,seed", [
+    (0, 270, 480, 0, 0, 16, 8, 6, 501),
+    (1, 270, 480, 512, 496, 12, 8, 6, 502),
+    (0, 1080, 1920, 0, 0, 16, 8, 6, 503),
+    (1, 1080, 1920, 0, 0, 5, 6, 10, 504),
+    (1, 2160, 3840, 0, 0, 16, 8, 6, 505),
+])
+def test_hip_matches_live_reference(native_lib, hdr, H, W, si, so, R, delta, nb, seed):
+    from hopperrender_amd import synth
+    from hopperrender_amd.calc import OpticalFlowCalcHDR, OpticalFlowCalcSDR
+    from oracle import oracle
+    if not oracle.ref_available():
+        pytest.skip("oracle/_ref (the compiled reference) or an OpenCL GPU is not available")
+    sc = synth.Scene(H, W, bool(hdr), seed, in_stride=si)
+    f = [sc.frame(k) for k in range(4)]
+    tvals = [0.0, 0.1998, 0.5994, 0.999]
+    s = oracle.RefSession(hdr, H, W, si, so, delta, nb, 0.0, 255.0, 270)
+    s.radius(R)
+    for x in f[:3]:
+        s.update(x)
+    s.calc(); s.stats(); s.dump_offsets("off"); s.dump_blurred(1, "blur")
+    s.update(f[3]); s.calc(); s.stats()
+    for m in (0, 1, 2):
+        for t in tvals:
+            s.warp(t, m); s.download(f"w{m}_{t}")
+    s.copy(); s.download("copy")
+    js, ref = s.run()
+
+    c = (OpticalFlowCalcHDR if hdr else OpticalFlowCalcSDR)(H, W, si, so, delta, nb, 0.0, 255.0, 270)
+    c.m_opticalFlowSearchRadius = R
+    for x in f[:3]:
+        c.updateFrame(x)
+    c.calculateOpticalFlow()
+    assert c.m_totalFrameDelta == js[0]["total_frame_delta"]
+    assert (c.readOffsets() == ref["off"]).all()
+    assert (c.readBlurredFlow(1) == ref["blur"]).all()
+    c.updateFrame(f[3]); c.calculateOpticalFlow()
+    assert c.m_totalFrameDelta == js[1]["total_frame_delta"]
+    for m in (0, 1, 2):
+        for t in tvals:
+            c.warpFrames(t, m)
+            assert (c.downloadFrame() == ref[f"w{m}_{t}"]).all(), f"mode {m} t {t}"
+    c.copyFrame()
+    assert (c.downloadFrame() == ref["copy"]).all()
+    c.close()
