@@ -298,8 +298,11 @@ __device__ __forceinline__ Run<E, GROUP> load_run_uv(const E* __restrict__ row, 
 
 // Body of the fast path for one plane (CZ = 0 luma, 1 chroma), everything plane-dependent is
 // compile-time so the per-element code is straight-line.
+typedef float float2v __attribute__((ext_vector_type(2)));
+
 template <typename E, int GROUP, int ROWS, int MODE, int CZ>
 __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a, int cy0, int cx0) {
+    using T = ElemTraits<E>;
     constexpr int VEC = 16 / sizeof(E);
     constexpr int NG = VEC / GROUP;
     static_assert(VEC % GROUP == 0, "group must divide the per-thread vector");
@@ -339,6 +342,9 @@ __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a,
         const int ox21 = (int)(int16_t)(f21 & 0xFFFFu), oy21 = (int)(int16_t)(f21 >> 16);
         xa[k] = cx + (int)roundf((float)ox12 * a.s12);
         xb[k] = cx - (int)roundf((float)ox21 * a.s21);
+#if defined(HF_EXP) && HF_EXP == 4
+        xa[k] = (xa[k] & ~7) | 8 * 0; xb[k] &= ~7;   // timing experiment: 16-byte aligned runs
+#endif
         if (CZ) {
             dya[k] = (int)roundf((float)oy12 * a.s12 * 0.5f);
             dyb[k] = -(int)roundf((float)oy21 * a.s21 * 0.5f);
@@ -413,16 +419,42 @@ __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a,
         __attribute__((aligned(16))) E v[VEC];
 #pragma unroll
         for (int k = 0; k < NG; k++) {
+            if (MODE == 0) {
 #pragma unroll
-            for (int i = 0; i < GROUP; i++) {
-                if (MODE == 0) v[k * GROUP + i] = ra[r][k].v[i];
-                else if (MODE == 1) v[k * GROUP + i] = rb[r][k].v[i];
-                else {
-                    const unsigned blended = (unsigned)__builtin_fmaf((float)ra[r][k].v[i], a.s21, (float)rb[r][k].v[i] * a.s12) & 0xFFFFu;
-                    v[k * GROUP + i] = (E)(CZ ? levels_uv<E>((float)blended, lv) : levels_y<E>((float)blended, lv));
+                for (int i = 0; i < GROUP; i++) v[k * GROUP + i] = ra[r][k].v[i];
+            } else if (MODE == 1) {
+#pragma unroll
+                for (int i = 0; i < GROUP; i++) v[k * GROUP + i] = rb[r][k].v[i];
+            } else {
+                // Blend + levels two elements at a time on the packed fp32 pipe (v_pk_mul/fma/add_f32: the
+                // same IEEE operations per element as the scalar form).  The launcher only selects this
+                // kernel for 0 <= t <= 1 and non-degenerate levels, where
+                //   (float)(unsigned short)x == trunc(x)   (0 <= x < 65536)   and
+                //   fmax(fmin(f, max), 0)    == med3(f, 0, max)               (f is never NaN).
+#pragma unroll
+                for (int i = 0; i < GROUP; i += 2) {
+                    const float2v fa = {(float)ra[r][k].v[i], (float)ra[r][k].v[i + 1]};
+                    const float2v fb = {(float)rb[r][k].v[i], (float)rb[r][k].v[i + 1]};
+                    const float2v s12 = {a.s12, a.s12}, s21 = {a.s21, a.s21};
+                    float2v bl = __builtin_elementwise_fma(fa, s21, fb * s12);          // :176-177 as compiled on gfx950
+                    bl.x = __builtin_truncf(bl.x);
+                    bl.y = __builtin_truncf(bl.y);
+                    float2v f;
+                    if (CZ) {
+                        const float2v mid = {T::mid, T::mid}, rcp = {lv.rcp_uv, lv.rcp_uv}, mx = {T::maxv, T::maxv};
+                        f = __builtin_elementwise_fma((bl - mid) * rcp, mx, mid);       // warpFrameKernelSDR.h:7-9
+                    } else {
+                        const float2v bk = {lv.black, lv.black}, rcp = {lv.rcp_y, lv.rcp_y}, mx = {T::maxv, T::maxv};
+                        f = ((bl - bk) * rcp) * mx;                                       // warpFrameKernelSDR.h:3-5
+                    }
+                    v[k * GROUP + i] = (E)(unsigned)__builtin_amdgcn_fmed3f(f.x, 0.0f, T::maxv);
+                    v[k * GROUP + i + 1] = (E)(unsigned)__builtin_amdgcn_fmed3f(f.y, 0.0f, T::maxv);
                 }
             }
         }
+#if defined(HF_EXP) && HF_EXP == 6
+        if (a.s12 == 12345.0f)   // timing experiment: no stores
+#endif
         *(uint4*)(out + (size_t)r * So) = *(const uint4*)v;
     }
 }
@@ -434,10 +466,29 @@ template <typename E, int GROUP, int ROWS, int MODE>
 __global__ __launch_bounds__(256) void warp_fast_kernel(const Geom g, const WarpArgs a, int y_groups) {
     constexpr int VEC = 16 / sizeof(E);
     // row group: luma groups first, then chroma; one row group per wave => the plane test is a scalar branch
-    const int rg = blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int cx0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * VEC;
+    // Work decomposition: a wave tile = 64 lanes x VEC elements of one row group; tiles are numbered
+    // row-major (consecutive tiles = consecutive memory), a workgroup takes 4 consecutive tiles, and
+    // workgroups are dealt to the XCDs in contiguous bands: linear block id b runs on XCD b % 8
+    // (MI355X_MICROARCH.md "Workgroup dispatch"), so block b works on band (b % 8).  Measured on the
+    // 2160p HDR blend: 20.7 us with the naive 2-D grid (every XCD walks a 1 KB wide column stripe)
+    // -> 19.0 us banded.  Placement only affects speed.
+    const int wpr = (g.W + 64 * VEC - 1) / (64 * VEC);            // wave tiles per row group
+    const int n_tiles = wpr * (y_groups + ((g.H >> 1) + ROWS - 1) / ROWS);
+    const int n_blocks = (n_tiles + 3) >> 2;
+    const int per_band = (n_blocks + 7) >> 3;
+    const int blk = (blockIdx.x & 7) * per_band + (blockIdx.x >> 3);
+    const int tile = blk * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (blk >= n_blocks || tile >= n_tiles) return;
+    const int rg = tile / wpr;
+    const int cx0 = ((tile - rg * wpr) * 64 + (threadIdx.x & 63)) * VEC;
     const int uv_groups = ((g.H >> 1) + ROWS - 1) / ROWS;
     if (rg >= y_groups + uv_groups || cx0 >= g.W) return;
+#if defined(HF_EXP) && HF_EXP == 8
+    if (rg >= y_groups) return;   // timing experiment: luma only
+#endif
+#if defined(HF_EXP) && HF_EXP == 9
+    if (rg < y_groups) return;    // timing experiment: chroma only
+#endif
     if (rg >= y_groups) warp_fast_body<E, GROUP, ROWS, MODE, 1>(g, a, (rg - y_groups) * ROWS, cx0);
     else warp_fast_body<E, GROUP, ROWS, MODE, 0>(g, a, rg * ROWS, cx0);
 }
@@ -497,15 +548,20 @@ static void launch_warp_t(const Geom& g, const WarpArgs& a, hipStream_t stream) 
     const int cell = 1 << g.rs;
     const int group = cell < VEC ? cell : VEC;
     // chroma runs are read with element-pair granularity: needs an even input stride
-    const bool fast = aligned && a.mode >= 0 && a.mode <= 2 && a.flow_xy && (g.in_stride % 2) == 0 && g.W >= 2 * VEC &&
-                      group * (int)sizeof(E) >= 4;
+    // blend shortcuts of the fast kernel need 0 <= t <= 1 and levels that cannot produce NaN
+    const bool sane = a.s12 >= 0.0f && a.s12 <= 1.0f && a.white != a.black && a.white != 0.0f &&
+                      a.white == a.white && a.black == a.black;
+    const bool fast = aligned && a.mode >= 0 && a.mode <= 2 && (a.mode != 2 || sane) && a.flow_xy && (g.in_stride % 2) == 0 &&
+                      g.W >= 2 * VEC && group * (int)sizeof(E) >= 4;
     if (fast) {
         // rows per thread (must divide the 2^rs rows of a flow cell)
         static const int rows_env = getenv("HF_WARP_ROWS") ? atoi(getenv("HF_WARP_ROWS")) : 0;
         int rows = 2;  // measured on MI355X, 2160p HDR blend: 1 row 25.9 us, 2 rows 24.3 us, 4 rows 30.2 us
         if (rows_env == 1 || rows_env == 2 || (rows_env == 4 && g.rs >= 2)) rows = rows_env;
         const int y_groups = (g.H + rows - 1) / rows, uv_groups = ((g.H >> 1) + rows - 1) / rows;
-        const dim3 fg((g.W + 64 * VEC - 1) / (64 * VEC), (y_groups + uv_groups + 3) / 4);
+        const int wpr = (g.W + 64 * VEC - 1) / (64 * VEC);
+        const int n_blocks = (wpr * (y_groups + uv_groups) + 3) / 4;
+        const dim3 fg(((n_blocks + 7) / 8) * 8);
 #define HF_WARP_FAST(G, R)                                                                   \
     do {                                                                                     \
         if (a.mode == 0) warp_fast_kernel<E, G, R, 0><<<fg, 256, 0, stream>>>(g, a, y_groups);      \
