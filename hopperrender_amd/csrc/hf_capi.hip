@@ -71,8 +71,8 @@ struct hf_ctx {
     uint32_t* sums = nullptr;                          // [kMaxSteps][n_windows_max][16]
     size_t sums_bytes = 0;
     size_t sums_stride = 0;                            // elements per step
-    uint32_t* d_total_delta = nullptr;
-    uint32_t* h_total_delta = nullptr;                 // pinned
+    uint32_t* d_total_delta = nullptr;                 // device view of h_total_delta (mapped pinned memory)
+    uint32_t* h_total_delta = nullptr;                 // pinned host slot the chain writes m_totalFrameDelta into
     float* d_probe = nullptr;
 
     int ring_phase = 0;   // number of rotations mod 3 (graph key)
@@ -164,7 +164,7 @@ int enqueue_flow_chain(hf_ctx* c) {
     c->last_iterations = iters;
     bool any_big = false;
     for (int k = 0; k < iters; k++) any_big |= c->levels[k].window > 32;
-    if (any_big) HF_HIP(c, hipMemsetAsync(c->sums, 0, c->sums_bytes, s));
+    // the window sums are zero on entry: zeroed at creation and re-zeroed by the blur kernel of every chain
 
     hf::FlowStep a{};
     a.py1 = c->py[1]; a.puv1 = c->puv[1];                         // :79 frame N-1
@@ -196,8 +196,8 @@ int enqueue_flow_chain(hf_ctx* c) {
         }
     }
     c->last_level = iters ? c->levels[iters - 1] : none;
-    hf::launch_blur_flow(g, c->last_level, c->blurred[0], c->blurred_xy[0], c->cfg.blur_radius, s);  // :115-116
-    HF_HIP(c, hipMemcpyAsync(c->h_total_delta, c->d_total_delta, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    hf::launch_blur_flow(g, c->last_level, c->blurred[0], c->blurred_xy[0], c->cfg.blur_radius,
+                         any_big ? c->sums : nullptr, (int)(c->sums_bytes / sizeof(uint32_t)), s);  // :115-116
     HF_HIP(c, hipGetLastError());
     return HF_OK;
 }
@@ -412,11 +412,13 @@ int hf_create(const hf_config* cfg, hf_ctx** out_ctx) {
         HF_TRY(hipMemsetAsync(c->blurred_xy[i], 0, c->plane_elems * sizeof(uint32_t), c->stream));
     }
     HF_TRY(hipMalloc((void**)&c->sums, c->sums_bytes));
-    HF_TRY(hipMalloc((void**)&c->d_total_delta, sizeof(uint32_t)));
-    HF_TRY(hipMemsetAsync(c->d_total_delta, 0, sizeof(uint32_t), c->stream));
+    HF_TRY(hipMemsetAsync(c->sums, 0, c->sums_bytes, c->stream));
     HF_TRY(hipMalloc((void**)&c->d_probe, 64 * sizeof(float)));
-    HF_TRY(hipHostMalloc((void**)&c->h_total_delta, sizeof(uint32_t), hipHostMallocDefault));
+    // m_totalFrameDelta is stored by the chain straight into mapped pinned memory (reference: blocking 4-byte
+    // readback in the middle of the chain, opticalFlowCalcSDR.cpp:91-94)
+    HF_TRY(hipHostMalloc((void**)&c->h_total_delta, 64, hipHostMallocMapped));
     *c->h_total_delta = 0;
+    HF_TRY(hipHostGetDevicePointer((void**)&c->d_total_delta, c->h_total_delta, 0));
     HF_TRY(hipEventCreate(&c->ev_upload));
     HF_TRY(hipEventCreate(&c->ev_flow_end));
     HF_TRY(hipEventCreate(&c->ev_warp_start));
@@ -440,7 +442,6 @@ void hf_destroy(hf_ctx* c) {
     if (c->out_frame) hipFree(c->out_frame);
     for (int i = 0; i < 2; i++) { if (c->blurred[i]) hipFree(c->blurred[i]); if (c->blurred_xy[i]) hipFree(c->blurred_xy[i]); }
     if (c->sums) hipFree(c->sums);
-    if (c->d_total_delta) hipFree(c->d_total_delta);
     if (c->d_probe) hipFree(c->d_probe);
     if (c->h_total_delta) hipHostFree(c->h_total_delta);
     for (auto& sp : c->spans) { hipEventDestroy(sp.b); hipEventDestroy(sp.e); }

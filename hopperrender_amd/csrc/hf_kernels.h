@@ -66,8 +66,9 @@ void launch_flow_big_argmin(const Geom& g, const FlowStep& a, hipStream_t stream
 void launch_expand_offsets(const Geom& g, const FlowLevel& last, int16_t* out, hipStream_t stream);
 // blurFlowKernel with a runtime radius (4 == reference); in: offsets of the last level, out: [2][lh][lw].
 // Also writes `packed` = x | y << 16 per grid point (what the fast warp kernel reads).
+// zero/zero_count: buffer this (last) kernel of the chain clears for the next chain (window sums).
 void launch_blur_flow(const Geom& g, const FlowLevel& last, int16_t* blurred, uint32_t* packed,
-                      int radius, hipStream_t stream);
+                      int radius, uint32_t* zero, int zero_count, hipStream_t stream);
 void launch_pack_flow(const Geom& g, const int16_t* flow, uint32_t* packed, hipStream_t stream);
 // warpFrameKernel, both planes in one launch.  black/white already scaled for HDR.
 void launch_warp(const Geom& g, const void* frame12, const void* frame21, const int16_t* flow, const uint32_t* flow_xy,
