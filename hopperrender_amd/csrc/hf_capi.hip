@@ -176,25 +176,43 @@ int enqueue_flow_chain(hf_ctx* c) {
     a.neighbor_scalar = c->p.neighbor_scalar;
     a.delta_divisor = (uint32_t)(g.lh * g.lw * (g.hdr ? 6 : 10));  // :93 / HDR :93
     hf::FlowLevel none{};
+    hf::PendingArgmin pending{};   // large-window step whose argmin the next launch takes (hf_kernels.h)
     int step_index = 0;
+    auto flush_pending = [&]() {   // explicit argmin launch for a pending step nobody can resolve lazily
+        if (!pending.active) return;
+        hf::FlowStep b = a;
+        b.cur = pending.lvl; b.prev = pending.lvl_prev; b.axis = pending.axis; b.capture_delta = pending.capture_delta;
+        b.sums = const_cast<uint32_t*>(pending.sums); b.use_neighbors = 0; b.pend = hf::PendingArgmin{};
+        hf::launch_flow_big_argmin(g, b, s);
+        pending = hf::PendingArgmin{};
+    };
+    const bool lazy = !(c->cfg.flags & HF_FLAG_NO_LAZY_ARGMIN);
     for (int k = 0; k < iters; k++) {                             // window halves every level (:110)
         a.cur = c->levels[k];
         a.prev = k ? c->levels[k - 1] : none;                     // :68-69: the chain starts from zero offsets
         a.use_neighbors = k >= 4;                                 // calcDeltaSumsKernelSDR.h:3,112
+        if (a.use_neighbors) flush_pending();                     // a launch with a neighbour term reads other windows' entries
         if (a.cur.window <= 32) {
             a.capture_delta = k == 0;                             // :91
             a.axis = 0;
+            a.pend = pending;
             hf::launch_flow_level_small(g, a, s);
+            pending = hf::PendingArgmin{};
         } else {
             for (int axis = 0; axis < 2; axis++, step_index++) {
                 a.axis = axis;
                 a.capture_delta = (k == 0 && axis == 0);
                 a.sums = c->sums + (size_t)step_index * c->sums_stride;
+                a.pend = pending;
                 hf::launch_flow_big_partial(g, a, s);
-                hf::launch_flow_big_argmin(g, a, s);
+                pending = hf::PendingArgmin{};
+                pending.active = 1; pending.axis = axis; pending.capture_delta = a.capture_delta;
+                pending.lvl = a.cur; pending.lvl_prev = a.prev; pending.sums = a.sums;
+                if (!lazy || a.use_neighbors) flush_pending();
             }
         }
     }
+    flush_pending();
     c->last_level = iters ? c->levels[iters - 1] : none;
     hf::launch_blur_flow(g, c->last_level, c->blurred[0], c->blurred_xy[0], c->cfg.blur_radius,
                          any_big ? c->sums : nullptr, (int)(c->sums_bytes / sizeof(uint32_t)), s);  // :115-116

@@ -324,6 +324,36 @@ __device__ __forceinline__ int group_argmin(const uint32_t* tot, int first, cons
     return b.cz;
 }
 
+// Resolves a.pend for the pending-level window that contains grid pixel (px, py): returns the window's
+// offset on the pending axis AFTER that step.  Must be called by whole waves whose lanes all lie in the
+// same pending window (true for every 32x32 tile); each aligned 16-lane group computes it redundantly.
+// `origin_leader`: this thread stores the result (exactly one thread per pending window does).
+__device__ __forceinline__ int resolve_pending(const Geom& g, const FlowStep& a, int px, int py, int lane, bool origin_leader) {
+    const PendingArgmin& p = a.pend;
+    const int wx = px >> p.lvl.log2w, wy = py >> p.lvl.log2w, w = wy * p.lvl.nwx + wx;
+    const int x0 = wx << p.lvl.log2w, y0 = wy << p.lvl.log2w;
+    int searched0 = 0;
+    if (p.lvl_prev.tx) searched0 = table_at(p.axis ? p.lvl_prev.ty : p.lvl_prev.tx, p.lvl_prev, x0, y0);
+    const uint32_t npix = (uint32_t)((min(g.lw, x0 + p.lvl.window) - x0) * (min(g.lh, y0 + p.lvl.window) - y0));
+    const int cz = lane & 15;
+    Best b{0xFFFFFFFFu, 16};
+    uint32_t mine = 0;
+    if (cz < a.R) {
+        const int cand = (int)(int16_t)(searched0 + rel_offset(cz, a.R));
+        mine = (p.sums[w * 16 + cz] << a.delta_scalar) + npix * ((uint32_t)(cand < 0 ? -cand : cand) & 0xFFFFu);  // no neighbour term (level < 4)
+        b.sum = mine; b.cz = cz;
+    }
+    best_xor(b, 1); best_xor(b, 2); best_xor(b, 4); best_xor(b, 8);
+    const int value = (int)(int16_t)(searched0 + rel_offset(b.cz, a.R));
+    if (p.capture_delta && w == 0) {   // opticalFlowCalcSDR.cpp:91-94
+        uint32_t cap = cz == (a.R >> 1) - 1 ? mine : 0u;
+        cap |= shfl_xor_u32(cap, 1); cap |= shfl_xor_u32(cap, 2); cap |= shfl_xor_u32(cap, 4); cap |= shfl_xor_u32(cap, 8);
+        if (origin_leader) *a.total_delta = cap / a.delta_divisor;
+    }
+    if (origin_leader) (p.axis ? p.lvl.ty : p.lvl.tx)[w] = (int16_t)value;
+    return value;
+}
+
 // ------------------------------------------------------------------------------------------
 // lane -> strip mapping: every window of size WS is an aligned, contiguous lane group
 // ------------------------------------------------------------------------------------------
@@ -376,6 +406,12 @@ __global__ __launch_bounds__(256) void flow_level_small_kernel(const Geom g, con
 
     WinConst wc{};
     if (win_in) wc = load_win_const(g, a, wx, wy, false);
+    if (a.pend.active) {   // the last large-window step (Y of the previous level) is resolved here
+        const int tx0 = blockIdx.x * M::TW, ty0 = blockIdx.y * M::TH;   // tile origin: inside the grid
+        const bool leader = tid == 0 && (tx0 & (a.pend.lvl.window - 1)) == 0 && (ty0 & (a.pend.lvl.window - 1)) == 0;
+        const int v = resolve_pending(g, a, tx0, ty0, lane, leader);
+        if (a.pend.axis) wc.oy = v; else wc.ox = v;
+    }
     const Strip<PX> strip = load_strip<PX>(g, a, cx0, cy);
     const int cap_cz = (a.R >> 1) - 1;
     uint32_t captured = 0;
@@ -418,7 +454,14 @@ __global__ __launch_bounds__(256) void flow_big_partial_kernel(const Geom g, con
         ox = table_at(a.prev.tx, a.prev, wx << a.cur.log2w, wy << a.cur.log2w);
         oy = table_at(a.prev.ty, a.prev, wx << a.cur.log2w, wy << a.cur.log2w);
     }
-    if (a.axis == 1) ox = a.cur.tx[wy * a.cur.nwx + wx];
+    if (a.pend.active) {   // argmin of the previous large-window step, taken here instead of in a launch of its own
+        const int tx0 = blockIdx.x * 32, ty0 = blockIdx.y * 32;
+        const bool leader = tid == 0 && (tx0 & (a.pend.lvl.window - 1)) == 0 && (ty0 & (a.pend.lvl.window - 1)) == 0;
+        const int v = resolve_pending(g, a, tx0, ty0, lane, leader);
+        if (a.pend.axis) oy = v; else ox = v;
+    } else if (a.axis == 1) {
+        ox = a.cur.tx[wy * a.cur.nwx + wx];
+    }
     const Strip<4> strip = load_strip<4>(g, a, cx0, cy);
     uint32_t sad[16];
     strip_sads<4>(sad, g, a, strip, ox, oy, a.axis);

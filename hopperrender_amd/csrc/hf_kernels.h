@@ -36,6 +36,19 @@ struct FlowLevel {
     int16_t* ty;             // [nwy][nwx] Y offsets after this level
 };
 
+// A large-window step whose argmin has not been taken yet: the NEXT launch resolves it in its prologue
+// (every workgroup recomputes the 16-way argmin of the window it lies in; the workgroup at the window's
+// origin also stores the result in the level table) instead of a separate tiny launch.  Only used for
+// steps without a neighbour term (levels < 4), so nothing in the consuming launch reads the table entry.
+struct PendingArgmin {
+    int active;
+    int axis;                // axis of the pending step
+    int capture_delta;       // pending step is the first of the chain: emit m_totalFrameDelta
+    FlowLevel lvl;           // level of the pending step (its table receives the result)
+    FlowLevel lvl_prev;      // level before it (offset the candidates were relative to); tx == nullptr: zero
+    const uint32_t* sums;    // [n_windows][16] raw SAD sums of the pending step
+};
+
 // One level (or one axis of a level for windows > 32) of the refinement chain
 // (calcDeltaSums + determineLowestLayer + adjustOffsetArray of the reference).
 struct FlowStep {
@@ -53,6 +66,7 @@ struct FlowStep {
     int delta_scalar, neighbor_scalar;
     int capture_delta;       // first step of the chain: emit m_totalFrameDelta
     uint32_t delta_divisor;  // lh*lw*10 (SDR) / lh*lw*6 (HDR)
+    PendingArgmin pend;      // previous large-window step still to be resolved (see above)
 };
 
 // Re-lay a freshly uploaded frame as phase planes (once per frame).

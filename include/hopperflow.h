@@ -53,6 +53,7 @@ typedef enum hf_output_mode {
 #define HF_FLAG_ASYNC 0x1 /* calls only enqueue; results/timings valid after hf_sync(). Default: every
                              call blocks like the reference (CL_TRUE transfers, clWaitForEvents). */
 #define HF_FLAG_NO_GRAPH 0x2 /* launch the flow chain eagerly instead of replaying a hipGraph (debug) */
+#define HF_FLAG_NO_LAZY_ARGMIN 0x8 /* large windows: take every argmin in a launch of its own (debug / A-B timing) */
 #define HF_FLAG_PROFILE 0x4  /* bracket every warp/copy launch and every flow chain with HIP events on ctx's
                                 stream; totals are read with hf_get_profile() (bench.py's live roofline figure) */
 

@@ -60,7 +60,7 @@ def test_eager_and_graph_paths_agree(native_lib):
     g = Golden("sdr_360p")
     frames = g.frames()
     outs = []
-    for flags in (0, capi.HF_FLAG_NO_GRAPH, capi.HF_FLAG_ASYNC):
+    for flags in (0, capi.HF_FLAG_NO_GRAPH, capi.HF_FLAG_ASYNC, capi.HF_FLAG_NO_LAZY_ARGMIN):
         c = make_calc(g.case, 16, 8, 6, flags=flags)
         for f in frames[:3]:
             c.updateFrame(f)
