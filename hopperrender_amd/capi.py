@@ -12,6 +12,7 @@ HF_FLAG_ASYNC = 0x1
 HF_FLAG_NO_GRAPH = 0x2
 HF_FLAG_PROFILE = 0x4
 HF_FLAG_NO_LAZY_ARGMIN = 0x8
+HF_FLAG_SHARED_WARP_STREAM = 0x10
 
 (HF_OK, HF_ERR_INVALID_ARGUMENT, HF_ERR_NO_DEVICE, HF_ERR_OUT_OF_MEMORY, HF_ERR_HIP, HF_ERR_STATE) = (0, -1, -2, -3, -4, -5)
 

@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <tuple>
@@ -37,6 +38,21 @@ constexpr int kMaxSearchRadius = 16;   // config.h:9
 constexpr int kCalcTimeInterval = 240; // config.h:17
 constexpr int kMaxSteps = 32;          // 2 * log2(max window)
 
+// HF_FLAG_SHARED_WARP_STREAM: one stream per device on which the (bandwidth-bound) warp kernels of all
+// contexts of this process are issued, so they run one after the other at full rate while the
+// latency-bound refinement chains of the other contexts fill the gaps on their own streams.
+std::mutex g_warp_stream_mutex;
+std::map<int, hipStream_t> g_warp_streams;
+hipStream_t shared_warp_stream(int device) {
+    std::lock_guard<std::mutex> lock(g_warp_stream_mutex);
+    auto it = g_warp_streams.find(device);
+    if (it != g_warp_streams.end()) return it->second;
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    g_warp_streams[device] = s;
+    return s;
+}
+
 }  // namespace
 
 struct hf_ctx {
@@ -44,6 +60,10 @@ struct hf_ctx {
     hf_config cfg{};
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t warp_stream = nullptr;                 // == stream unless HF_FLAG_SHARED_WARP_STREAM
+    hipEvent_t ev_chain_done = nullptr, ev_warps_done = nullptr;
+    bool on_warp_stream = false;                       // warp stream currently ordered after `stream`
+    bool in_period = false;                            // inside hf_interpolate_period (one completion event for all its warps)
     std::string err;
 
     // public fields of the reference object (opticalFlowCalc.h:27-48)
@@ -89,7 +109,7 @@ struct hf_ctx {
     std::map<std::tuple<int, int, int, int, int>, hipGraphExec_t> graphs;
 
     // HF_FLAG_PROFILE: event pairs around warp / copy / flow-chain launches
-    struct Span { hipEvent_t b, e; int kind; };
+    struct Span { hipEvent_t b, e; int kind; hipStream_t stream; };
     std::vector<hipEvent_t> ev_pool;
     std::vector<Span> spans;
     hf_profile prof{};
@@ -246,17 +266,18 @@ hipEvent_t pool_event(hf_ctx* c) {
 }
 
 // Opens a profiled span on the stream; returns the index of the span or -1.
-int span_begin(hf_ctx* c, int kind) {
+int span_begin(hf_ctx* c, int kind, hipStream_t stream = nullptr) {
     if (!c->profiling()) return -1;
     if ((c->prof_seen[kind]++ % (unsigned)c->prof_every[kind]) != 0) return -1;
-    hf_ctx::Span s{pool_event(c), pool_event(c), kind};
+    hf_ctx::Span s{pool_event(c), pool_event(c), kind, nullptr};
     if (!s.b || !s.e) return -1;
-    hipEventRecord(s.b, c->stream);
+    s.stream = stream ? stream : c->stream;
+    hipEventRecord(s.b, s.stream);
     c->spans.push_back(s);
     return (int)c->spans.size() - 1;
 }
 void span_end(hf_ctx* c, int idx) {
-    if (idx >= 0) hipEventRecord(c->spans[idx].e, c->stream);
+    if (idx >= 0) hipEventRecord(c->spans[idx].e, c->spans[idx].stream);
 }
 void collect_spans(hf_ctx* c) {  // stream must be idle
     for (auto& s : c->spans) {
@@ -272,7 +293,27 @@ void collect_spans(hf_ctx* c) {  // stream must be idle
     c->spans.clear();
 }
 
+// Warp/copy launches go to c->warp_stream.  With a shared warp stream the two streams are tied together by
+// events: the warp stream waits for everything enqueued on c->stream so far, and leave_warp_stream() makes
+// c->stream wait for the warps again, so every other call keeps its plain in-order semantics.
+int enter_warp_stream(hf_ctx* c) {
+    if (c->warp_stream == c->stream || c->on_warp_stream) return HF_OK;
+    HF_HIP(c, hipEventRecord(c->ev_chain_done, c->stream));
+    HF_HIP(c, hipStreamWaitEvent(c->warp_stream, c->ev_chain_done, 0));
+    c->on_warp_stream = true;
+    return HF_OK;
+}
+int leave_warp_stream(hf_ctx* c) {
+    if (!c->on_warp_stream) return HF_OK;
+    // ev_warps_done was recorded right behind this context's last warp launch (not here: by now other
+    // contexts have queued their warps on the shared stream and we must not wait for those)
+    HF_HIP(c, hipStreamWaitEvent(c->stream, c->ev_warps_done, 0));
+    c->on_warp_stream = false;
+    return HF_OK;
+}
+
 int sync_ctx(hf_ctx* c) {
+    if (int rc = leave_warp_stream(c)) return rc;
     HF_HIP(c, hipStreamSynchronize(c->stream));
     collect_spans(c);
     if (c->delta_pending) { c->total_frame_delta = *c->h_total_delta; c->delta_pending = false; }
@@ -298,6 +339,7 @@ int rotate_after_upload(hf_ctx* c) {
 // by_reference: the ring slot points at the caller's device frame instead of receiving a copy
 int update_common(hf_ctx* c, const void* src, hipMemcpyKind kind, bool by_reference = false) {
     if (int rc = set_device(c)) return rc;
+    if (int rc = leave_warp_stream(c)) return rc;
     HF_HIP(c, hipEventRecord(c->ev_upload, c->stream));  // m_ofcStartedEvent (:20)
     c->upload_recorded = true;
     if (by_reference) {
@@ -401,6 +443,13 @@ int hf_create(const hf_config* cfg, hf_ctx** out_ctx) {
         fail(c, _e == hipErrorOutOfMemory ? HF_ERR_OUT_OF_MEMORY : HF_ERR_HIP, "HIP error %d (%s) in %s", (int)_e, hipGetErrorString(_e), #call); \
         return bail(_e == hipErrorOutOfMemory ? HF_ERR_OUT_OF_MEMORY : HF_ERR_HIP); } } while (0)
     HF_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->warp_stream = c->stream;
+    if (cfg->flags & HF_FLAG_SHARED_WARP_STREAM) {
+        c->warp_stream = shared_warp_stream(c->device);
+        if (!c->warp_stream) { fail(c, HF_ERR_HIP, "cannot create the shared warp stream"); return bail(HF_ERR_HIP); }
+    }
+    HF_TRY(hipEventCreateWithFlags(&c->ev_chain_done, hipEventDisableTiming));
+    HF_TRY(hipEventCreateWithFlags(&c->ev_warps_done, hipEventDisableTiming));
     for (int i = 0; i < 3; i++) {
         HF_TRY(hipMalloc(&c->ring_store[i], c->in_bytes));
         c->ring[i] = c->ring_store[i];
@@ -452,7 +501,7 @@ int hf_create(const hf_config* cfg, hf_ctx** out_ctx) {
 void hf_destroy(hf_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
-    if (c->stream) hipStreamSynchronize(c->stream);  // clFinish (opticalFlowCalcSDR.cpp:186)
+    if (c->stream) { leave_warp_stream(c); hipStreamSynchronize(c->stream); }  // clFinish (opticalFlowCalcSDR.cpp:186)
     for (auto& kv : c->graphs) hipGraphExecDestroy(kv.second);
     for (int i = 0; i < 3; i++) { if (c->ring_store[i]) hipFree(c->ring_store[i]); if (c->py[i]) hipFree(c->py[i]); if (c->puv[i]) hipFree(c->puv[i]); }
     if (c->tables) hipFree(c->tables);
@@ -464,6 +513,8 @@ void hf_destroy(hf_ctx* c) {
     if (c->h_total_delta) hipHostFree(c->h_total_delta);
     for (auto& sp : c->spans) { hipEventDestroy(sp.b); hipEventDestroy(sp.e); }
     for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
+    if (c->ev_chain_done) hipEventDestroy(c->ev_chain_done);
+    if (c->ev_warps_done) hipEventDestroy(c->ev_warps_done);
     hipEvent_t evs[] = {c->ev_upload, c->ev_flow_end, c->ev_warp_start, c->ev_warp_end, c->ev_user0, c->ev_user1};
     for (hipEvent_t e : evs) if (e) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -495,6 +546,7 @@ int hf_calculate_optical_flow(hf_ctx* c) {
     if (R < 2 || R > kMaxSearchRadius) return fail(c, HF_ERR_INVALID_ARGUMENT, "calculateOpticalFlow: search radius %d outside [2, 16]", R);
     if (c->p.delta_scalar < 0 || c->p.delta_scalar > 24 || c->p.neighbor_scalar < 0 || c->p.neighbor_scalar > 24)
         return fail(c, HF_ERR_INVALID_ARGUMENT, "calculateOpticalFlow: delta/neighbor scalar outside [0, 24]");
+    if (int rc = leave_warp_stream(c)) return rc;
 
     int span = -1;
     if (c->cfg.flags & HF_FLAG_NO_GRAPH) {
@@ -552,11 +604,13 @@ int hf_warp_frames(hf_ctx* c, float t, int mode) {
     if (int rc = set_device(c)) return rc;
     const float scale = c->g.hdr ? 256.0f : 1.0f;  // opticalFlowCalcHDR.cpp:151-152
     if (!c->warp_started) { HF_HIP(c, hipEventRecord(c->ev_warp_start, c->stream)); c->warp_started = true; }
+    if (int rc = enter_warp_stream(c)) return rc;
     // frames N-2 / N-1 and the PREVIOUS flow (:154-156)
-    const int span = span_begin(c, 0);
+    const int span = span_begin(c, 0, c->warp_stream);
     hf::launch_warp(c->g, c->ring[0], c->ring[1], c->blurred[0], c->blurred_xy[0], c->out_target, t, mode,
-                    c->p.black_level * scale, c->p.white_level * scale, c->stream);
+                    c->p.black_level * scale, c->p.white_level * scale, c->warp_stream);
     span_end(c, span);
+    if (c->on_warp_stream && !c->in_period) HF_HIP(c, hipEventRecord(c->ev_warps_done, c->warp_stream));
     HF_HIP(c, hipGetLastError());
     return HF_OK;
 }
@@ -566,6 +620,7 @@ int hf_copy_frame(hf_ctx* c) {
     if (int rc = set_device(c)) return rc;
     const float scale = c->g.hdr ? 256.0f : 1.0f;  // opticalFlowCalcHDR.cpp:173-174
     const int idx = c->p.frame_count >= 3 ? 0 : c->p.frame_count >= 2 ? 1 : 2;  // opticalFlowCalcSDR.cpp:173
+    if (int rc = leave_warp_stream(c)) return rc;
     if (!c->warp_started) { HF_HIP(c, hipEventRecord(c->ev_warp_start, c->stream)); c->warp_started = true; }
     const int span = span_begin(c, 1);
     hf::launch_copy(c->g, c->ring[idx], c->out_target, c->p.black_level * scale, c->p.white_level * scale, c->stream);
@@ -580,16 +635,21 @@ int hf_interpolate_period(hf_ctx* c, const void* device_frame, int n_out, const 
     if (device_frame) if (int rc = hf_update_frame_device_ref(c, device_frame)) return rc;
     if (int rc = hf_calculate_optical_flow(c)) return rc;
     void* const saved = c->out_target;
-    for (int i = 0; i < n_out; i++) {
+    c->in_period = true;
+    int rc = HF_OK;
+    for (int i = 0; i < n_out && rc == HF_OK; i++) {
         c->out_target = device_out[i] ? device_out[i] : c->out_frame;
-        if (int rc = hf_warp_frames(c, t[i], mode)) { c->out_target = saved; return rc; }
+        rc = hf_warp_frames(c, t[i], mode);
     }
+    c->in_period = false;
     c->out_target = saved;
-    return HF_OK;
+    if (rc == HF_OK && c->on_warp_stream) HF_HIP(c, hipEventRecord(c->ev_warps_done, c->warp_stream));
+    return rc;
 }
 
 static int download_common(hf_ctx* c, void* dst, hipMemcpyKind kind) {
     if (int rc = set_device(c)) return rc;
+    if (int rc = leave_warp_stream(c)) return rc;
     if (c->out_target != dst) HF_HIP(c, hipMemcpyAsync(dst, c->out_target, c->out_bytes, kind, c->stream));
     HF_HIP(c, hipEventRecord(c->ev_warp_end, c->stream));
     if (kind == hipMemcpyDeviceToHost || !c->async()) {
@@ -722,6 +782,7 @@ int hf_write_blurred_flow(hf_ctx* c, int idx, const int16_t* host_in) {
 int hf_timer_begin(hf_ctx* c) {
     HF_CHECK_CTX(c);
     if (int rc = set_device(c)) return rc;
+    if (int rc = leave_warp_stream(c)) return rc;
     HF_HIP(c, hipEventRecord(c->ev_user0, c->stream));
     return HF_OK;
 }
@@ -730,6 +791,7 @@ int hf_timer_end(hf_ctx* c, float* elapsed_ms) {
     HF_CHECK_CTX(c);
     if (!elapsed_ms) return fail(c, HF_ERR_INVALID_ARGUMENT, "hf_timer_end: null");
     if (int rc = set_device(c)) return rc;
+    if (int rc = leave_warp_stream(c)) return rc;
     HF_HIP(c, hipEventRecord(c->ev_user1, c->stream));
     HF_HIP(c, hipEventSynchronize(c->ev_user1));
     HF_HIP(c, hipEventElapsedTime(elapsed_ms, c->ev_user0, c->ev_user1));

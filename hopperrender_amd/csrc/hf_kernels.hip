@@ -468,7 +468,10 @@ __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a,
 // divides 2^rs).  Flow lookups and displacement maths are done once per GROUP and reused for the
 // ROWS rows; all 2 * ROWS source runs are requested before any is consumed.
 template <typename E, int GROUP, int ROWS, int MODE>
-__global__ __launch_bounds__(256) void warp_fast_kernel(const Geom g, const WarpArgs a, int y_groups) {
+#ifndef HF_WARP_WAVES
+#define HF_WARP_WAVES 4   // waves (wave tiles) per workgroup
+#endif
+__global__ __launch_bounds__(64 * HF_WARP_WAVES) void warp_fast_kernel(const Geom g, const WarpArgs a, int y_groups) {
     constexpr int VEC = 16 / sizeof(E);
     // row group: luma groups first, then chroma; one row group per wave => the plane test is a scalar branch
     // Work decomposition: a wave tile = 64 lanes x VEC elements of one row group; tiles are numbered
@@ -479,10 +482,10 @@ __global__ __launch_bounds__(256) void warp_fast_kernel(const Geom g, const Warp
     // -> 19.0 us banded.  Placement only affects speed.
     const int wpr = (g.W + 64 * VEC - 1) / (64 * VEC);            // wave tiles per row group
     const int n_tiles = wpr * (y_groups + ((g.H >> 1) + ROWS - 1) / ROWS);
-    const int n_blocks = (n_tiles + 3) >> 2;
+    const int n_blocks = (n_tiles + HF_WARP_WAVES - 1) / HF_WARP_WAVES;
     const int per_band = (n_blocks + 7) >> 3;
     const int blk = (blockIdx.x & 7) * per_band + (blockIdx.x >> 3);
-    const int tile = blk * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile = blk * HF_WARP_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (blk >= n_blocks || tile >= n_tiles) return;
     const int rg = tile / wpr;
     const int cx0 = ((tile - rg * wpr) * 64 + (threadIdx.x & 63)) * VEC;
@@ -565,13 +568,13 @@ static void launch_warp_t(const Geom& g, const WarpArgs& a, hipStream_t stream) 
         if (rows_env == 1 || rows_env == 2 || (rows_env == 4 && g.rs >= 2)) rows = rows_env;
         const int y_groups = (g.H + rows - 1) / rows, uv_groups = ((g.H >> 1) + rows - 1) / rows;
         const int wpr = (g.W + 64 * VEC - 1) / (64 * VEC);
-        const int n_blocks = (wpr * (y_groups + uv_groups) + 3) / 4;
+        const int n_blocks = (wpr * (y_groups + uv_groups) + HF_WARP_WAVES - 1) / HF_WARP_WAVES;
         const dim3 fg(((n_blocks + 7) / 8) * 8);
 #define HF_WARP_FAST(G, R)                                                                   \
     do {                                                                                     \
-        if (a.mode == 0) warp_fast_kernel<E, G, R, 0><<<fg, 256, 0, stream>>>(g, a, y_groups);      \
-        else if (a.mode == 1) warp_fast_kernel<E, G, R, 1><<<fg, 256, 0, stream>>>(g, a, y_groups); \
-        else warp_fast_kernel<E, G, R, 2><<<fg, 256, 0, stream>>>(g, a, y_groups);                  \
+        if (a.mode == 0) warp_fast_kernel<E, G, R, 0><<<fg, 64 * HF_WARP_WAVES, 0, stream>>>(g, a, y_groups);      \
+        else if (a.mode == 1) warp_fast_kernel<E, G, R, 1><<<fg, 64 * HF_WARP_WAVES, 0, stream>>>(g, a, y_groups); \
+        else warp_fast_kernel<E, G, R, 2><<<fg, 64 * HF_WARP_WAVES, 0, stream>>>(g, a, y_groups);                  \
     } while (0)
 #define HF_WARP_ROWS(R)                                   \
     do {                                                  \

@@ -54,6 +54,9 @@ typedef enum hf_output_mode {
                              call blocks like the reference (CL_TRUE transfers, clWaitForEvents). */
 #define HF_FLAG_NO_GRAPH 0x2 /* launch the flow chain eagerly instead of replaying a hipGraph (debug) */
 #define HF_FLAG_NO_LAZY_ARGMIN 0x8 /* large windows: take every argmin in a launch of its own (debug / A-B timing) */
+#define HF_FLAG_SHARED_WARP_STREAM 0x10 /* batch hosts: warp kernels of all contexts of a device are issued on one shared
+                                           stream (they are bandwidth-bound: back-to-back beats side by side), the
+                                           latency-bound flow chains of the other contexts overlap them */
 #define HF_FLAG_PROFILE 0x4  /* bracket every warp/copy launch and every flow chain with HIP events on ctx's
                                 stream; totals are read with hf_get_profile() (bench.py's live roofline figure) */
 
