@@ -46,7 +46,7 @@ def parse_args():
     ap.add_argument("--neighbor", type=int, default=6)
     ap.add_argument("--blur-radius", type=int, default=4)
     ap.add_argument("--streams", type=int, default=8, help="independent frame-pair streams per GPU")
-    ap.add_argument("--pool", type=int, default=6, help="distinct synthetic source frames resident in HBM")
+    ap.add_argument("--pool", type=int, default=6, help="distinct synthetic source frames resident in HBM, per pair stream")
     ap.add_argument("--shared-warp-stream", action="store_true",
                     help="issue the warp kernels of all pair streams on one shared stream per GPU (measured slower: 26.5k vs 33k frames/s)")
     ap.add_argument("--copy-in", action="store_true",
@@ -133,11 +133,16 @@ def main():
     # ---- synthetic source frames, resident in HBM before the timed region ----
     scene = synth.Scene(H, W, bool(hdr), seed=1234 + rank)
     host_frames = [scene.frame(k) for k in range(a.pool)]
-    pool = []
-    for f in host_frames:
-        b = DeviceBuffer(f.nbytes, dev)
-        b.upload(f)
-        pool.append(b)
+    # every pair stream gets its OWN device copies (no artificial cache sharing between streams); the
+    # streams start at different frames of the sequence
+    pools = []
+    for s in range(a.streams):
+        bufs = []
+        for f in host_frames:
+            b = DeviceBuffer(f.nbytes, dev)
+            b.upload(f)
+            bufs.append(b)
+        pools.append(bufs)
 
     def update(c, ptr):
         if a.copy_in:
@@ -161,7 +166,7 @@ def main():
         outbufs.append([DeviceBuffer(c.output_frame_bytes, dev) for _ in range(max_out)])
         plans.append(BlendSchedule(SOURCE_24, target).plan(total_steps + 3)[3:])
         for k in range(3):  # prime the 3-frame ring and the previous-flow slot (m_frameCount >= 3)
-            update(c, pool[(s + k) % a.pool].ptr)
+            update(c, pools[s][(s + k) % a.pool].ptr)
         c.calculateOpticalFlow()
         c.sync()
 
@@ -172,10 +177,10 @@ def main():
         for s, c in enumerate(calcs):
             ts = plans[s][i]
             if a.copy_in:
-                c.updateFrameDevice(pool[(s + 3 + i) % a.pool].ptr)
+                c.updateFrameDevice(pools[s][(s + 3 + i) % a.pool].ptr)
                 c.interpolatePeriod(0, ts, out_ptrs[s], 2)
             else:
-                c.interpolatePeriod(pool[(s + 3 + i) % a.pool].ptr, ts, out_ptrs[s], 2)
+                c.interpolatePeriod(pools[s][(s + 3 + i) % a.pool].ptr, ts, out_ptrs[s], 2)
             n += len(ts)
         return n
 
@@ -227,7 +232,7 @@ def main():
         c.setProfileInterval(1, 1)
         c.resetProfile()
         for i in range(20):
-            c.interpolatePeriod(pool[i % a.pool].ptr, plans[0][i % len(plans[0])], out_ptrs[0], 2)
+            c.interpolatePeriod(pools[0][i % a.pool].ptr, plans[0][i % len(plans[0])], out_ptrs[0], 2)
             c.sync()
         p = c.profile()
         isolated = {"warp_us": 1e3 * p["warp_ms"] / max(p["warp_launches"], 1),
