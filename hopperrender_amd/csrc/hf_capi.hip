@@ -276,6 +276,15 @@ int span_begin(hf_ctx* c, int kind, hipStream_t stream = nullptr) {
     c->spans.push_back(s);
     return (int)c->spans.size() - 1;
 }
+// Span whose two events are filled in by the launch itself (hipExtLaunchKernelGGL start/stop events).
+int span_open(hf_ctx* c, int kind) {
+    if (!c->profiling()) return -1;
+    if ((c->prof_seen[kind]++ % (unsigned)c->prof_every[kind]) != 0) return -1;
+    hf_ctx::Span s{pool_event(c), pool_event(c), kind, nullptr};
+    if (!s.b || !s.e) return -1;
+    c->spans.push_back(s);
+    return (int)c->spans.size() - 1;
+}
 void span_end(hf_ctx* c, int idx) {
     if (idx >= 0) hipEventRecord(c->spans[idx].e, c->spans[idx].stream);
 }
@@ -606,10 +615,12 @@ int hf_warp_frames(hf_ctx* c, float t, int mode) {
     if (!c->warp_started) { HF_HIP(c, hipEventRecord(c->ev_warp_start, c->stream)); c->warp_started = true; }
     if (int rc = enter_warp_stream(c)) return rc;
     // frames N-2 / N-1 and the PREVIOUS flow (:154-156)
-    const int span = span_begin(c, 0, c->warp_stream);
+    // profiled launches carry start/stop events of the dispatch itself (hipExtLaunchKernel), i.e. the kernel's
+    // execution time as rocprof reports it, not the time the launch spent queued behind other streams
+    const int span = span_open(c, 0);
     hf::launch_warp(c->g, c->ring[0], c->ring[1], c->blurred[0], c->blurred_xy[0], c->out_target, t, mode,
-                    c->p.black_level * scale, c->p.white_level * scale, c->warp_stream);
-    span_end(c, span);
+                    c->p.black_level * scale, c->p.white_level * scale, c->warp_stream,
+                    span >= 0 ? c->spans[span].b : nullptr, span >= 0 ? c->spans[span].e : nullptr);
     if (c->on_warp_stream && !c->in_period) HF_HIP(c, hipEventRecord(c->ev_warps_done, c->warp_stream));
     HF_HIP(c, hipGetLastError());
     return HF_OK;

@@ -86,7 +86,8 @@ void launch_blur_flow(const Geom& g, const FlowLevel& last, int16_t* blurred, ui
 void launch_pack_flow(const Geom& g, const int16_t* flow, uint32_t* packed, hipStream_t stream);
 // warpFrameKernel, both planes in one launch.  black/white already scaled for HDR.
 void launch_warp(const Geom& g, const void* frame12, const void* frame21, const int16_t* flow, const uint32_t* flow_xy,
-                 void* out, float t, int mode, float black, float white, hipStream_t stream);
+                 void* out, float t, int mode, float black, float white, hipStream_t stream,
+                 hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);  // events: timestamps of the dispatch itself
 // copyFrameKernel, both planes in one launch.
 void launch_copy(const Geom& g, const void* src, void* out, float black, float white, hipStream_t stream);
 // v_rcp_f32 of the device (parity tooling: the reference's levels use it through OpenCL's fdiv).

@@ -15,6 +15,8 @@
 
 #include <cstdlib>
 
+#include <hip/hip_ext.h>
+
 namespace hf {
 
 namespace {
@@ -549,7 +551,7 @@ void launch_pack_flow(const Geom& g, const int16_t* flow, uint32_t* packed, hipS
 }
 
 template <typename E>
-static void launch_warp_t(const Geom& g, const WarpArgs& a, hipStream_t stream) {
+static void launch_warp_t(const Geom& g, const WarpArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
     constexpr int VEC = 16 / sizeof(E);  // 16-byte stores
     const bool aligned = (g.out_stride % VEC) == 0 && (((uintptr_t)a.out) & 15) == 0;
     const dim3 grd((g.W + 64 * VEC - 1) / (64 * VEC), (g.H + (g.H >> 1) + 3) / 4);
@@ -572,9 +574,10 @@ static void launch_warp_t(const Geom& g, const WarpArgs& a, hipStream_t stream) 
         const dim3 fg(((n_blocks + 7) / 8) * 8);
 #define HF_WARP_FAST(G, R)                                                                   \
     do {                                                                                     \
-        if (a.mode == 0) warp_fast_kernel<E, G, R, 0><<<fg, 64 * HF_WARP_WAVES, 0, stream>>>(g, a, y_groups);      \
-        else if (a.mode == 1) warp_fast_kernel<E, G, R, 1><<<fg, 64 * HF_WARP_WAVES, 0, stream>>>(g, a, y_groups); \
-        else warp_fast_kernel<E, G, R, 2><<<fg, 64 * HF_WARP_WAVES, 0, stream>>>(g, a, y_groups);                  \
+        /* ev0/ev1 (may be null): timestamps of the dispatch itself, like rocprof's kernel trace */ \
+        if (a.mode == 0) hipExtLaunchKernelGGL((warp_fast_kernel<E, G, R, 0>), fg, dim3(64 * HF_WARP_WAVES), 0, stream, ev0, ev1, 0, g, a, y_groups);      \
+        else if (a.mode == 1) hipExtLaunchKernelGGL((warp_fast_kernel<E, G, R, 1>), fg, dim3(64 * HF_WARP_WAVES), 0, stream, ev0, ev1, 0, g, a, y_groups); \
+        else hipExtLaunchKernelGGL((warp_fast_kernel<E, G, R, 2>), fg, dim3(64 * HF_WARP_WAVES), 0, stream, ev0, ev1, 0, g, a, y_groups);                  \
     } while (0)
 #define HF_WARP_ROWS(R)                                   \
     do {                                                  \
@@ -589,17 +592,17 @@ static void launch_warp_t(const Geom& g, const WarpArgs& a, hipStream_t stream) 
 #undef HF_WARP_FAST
         return;
     }
-    if (aligned) warp_kernel<E, VEC, true><<<grd, 256, 0, stream>>>(g, a);
-    else warp_kernel<E, VEC, false><<<grd, 256, 0, stream>>>(g, a);
+    if (aligned) hipExtLaunchKernelGGL((warp_kernel<E, VEC, true>), grd, dim3(256), 0, stream, ev0, ev1, 0, g, a);
+    else hipExtLaunchKernelGGL((warp_kernel<E, VEC, false>), grd, dim3(256), 0, stream, ev0, ev1, 0, g, a);
 }
 
 void launch_warp(const Geom& g, const void* frame12, const void* frame21, const int16_t* flow, const uint32_t* flow_xy,
-                 void* out, float t, int mode, float black, float white, hipStream_t stream) {
+                 void* out, float t, int mode, float black, float white, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
     WarpArgs a;
     a.frame12 = frame12; a.frame21 = frame21; a.flow = flow; a.flow_xy = flow_xy; a.out = out;
     a.s12 = t; a.s21 = 1.0f - t; a.mode = mode; a.black = black; a.white = white;
-    if (g.hdr) launch_warp_t<uint16_t>(g, a, stream);
-    else launch_warp_t<uint8_t>(g, a, stream);
+    if (g.hdr) launch_warp_t<uint16_t>(g, a, stream, ev0, ev1);
+    else launch_warp_t<uint8_t>(g, a, stream, ev0, ev1);
 }
 
 template <typename E>
