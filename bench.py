@@ -47,6 +47,8 @@ def parse_args():
     ap.add_argument("--blur-radius", type=int, default=4)
     ap.add_argument("--streams", type=int, default=8, help="independent frame-pair streams per GPU")
     ap.add_argument("--pool", type=int, default=6, help="distinct synthetic source frames resident in HBM, per pair stream")
+    ap.add_argument("--priority-streams", action="store_true",
+                    help="per pair stream: flow chain on a high-priority stream, warps on a low-priority stream")
     ap.add_argument("--shared-warp-stream", action="store_true",
                     help="issue the warp kernels of all pair streams on one shared stream per GPU (measured slower: 26.5k vs 33k frames/s)")
     ap.add_argument("--copy-in", action="store_true",
@@ -153,6 +155,8 @@ def main():
     flags = capi.HF_FLAG_ASYNC | (0 if a.no_profile else capi.HF_FLAG_PROFILE)
     if a.shared_warp_stream:
         flags |= capi.HF_FLAG_SHARED_WARP_STREAM
+    if a.priority_streams:
+        flags |= capi.HF_FLAG_PRIORITY_STREAMS
     cls = OpticalFlowCalcHDR if hdr else OpticalFlowCalcSDR
     calcs, outbufs, plans = [], [], []
     total_steps = a.warmup + a.steps

@@ -243,3 +243,21 @@ class DeviceBuffer:
             self.free()
         except Exception:
             pass
+
+
+class PinnedArray:
+    """A numpy view of page-locked host memory (hf_host_malloc_pinned) for frame I/O at full PCIe rate."""
+
+    def __init__(self, count, dtype):
+        self._lib = capi.load()
+        dt = np.dtype(dtype)
+        p = C.c_void_p()
+        capi.check(self._lib.hf_host_malloc_pinned(count * dt.itemsize, C.byref(p)))
+        self.ptr = p.value
+        self.array = np.ctypeslib.as_array((C.c_ubyte * (count * dt.itemsize)).from_address(self.ptr)).view(dt)
+
+    def free(self):
+        if self.ptr:
+            self.array = None
+            self._lib.hf_host_free_pinned(C.c_void_p(self.ptr))
+            self.ptr = None

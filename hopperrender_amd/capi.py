@@ -13,6 +13,7 @@ HF_FLAG_NO_GRAPH = 0x2
 HF_FLAG_PROFILE = 0x4
 HF_FLAG_NO_LAZY_ARGMIN = 0x8
 HF_FLAG_SHARED_WARP_STREAM = 0x10
+HF_FLAG_PRIORITY_STREAMS = 0x20
 
 (HF_OK, HF_ERR_INVALID_ARGUMENT, HF_ERR_NO_DEVICE, HF_ERR_OUT_OF_MEMORY, HF_ERR_HIP, HF_ERR_STATE) = (0, -1, -2, -3, -4, -5)
 
@@ -80,6 +81,8 @@ SIGNATURES = {
     "hf_device_free": (_i, [_i, _vp]),
     "hf_memcpy_h2d": (_i, [_i, _vp, _vp, C.c_size_t]),
     "hf_memcpy_d2h": (_i, [_i, _vp, _vp, C.c_size_t]),
+    "hf_host_malloc_pinned": (_i, [C.c_size_t, C.POINTER(_vp)]),
+    "hf_host_free_pinned": (_i, [_vp]),
 }
 
 _lib = None

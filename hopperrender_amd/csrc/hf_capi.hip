@@ -60,7 +60,8 @@ struct hf_ctx {
     hf_config cfg{};
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t warp_stream = nullptr;                 // == stream unless HF_FLAG_SHARED_WARP_STREAM
+    hipStream_t warp_stream = nullptr;                 // == stream unless HF_FLAG_SHARED_WARP_STREAM / HF_FLAG_PRIORITY_STREAMS
+    hipStream_t own_warp_stream = nullptr;             // HF_FLAG_PRIORITY_STREAMS: this context's low-priority warp stream
     hipEvent_t ev_chain_done = nullptr, ev_warps_done = nullptr;
     bool on_warp_stream = false;                       // warp stream currently ordered after `stream`
     bool in_period = false;                            // inside hf_interpolate_period (one completion event for all its warps)
@@ -451,8 +452,17 @@ int hf_create(const hf_config* cfg, hf_ctx** out_ctx) {
 #define HF_TRY(call) do { hipError_t _e = (call); if (_e != hipSuccess) { \
         fail(c, _e == hipErrorOutOfMemory ? HF_ERR_OUT_OF_MEMORY : HF_ERR_HIP, "HIP error %d (%s) in %s", (int)_e, hipGetErrorString(_e), #call); \
         return bail(_e == hipErrorOutOfMemory ? HF_ERR_OUT_OF_MEMORY : HF_ERR_HIP); } } while (0)
-    HF_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    c->warp_stream = c->stream;
+    if (cfg->flags & HF_FLAG_PRIORITY_STREAMS) {
+        // latency-bound chain on a high-priority stream, bandwidth-bound warps on a low-priority one: when
+        // several contexts share a GPU the short chain kernels are not starved by other contexts' warps
+        int lo = 0, hi = 0;
+        HF_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));   // lo = least priority (numerically greatest)
+        HF_TRY(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi));
+        HF_TRY(hipStreamCreateWithPriority(&c->own_warp_stream, hipStreamNonBlocking, lo));
+    } else {
+        HF_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    }
+    c->warp_stream = c->own_warp_stream ? c->own_warp_stream : c->stream;
     if (cfg->flags & HF_FLAG_SHARED_WARP_STREAM) {
         c->warp_stream = shared_warp_stream(c->device);
         if (!c->warp_stream) { fail(c, HF_ERR_HIP, "cannot create the shared warp stream"); return bail(HF_ERR_HIP); }
@@ -526,6 +536,7 @@ void hf_destroy(hf_ctx* c) {
     if (c->ev_warps_done) hipEventDestroy(c->ev_warps_done);
     hipEvent_t evs[] = {c->ev_upload, c->ev_flow_end, c->ev_warp_start, c->ev_warp_end, c->ev_user0, c->ev_user1};
     for (hipEvent_t e : evs) if (e) hipEventDestroy(e);
+    if (c->own_warp_stream) hipStreamDestroy(c->own_warp_stream);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -833,6 +844,15 @@ int hf_device_free(int device_index, void* p) {
     if (hipSetDevice(device_index) != hipSuccess) return HF_ERR_NO_DEVICE;
     return hipFree(p) == hipSuccess ? HF_OK : HF_ERR_HIP;
 }
+
+int hf_host_malloc_pinned(size_t bytes, void** out) {
+    if (!out) return HF_ERR_INVALID_ARGUMENT;
+    hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(nullptr, e == hipErrorOutOfMemory ? HF_ERR_OUT_OF_MEMORY : HF_ERR_HIP, "hf_host_malloc_pinned: %s", hipGetErrorString(e));
+    return HF_OK;
+}
+
+int hf_host_free_pinned(void* p) { return hipHostFree(p) == hipSuccess ? HF_OK : HF_ERR_HIP; }
 
 int hf_memcpy_h2d(int device_index, void* d, const void* h, size_t bytes) {
     if (hipSetDevice(device_index) != hipSuccess) return HF_ERR_NO_DEVICE;

@@ -288,9 +288,6 @@ __device__ __forceinline__ Run<E, GROUP> load_run(const E* __restrict__ p) {
 // elements that follow the run when o = 1), no lane divergence.
 template <typename E, int GROUP>
 __device__ __forceinline__ Run<E, GROUP> load_run_uv(const E* __restrict__ row, int x_first) {
-#if defined(HF_EXP) && HF_EXP == 2
-    return load_run<E, GROUP>(row + x_first);                       // timing experiment: single chroma load
-#endif
     const int e = x_first & ~1, o = x_first & 1;
     const Run<E, GROUP> lo = load_run<E, GROUP>(row + e);
     const Run<E, 2> ext = load_run<E, 2>(row + e + GROUP - 2 + 2 * o);   // o = 0: re-reads the run's tail (unused)
@@ -333,25 +330,14 @@ __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a,
     for (int k = 0; k < NG; k++) {
         const int cx = cx0 + k * GROUP;
         const int lx = CZ ? ((cx >> rs) & ~1) : (cx >> rs);
-#if defined(HF_EXP) && HF_EXP == 3
-        const uint32_t f12 = (uint32_t)(ly + lx) * 0u + 0x00030005u;   // timing experiment: no flow loads at all
-#else
         const uint32_t f12 = a.flow_xy[(size_t)ly * lw + lx];
-#endif
         const int ox12 = (int)(int16_t)(f12 & 0xFFFFu), oy12 = (int)(int16_t)(f12 >> 16);
         const int py = clampi(ly - (oy12 >> rs), 0, lh - 1);
         const int px = clampi(lx - (ox12 >> rs), 0, lw - 1);
-#if defined(HF_EXP) && (HF_EXP == 1 || HF_EXP == 3)
-        const uint32_t f21 = f12 + (uint32_t)(px + py) * 0u;   // timing experiment: no dependent second lookup
-#else
         const uint32_t f21 = a.flow_xy[(size_t)py * lw + px];
-#endif
         const int ox21 = (int)(int16_t)(f21 & 0xFFFFu), oy21 = (int)(int16_t)(f21 >> 16);
         xa[k] = cx + (int)roundf((float)ox12 * a.s12);
         xb[k] = cx - (int)roundf((float)ox21 * a.s21);
-#if defined(HF_EXP) && HF_EXP == 4
-        xa[k] = (xa[k] & ~7) | 8 * 0; xb[k] &= ~7;   // timing experiment: 16-byte aligned runs
-#endif
         if (CZ) {
             dya[k] = (int)roundf((float)oy12 * a.s12 * 0.5f);
             dyb[k] = -(int)roundf((float)oy21 * a.s21 * 0.5f);
@@ -459,9 +445,6 @@ __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a,
                 }
             }
         }
-#if defined(HF_EXP) && HF_EXP == 6
-        if (a.s12 == 12345.0f)   // timing experiment: no stores
-#endif
         *(uint4*)(out + (size_t)r * So) = *(const uint4*)v;
     }
 }
@@ -493,12 +476,6 @@ __global__ __launch_bounds__(64 * HF_WARP_WAVES) void warp_fast_kernel(const Geo
     const int cx0 = ((tile - rg * wpr) * 64 + (threadIdx.x & 63)) * VEC;
     const int uv_groups = ((g.H >> 1) + ROWS - 1) / ROWS;
     if (rg >= y_groups + uv_groups || cx0 >= g.W) return;
-#if defined(HF_EXP) && HF_EXP == 8
-    if (rg >= y_groups) return;   // timing experiment: luma only
-#endif
-#if defined(HF_EXP) && HF_EXP == 9
-    if (rg < y_groups) return;    // timing experiment: chroma only
-#endif
     if (rg >= y_groups) warp_fast_body<E, GROUP, ROWS, MODE, 1>(g, a, (rg - y_groups) * ROWS, cx0);
     else warp_fast_body<E, GROUP, ROWS, MODE, 0>(g, a, rg * ROWS, cx0);
 }

@@ -57,6 +57,9 @@ typedef enum hf_output_mode {
 #define HF_FLAG_SHARED_WARP_STREAM 0x10 /* batch hosts: warp kernels of all contexts of a device are issued on one shared
                                            stream (they are bandwidth-bound: back-to-back beats side by side), the
                                            latency-bound flow chains of the other contexts overlap them */
+#define HF_FLAG_PRIORITY_STREAMS 0x20 /* batch hosts: the context's flow chain runs on a high-priority stream, its warp
+                                         kernels on a low-priority one (tied by events), so the short latency-bound
+                                         chain kernels are not starved by other contexts' bandwidth-bound warps */
 #define HF_FLAG_PROFILE 0x4  /* bracket every warp/copy launch and every flow chain with HIP events on ctx's
                                 stream; totals are read with hf_get_profile() (bench.py's live roofline figure) */
 
@@ -186,6 +189,9 @@ int hf_device_malloc(int device_index, size_t bytes, void** out_dev_ptr);
 int hf_device_free(int device_index, void* dev_ptr);
 int hf_memcpy_h2d(int device_index, void* dev_dst, const void* host_src, size_t bytes);
 int hf_memcpy_d2h(int device_index, void* host_dst, const void* dev_src, size_t bytes);
+/* Page-locked host memory for frame buffers handed to hf_update_frame / hf_download_frame (full PCIe rate). */
+int hf_host_malloc_pinned(size_t bytes, void** out_host_ptr);
+int hf_host_free_pinned(void* host_ptr);
 
 #ifdef __cplusplus
 }
