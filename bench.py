@@ -45,8 +45,10 @@ def parse_args():
     ap.add_argument("--radius", type=int, default=16)
     ap.add_argument("--neighbor", type=int, default=6)
     ap.add_argument("--blur-radius", type=int, default=4)
-    ap.add_argument("--streams", type=int, default=8, help="independent frame-pair streams per GPU")
+    ap.add_argument("--streams", type=int, default=4, help="independent frame-pair streams per GPU")
     ap.add_argument("--pool", type=int, default=6, help="distinct synthetic source frames resident in HBM, per pair stream")
+    ap.add_argument("--single-stream-contexts", action="store_true",
+                    help="one HIP stream per pair stream (default: two -- the warps of a period overlap its flow chain)")
     ap.add_argument("--priority-streams", action="store_true",
                     help="per pair stream: flow chain on a high-priority stream, warps on a low-priority stream")
     ap.add_argument("--shared-warp-stream", action="store_true",
@@ -114,14 +116,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # HF_BENCH_BACKEND=gloo lets the multi-rank path be exercised on a box with fewer GPUs than ranks
+    # (ranks then share devices; the timing reductions run on CPU tensors).  Default: nccl (= RCCL).
+    backend = os.environ.get("HF_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
     n_gpus = world
     if a.gpus != n_gpus and rank == 0 and world > 1:
         print(f"warning: --gpus {a.gpus} but WORLD_SIZE {world}", file=sys.stderr)
-    torch.cuda.set_device(local_rank)
 
     import __graft_entry__
     __graft_entry__.build(quiet=True)
@@ -130,7 +138,7 @@ def main():
     from hopperrender_amd.protocol import SOURCE_24, BlendSchedule
 
     hdr, H, W, target, desc = WORKLOADS[a.workload]
-    dev = local_rank
+    dev = dev_index
 
     # ---- synthetic source frames, resident in HBM before the timed region ----
     scene = synth.Scene(H, W, bool(hdr), seed=1234 + rank)
@@ -157,6 +165,8 @@ def main():
         flags |= capi.HF_FLAG_SHARED_WARP_STREAM
     if a.priority_streams:
         flags |= capi.HF_FLAG_PRIORITY_STREAMS
+    if not a.single_stream_contexts and not a.shared_warp_stream and not a.priority_streams:
+        flags |= capi.HF_FLAG_DUAL_STREAM
     cls = OpticalFlowCalcHDR if hdr else OpticalFlowCalcSDR
     calcs, outbufs, plans = [], [], []
     total_steps = a.warmup + a.steps
@@ -213,8 +223,9 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
 
-    tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    ft = torch.tensor([float(frames_out)], dtype=torch.float64, device="cuda")
+    red_dev = "cuda" if backend == "nccl" else "cpu"
+    tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    ft = torch.tensor([float(frames_out)], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(ft, op=dist.ReduceOp.SUM)
@@ -281,7 +292,7 @@ def main():
             "dtype": "u16" if hdr else "u8", "data": "synthetic",
             "config": {"workload": a.workload, "description": desc, "search_radius": a.radius,
                        "delta_scalar": 8, "neighbor_scalar": a.neighbor, "blur_radius": a.blur_radius,
-                       "pair_streams_per_gpu": a.streams, "warp_stream": "shared per GPU" if a.shared_warp_stream else "per pair stream", "source_frames": "copied into the ring" if a.copy_in else "referenced in place (zero-copy)", "source_periods_per_step": a.streams,
+                       "pair_streams_per_gpu": a.streams, "warp_stream": "shared per GPU" if a.shared_warp_stream else ("own stream, overlapping the context's flow chain" if not a.single_stream_contexts else "same stream as the flow chain"), "source_frames": "copied into the ring" if a.copy_in else "referenced in place (zero-copy)", "source_periods_per_step": a.streams,
                        "output_frames_total": int(frames_total), "parallelism": f"pair-sharded x{n_gpus}, no collective",
                        "frame_bytes": F, "flow_grid": [st["low_width"], st["low_height"]], "res_scalar": st["res_scalar"]},
             "ms_per_flow_calc": round(prof["flow_ms"] / prof["flow_chains"], 4) if prof["flow_chains"] else None,

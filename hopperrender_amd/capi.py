@@ -14,6 +14,7 @@ HF_FLAG_PROFILE = 0x4
 HF_FLAG_NO_LAZY_ARGMIN = 0x8
 HF_FLAG_SHARED_WARP_STREAM = 0x10
 HF_FLAG_PRIORITY_STREAMS = 0x20
+HF_FLAG_DUAL_STREAM = 0x40
 
 (HF_OK, HF_ERR_INVALID_ARGUMENT, HF_ERR_NO_DEVICE, HF_ERR_OUT_OF_MEMORY, HF_ERR_HIP, HF_ERR_STATE) = (0, -1, -2, -3, -4, -5)
 

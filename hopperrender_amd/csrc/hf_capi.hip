@@ -63,6 +63,9 @@ struct hf_ctx {
     hipStream_t warp_stream = nullptr;                 // == stream unless HF_FLAG_SHARED_WARP_STREAM / HF_FLAG_PRIORITY_STREAMS
     hipStream_t own_warp_stream = nullptr;             // HF_FLAG_PRIORITY_STREAMS: this context's low-priority warp stream
     hipEvent_t ev_chain_done = nullptr, ev_warps_done = nullptr;
+    hipEvent_t ev_flow[2] = {nullptr, nullptr};        // recorded behind the chain that wrote blurred[i] (swapped with it)
+    bool ev_flow_valid[2] = {false, false};
+    bool dual() const { return (cfg.flags & HF_FLAG_DUAL_STREAM) != 0; }
     bool on_warp_stream = false;                       // warp stream currently ordered after `stream`
     bool in_period = false;                            // inside hf_interpolate_period (one completion event for all its warps)
     std::string err;
@@ -308,8 +311,15 @@ void collect_spans(hf_ctx* c) {  // stream must be idle
 // c->stream wait for the warps again, so every other call keeps its plain in-order semantics.
 int enter_warp_stream(hf_ctx* c) {
     if (c->warp_stream == c->stream || c->on_warp_stream) return HF_OK;
-    HF_HIP(c, hipEventRecord(c->ev_chain_done, c->stream));
-    HF_HIP(c, hipStreamWaitEvent(c->warp_stream, c->ev_chain_done, 0));
+    if (c->dual()) {
+        // warpFrames reads frames N-2/N-1 and the PREVIOUS flow (blurred[0]); the chain that may have just been
+        // enqueued on c->stream writes the OTHER flow buffer, so the warps only wait for the chain that produced
+        // blurred[0] and run side by side with the current one
+        if (c->ev_flow_valid[0]) HF_HIP(c, hipStreamWaitEvent(c->warp_stream, c->ev_flow[0], 0));
+    } else {
+        HF_HIP(c, hipEventRecord(c->ev_chain_done, c->stream));
+        HF_HIP(c, hipStreamWaitEvent(c->warp_stream, c->ev_chain_done, 0));
+    }
     c->on_warp_stream = true;
     return HF_OK;
 }
@@ -452,7 +462,12 @@ int hf_create(const hf_config* cfg, hf_ctx** out_ctx) {
 #define HF_TRY(call) do { hipError_t _e = (call); if (_e != hipSuccess) { \
         fail(c, _e == hipErrorOutOfMemory ? HF_ERR_OUT_OF_MEMORY : HF_ERR_HIP, "HIP error %d (%s) in %s", (int)_e, hipGetErrorString(_e), #call); \
         return bail(_e == hipErrorOutOfMemory ? HF_ERR_OUT_OF_MEMORY : HF_ERR_HIP); } } while (0)
-    if (cfg->flags & HF_FLAG_PRIORITY_STREAMS) {
+    if (cfg->flags & HF_FLAG_DUAL_STREAM) {
+        HF_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        HF_TRY(hipStreamCreateWithFlags(&c->own_warp_stream, hipStreamNonBlocking));
+        HF_TRY(hipEventCreateWithFlags(&c->ev_flow[0], hipEventDisableTiming));
+        HF_TRY(hipEventCreateWithFlags(&c->ev_flow[1], hipEventDisableTiming));
+    } else if (cfg->flags & HF_FLAG_PRIORITY_STREAMS) {
         // latency-bound chain on a high-priority stream, bandwidth-bound warps on a low-priority one: when
         // several contexts share a GPU the short chain kernels are not starved by other contexts' warps
         int lo = 0, hi = 0;
@@ -532,6 +547,7 @@ void hf_destroy(hf_ctx* c) {
     if (c->h_total_delta) hipHostFree(c->h_total_delta);
     for (auto& sp : c->spans) { hipEventDestroy(sp.b); hipEventDestroy(sp.e); }
     for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
+    for (hipEvent_t e : c->ev_flow) if (e) hipEventDestroy(e);
     if (c->ev_chain_done) hipEventDestroy(c->ev_chain_done);
     if (c->ev_warps_done) hipEventDestroy(c->ev_warps_done);
     hipEvent_t evs[] = {c->ev_upload, c->ev_flow_end, c->ev_warp_start, c->ev_warp_end, c->ev_user0, c->ev_user1};
@@ -604,6 +620,12 @@ int hf_calculate_optical_flow(hf_ctx* c) {
     HF_HIP(c, hipEventRecord(c->ev_flow_end, c->stream));
     c->delta_pending = c->last_iterations > 0;
     c->flow_timing_pending = true;
+    if (c->dual()) {   // tag the flow buffer just written, the tag travels with the buffer through the swap below
+        HF_HIP(c, hipEventRecord(c->ev_flow[0], c->stream));
+        c->ev_flow_valid[0] = true;
+        hipEvent_t te = c->ev_flow[0]; c->ev_flow[0] = c->ev_flow[1]; c->ev_flow[1] = te;
+        bool tv = c->ev_flow_valid[0]; c->ev_flow_valid[0] = c->ev_flow_valid[1]; c->ev_flow_valid[1] = tv;
+    }
     // opticalFlowCalcSDR.cpp:121-123 : swap so that [1] = newest flow, [0] = previous flow
     int16_t* t = c->blurred[0];
     c->blurred[0] = c->blurred[1];

@@ -356,7 +356,36 @@ __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a,
         if (need_a) interior = interior && xa[k] >= 1 && xa[k] + GROUP - 1 <= W - 2;
         if (need_b) interior = interior && xb[k] >= 1 && xb[k] + GROUP - 1 <= W - 2;
     }
-    if (__builtin_amdgcn_ballot_w64(!interior) == 0) {
+    // Several flow cells per thread (NG > 1, e.g. 8-bit frames at rs = 2): where the blurred flow is locally
+    // uniform the NG runs of a row are one contiguous VEC-wide run -> one 16-byte load instead of NG small ones.
+    bool merged = NG > 1;
+#pragma unroll
+    for (int k = 1; k < NG; k++) {
+        if (need_a) merged = merged && xa[k] == xa[0] + k * GROUP && dya[k] == dya[0];
+        if (need_b) merged = merged && xb[k] == xb[0] + k * GROUP && dyb[k] == dyb[0];
+    }
+    if (NG > 1 && __builtin_amdgcn_ballot_w64(!(interior && merged)) == 0) {
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) {
+            const int cy = min(cy0 + r, dim_y - 1);
+            if (need_a) {
+                const E* rowp = A + (size_t)mirror_warp(cy + dya[0], dim_y) * Si;
+                const Run<E, VEC> w = CZ ? load_run_uv<E, VEC>(rowp, xa[0]) : load_run<E, VEC>(rowp + xa[0]);
+#pragma unroll
+                for (int k = 0; k < NG; k++)
+#pragma unroll
+                    for (int i = 0; i < GROUP; i++) ra[r][k].v[i] = w.v[k * GROUP + i];
+            }
+            if (need_b) {
+                const E* rowp = B + (size_t)mirror_warp(cy + dyb[0], dim_y) * Si;
+                const Run<E, VEC> w = CZ ? load_run_uv<E, VEC>(rowp, xb[0]) : load_run<E, VEC>(rowp + xb[0]);
+#pragma unroll
+                for (int k = 0; k < NG; k++)
+#pragma unroll
+                    for (int i = 0; i < GROUP; i++) rb[r][k].v[i] = w.v[k * GROUP + i];
+            }
+        }
+    } else if (__builtin_amdgcn_ballot_w64(!interior) == 0) {
 #pragma unroll
         for (int r = 0; r < ROWS; r++) {
             const int cy = min(cy0 + r, dim_y - 1);           // rows past the plane end re-read the last row (not stored)

@@ -60,6 +60,10 @@ typedef enum hf_output_mode {
 #define HF_FLAG_PRIORITY_STREAMS 0x20 /* batch hosts: the context's flow chain runs on a high-priority stream, its warp
                                          kernels on a low-priority one (tied by events), so the short latency-bound
                                          chain kernels are not starved by other contexts' bandwidth-bound warps */
+#define HF_FLAG_DUAL_STREAM 0x40 /* async hosts: warp kernels on a second stream of the context.  warpFrames consumes the
+                                    PREVIOUS flow and frames N-2/N-1 (opticalFlowCalcSDR.cpp:154-156) while
+                                    calculateOpticalFlow produces the next flow from N-1/N into the other buffer, so the two
+                                    overlap inside one context; events keep every other ordering intact */
 #define HF_FLAG_PROFILE 0x4  /* bracket every warp/copy launch and every flow chain with HIP events on ctx's
                                 stream; totals are read with hf_get_profile() (bench.py's live roofline figure) */
 

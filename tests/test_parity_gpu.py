@@ -61,7 +61,7 @@ def test_eager_and_graph_paths_agree(native_lib):
     frames = g.frames()
     outs = []
     for flags in (0, capi.HF_FLAG_NO_GRAPH, capi.HF_FLAG_ASYNC, capi.HF_FLAG_NO_LAZY_ARGMIN,
-                  capi.HF_FLAG_ASYNC | capi.HF_FLAG_SHARED_WARP_STREAM):
+                  capi.HF_FLAG_ASYNC | capi.HF_FLAG_SHARED_WARP_STREAM, capi.HF_FLAG_ASYNC | capi.HF_FLAG_DUAL_STREAM):
         c = make_calc(g.case, 16, 8, 6, flags=flags)
         for f in frames[:3]:
             c.updateFrame(f)
@@ -176,7 +176,13 @@ def test_batched_async_contexts_match_blocking_path(native_lib):
                     outs.append(c.downloadFrame().copy())
         want.append(outs)
         c.close()
-    flags = capi.HF_FLAG_ASYNC | capi.HF_FLAG_SHARED_WARP_STREAM
+    run_batched(frames, want, ts, capi.HF_FLAG_ASYNC | capi.HF_FLAG_SHARED_WARP_STREAM)
+    run_batched(frames, want, ts, capi.HF_FLAG_ASYNC | capi.HF_FLAG_DUAL_STREAM)
+
+
+def run_batched(frames, want, ts, flags):
+    from hopperrender_amd.calc import DeviceBuffer, OpticalFlowCalcSDR
+    H, W, n = 180, 320, len(frames[0])
     calcs = [OpticalFlowCalcSDR(H, W, search_radius=12, flags=flags) for _ in frames]
     dev = [[DeviceBuffer(f.nbytes) for f in fs] for fs in frames]
     for s, fs in enumerate(frames):
