@@ -57,10 +57,12 @@ def parse_args():
                     help="updateFrame copies the device-resident source frame into the ring (default: zero-copy reference)")
     ap.add_argument("--profile-every", type=int, default=8,
                     help="bracket every n-th warp launch / flow chain with HIP events (event records perturb back-to-back launches)")
+    ap.add_argument("--diagnose", default="", choices=["", "no-flow", "no-warp"],
+                    help="NOT a benchmark: drop the flow chain or the warps from the step to see what the other part costs")
     ap.add_argument("--no-profile", action="store_true", help="no per-kernel HIP events in the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference", action="store_true")
-    ap.add_argument("--cpu-sample-pairs", type=int, default=6)
+    ap.add_argument("--cpu-sample-pairs", type=int, default=8)
     return ap.parse_args()
 
 
@@ -190,7 +192,13 @@ def main():
         n = 0
         for s, c in enumerate(calcs):
             ts = plans[s][i]
-            if a.copy_in:
+            if a.diagnose == "no-flow":
+                c.updateFrameDeviceRef(pools[s][(s + 3 + i) % a.pool].ptr)
+                for j, t in enumerate(ts):
+                    c.setOutputBuffer(out_ptrs[s][j]); c.warpFrames(t, 2)
+            elif a.diagnose == "no-warp":
+                c.interpolatePeriod(pools[s][(s + 3 + i) % a.pool].ptr, [], [], 2)
+            elif a.copy_in:
                 c.updateFrameDevice(pools[s][(s + 3 + i) % a.pool].ptr)
                 c.interpolatePeriod(0, ts, out_ptrs[s], 2)
             else:
@@ -247,8 +255,13 @@ def main():
         c.setProfileInterval(1, 1)
         c.resetProfile()
         for i in range(20):
-            c.interpolatePeriod(pools[0][i % a.pool].ptr, plans[0][i % len(plans[0])], out_ptrs[0], 2)
-            c.sync()
+            c.updateFrameDeviceRef(pools[0][i % a.pool].ptr)
+            c.calculateOpticalFlow()
+            c.sync()                                   # chain alone ...
+            for j, t in enumerate(plans[0][i % len(plans[0])]):
+                c.setOutputBuffer(out_ptrs[0][j])
+                c.warpFrames(t, 2)
+            c.sync()                                   # ... then the warps alone
         p = c.profile()
         isolated = {"warp_us": 1e3 * p["warp_ms"] / max(p["warp_launches"], 1),
                     "flow_chain_us": 1e3 * p["flow_ms"] / max(p["flow_chains"], 1)}
@@ -283,6 +296,7 @@ def main():
                                     "frac": round(iso / HBM_PEAK_GBS, 4), "frac_of_measured_copy_bw_6290": round(iso / 6290.0, 4),
                                     "note": "same kernel alone on the GPU (one stream), measured after the timed region"}
         out = {
+            **({"DIAGNOSTIC_NOT_A_BENCHMARK": a.diagnose} if a.diagnose else {}),
             "metric": "interpolated frames/sec + ms/flow-calc, 2160p HDR, 1/2/4/8 MI355X",
             "value": round(frames_total / elapsed_max, 1),
             "unit": "frames/s",
