@@ -102,6 +102,70 @@ __global__ __launch_bounds__(256) void prep_phase_kernel(const E* __restrict__ f
     }
 }
 
+// Fast path of the phase-plane build (no LDS): a thread takes the 4 << RS consecutive elements behind 4
+// consecutive grid columns, reduces them to their top 8 bits and emits one dword per phase (4 columns x 1 byte;
+// chroma: two dwords per phase pair, 4 columns x (U,V)).  A wave therefore reads 64 x 16..64 contiguous bytes
+// and writes 256 contiguous bytes per phase row.  The mirrored margins need no extra loads:
+//     PY [ph ][-1-k] = PY [nph-1-ph ][k]        PY [ph ][lw+k] = PY [nph-1-ph ][lw-1-k]
+//     PUV[ph2][-1-k] = PUV[nph2-1-ph2][k]       (same on the right; U,V keep their order inside a pair)
+// because reflecting x -> -x-1 (or 2W-x-1) maps phase ph of column j to phase nph-1-ph of column -j-1, so a
+// thread whose columns lie within `mx` of an edge also stores its dwords, columns reversed, into the margin.
+// Requires W == lw << RS, lw % 4 == 0, mx <= lw and 16-byte aligned rows (else: prep_phase_kernel).
+template <typename E, int RS>
+__global__ __launch_bounds__(128) void prep_phase_fast_kernel(const E* __restrict__ f, uint8_t* __restrict__ py,
+                                                               uint16_t* __restrict__ puv, int H, int W, int S,
+                                                               PhaseLayout pl) {
+    constexpr int NPH = 1 << RS, NE = 4 << RS;               // phases, elements per thread
+    constexpr int NPH2 = NPH > 1 ? NPH / 2 : 1;
+    const int row = blockIdx.y;
+    const int t = blockIdx.x * 128 + threadIdx.x;            // group of 4 grid columns
+    const int lw = W >> RS;
+    if (4 * t >= lw) return;
+    const bool luma = row < H;
+    const E* __restrict__ src = (luma ? f + (size_t)row * S : f + (size_t)H * S + (size_t)(row - H) * S) + (size_t)t * NE;
+    __attribute__((aligned(16))) E e[NE];
+#pragma unroll
+    for (int i = 0; i < NE * (int)sizeof(E) / 16; i++) ((uint4*)e)[i] = ((const uint4*)src)[i];
+    if (NE * sizeof(E) < 16) {                               // RS = 0..1 with 8-bit elements: 4 or 8 bytes per thread
+#pragma unroll
+        for (int i = 0; i < NE; i++) e[i] = src[i];
+    }
+    const int j0 = 4 * t;                                    // first column of this thread
+    const int jl = pl.mx - 4 - j0;                           // plane index of the mirrored dword in the left margin
+    const int jr = pl.mx + 2 * lw - 4 - j0;                  // ... and in the right margin
+    const bool left = j0 + 4 <= pl.mx, right = j0 >= lw - pl.mx;
+    if (luma) {
+        uint8_t* __restrict__ base = py + (size_t)row * NPH * pl.lwp;
+#pragma unroll
+        for (int ph = 0; ph < NPH; ph++) {
+            const uint32_t b0 = top8<E>(e[ph]), b1 = top8<E>(e[NPH + ph]), b2 = top8<E>(e[2 * NPH + ph]), b3 = top8<E>(e[3 * NPH + ph]);
+            *(uint32_t*)(base + (size_t)ph * pl.lwp + pl.mx + j0) = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+            const uint32_t rev = b3 | (b2 << 8) | (b1 << 16) | (b0 << 24);
+            uint8_t* mrow = base + (size_t)(NPH - 1 - ph) * pl.lwp;
+            if (left) *(uint32_t*)(mrow + jl) = rev;
+            if (right) *(uint32_t*)(mrow + jr) = rev;
+        }
+    } else {
+        uint16_t* __restrict__ base = puv + (size_t)(row - H) * NPH2 * pl.lwp;
+#pragma unroll
+        for (int p2 = 0; p2 < NPH2; p2++) {
+            // pair of column c: elements (c << RS) + 2*p2, +1   (RS = 0: pair at c & ~1)
+            uint32_t pr[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int x = RS > 0 ? c * NPH + 2 * p2 : (c & ~1);
+                pr[c] = top8<E>(e[x]) | (top8<E>(e[x + 1]) << 8);
+            }
+            uint16_t* d = base + (size_t)p2 * pl.lwp + pl.mx + j0;
+            *(uint2*)d = make_uint2(pr[0] | (pr[1] << 16), pr[2] | (pr[3] << 16));
+            uint16_t* mrow = base + (size_t)(NPH2 - 1 - p2) * pl.lwp;
+            const uint2 rev = make_uint2(pr[3] | (pr[2] << 16), pr[1] | (pr[0] << 16));
+            if (left) *(uint2*)(mrow + jl) = rev;
+            if (right) *(uint2*)(mrow + jr) = rev;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // per-window constants
 // ------------------------------------------------------------------------------------------
@@ -517,14 +581,35 @@ PhaseLayout make_phase_layout(const Geom& g, int max_iterations) {
     pl.nph = 1 << g.rs;
     pl.nph2 = pl.nph > 1 ? pl.nph / 2 : 1;
     const int reach = (max_iterations + 1) * 64 + 8;   // |offset| <= iterations * (R/2)^2, + one candidate, R <= 16
-    pl.mx = (reach >> g.rs) + 2;
+    pl.mx = (((reach >> g.rs) + 2 + 3) / 4) * 4;        // multiple of 4: margin dwords line up with the 4-column groups
     pl.lwp = ((g.lw + 2 * pl.mx + 8 + 15) / 16) * 16;
     pl.py_bytes = (size_t)g.H * pl.nph * pl.lwp;
     pl.puv_bytes = (size_t)(g.H / 2) * pl.nph2 * pl.lwp * sizeof(uint16_t);
     return pl;
 }
 
+template <typename E>
+static bool launch_prep_fast(const Geom& g, const PhaseLayout& pl, const void* frame, uint8_t* py, uint16_t* puv, hipStream_t stream) {
+    const int lw = g.W >> g.rs;
+    const size_t row_bytes = (size_t)g.in_stride * sizeof(E);
+    // RS = 0 chroma pairs straddle nothing only when columns come in even pairs: lw % 4 == 0 covers it
+    if ((lw << g.rs) != g.W || lw != g.lw || (lw & 3) || pl.mx > lw || (pl.mx & 3) || (row_bytes & 15) || (((uintptr_t)frame) & 15) ||
+        (pl.lwp & 3) || g.rs > 4)
+        return false;
+    const dim3 grd((lw / 4 + 127) / 128, g.H + g.H / 2);
+    const E* f = (const E*)frame;
+    switch (g.rs) {
+        case 0: prep_phase_fast_kernel<E, 0><<<grd, 128, 0, stream>>>(f, py, puv, g.H, g.W, g.in_stride, pl); break;
+        case 1: prep_phase_fast_kernel<E, 1><<<grd, 128, 0, stream>>>(f, py, puv, g.H, g.W, g.in_stride, pl); break;
+        case 2: prep_phase_fast_kernel<E, 2><<<grd, 128, 0, stream>>>(f, py, puv, g.H, g.W, g.in_stride, pl); break;
+        case 3: prep_phase_fast_kernel<E, 3><<<grd, 128, 0, stream>>>(f, py, puv, g.H, g.W, g.in_stride, pl); break;
+        default: prep_phase_fast_kernel<E, 4><<<grd, 128, 0, stream>>>(f, py, puv, g.H, g.W, g.in_stride, pl); break;
+    }
+    return true;
+}
+
 void launch_prep_frame(const Geom& g, const PhaseLayout& pl, const void* frame, uint8_t* py, uint16_t* puv, hipStream_t stream) {
+    if (g.hdr ? launch_prep_fast<uint16_t>(g, pl, frame, py, puv, stream) : launch_prep_fast<uint8_t>(g, pl, frame, py, puv, stream)) return;
     const int rows = g.H + g.H / 2;
     const size_t smem = (size_t)((g.W + 15) / 16) * 16 + 16;
     if (g.hdr) prep_phase_kernel<uint16_t><<<rows, 256, smem, stream>>>((const uint16_t*)frame, py, puv, g.H, g.W, g.in_stride, pl);
