@@ -304,10 +304,15 @@ __device__ __forceinline__ Run<E, GROUP> load_run_uv(const E* __restrict__ row, 
 // compile-time so the per-element code is straight-line.
 typedef float float2v __attribute__((ext_vector_type(2)));
 
-template <typename E, int GROUP, int ROWS, int MODE, int CZ>
+template <int VB> struct StoreVec;
+template <> struct StoreVec<16> { using type = uint4; };
+template <> struct StoreVec<8> { using type = uint2; };
+
+template <typename E, int GROUP, int ROWS, int MODE, int CZ, int VB>
 __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a, int cy0, int cx0) {
     using T = ElemTraits<E>;
-    constexpr int VEC = 16 / sizeof(E);
+    using SV = typename StoreVec<VB>::type;
+    constexpr int VEC = VB / sizeof(E);
     constexpr int NG = VEC / GROUP;
     static_assert(VEC % GROUP == 0, "group must divide the per-thread vector");
     const int H = g.H, W = g.W, Si = g.in_stride, So = g.out_stride, rs = g.rs, lw = g.lw, lh = g.lh;
@@ -438,7 +443,7 @@ __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a,
 #pragma unroll
     for (int r = 0; r < ROWS; r++) {
         if (r >= nrows) break;
-        __attribute__((aligned(16))) E v[VEC];
+        __attribute__((aligned(VB))) E v[VEC];
 #pragma unroll
         for (int k = 0; k < NG; k++) {
             if (MODE == 0) {
@@ -474,19 +479,21 @@ __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a,
                 }
             }
         }
-        *(uint4*)(out + (size_t)r * So) = *(const uint4*)v;
+        *(SV*)(out + (size_t)r * So) = *(const SV*)v;
     }
 }
 
 // Thread = VEC consecutive elements x ROWS consecutive rows that share one flow-cell row (ROWS
 // divides 2^rs).  Flow lookups and displacement maths are done once per GROUP and reused for the
 // ROWS rows; all 2 * ROWS source runs are requested before any is consumed.
-template <typename E, int GROUP, int ROWS, int MODE>
 #ifndef HF_WARP_WAVES
 #define HF_WARP_WAVES 4   // waves (wave tiles) per workgroup
 #endif
+// VB = bytes of output per thread and row: 16, or 8 for small frames (<= 1080p 8-bit), where 16-byte threads
+// leave too few waves to hide the per-wave latency chain (one round of fat waves: 9.4 us for 9.3 MB).
+template <typename E, int GROUP, int ROWS, int MODE, int VB>
 __global__ __launch_bounds__(64 * HF_WARP_WAVES) void warp_fast_kernel(const Geom g, const WarpArgs a, int y_groups) {
-    constexpr int VEC = 16 / sizeof(E);
+    constexpr int VEC = VB / sizeof(E);
     // row group: luma groups first, then chroma; one row group per wave => the plane test is a scalar branch
     // Work decomposition: a wave tile = 64 lanes x VEC elements of one row group; tiles are numbered
     // row-major (consecutive tiles = consecutive memory), a workgroup takes 4 consecutive tiles, and
@@ -505,8 +512,8 @@ __global__ __launch_bounds__(64 * HF_WARP_WAVES) void warp_fast_kernel(const Geo
     const int cx0 = ((tile - rg * wpr) * 64 + (threadIdx.x & 63)) * VEC;
     const int uv_groups = ((g.H >> 1) + ROWS - 1) / ROWS;
     if (rg >= y_groups + uv_groups || cx0 >= g.W) return;
-    if (rg >= y_groups) warp_fast_body<E, GROUP, ROWS, MODE, 1>(g, a, (rg - y_groups) * ROWS, cx0);
-    else warp_fast_body<E, GROUP, ROWS, MODE, 0>(g, a, rg * ROWS, cx0);
+    if (rg >= y_groups) warp_fast_body<E, GROUP, ROWS, MODE, 1, VB>(g, a, (rg - y_groups) * ROWS, cx0);
+    else warp_fast_body<E, GROUP, ROWS, MODE, 0, VB>(g, a, rg * ROWS, cx0);
 }
 
 template <typename E, int VEC, bool ALIGNED>
@@ -556,34 +563,34 @@ void launch_pack_flow(const Geom& g, const int16_t* flow, uint32_t* packed, hipS
     pack_flow_kernel<<<(n + 255) / 256, 256, 0, stream>>>(flow, packed, n);
 }
 
-template <typename E>
-static void launch_warp_t(const Geom& g, const WarpArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
-    constexpr int VEC = 16 / sizeof(E);  // 16-byte stores
-    const bool aligned = (g.out_stride % VEC) == 0 && (((uintptr_t)a.out) & 15) == 0;
-    const dim3 grd((g.W + 64 * VEC - 1) / (64 * VEC), (g.H + (g.H >> 1) + 3) / 4);
+// Fast-path launch for VB bytes per thread and row.  Returns false when the shape does not qualify.
+template <typename E, int VB, bool ALL_ROWS>
+static bool launch_warp_fast(const Geom& g, const WarpArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+    constexpr int VEC = VB / sizeof(E);
+    const bool aligned = (g.out_stride % VEC) == 0 && (((uintptr_t)a.out) & (VB - 1)) == 0;
     const int cell = 1 << g.rs;
     const int group = cell < VEC ? cell : VEC;
+    // blend shortcuts of the fast kernel need 0 <= t <= 1 and levels that cannot produce NaN;
     // chroma runs are read with element-pair granularity: needs an even input stride
-    // blend shortcuts of the fast kernel need 0 <= t <= 1 and levels that cannot produce NaN
     const bool sane = a.s12 >= 0.0f && a.s12 <= 1.0f && a.white != a.black && a.white != 0.0f &&
                       a.white == a.white && a.black == a.black;
     const bool fast = aligned && a.mode >= 0 && a.mode <= 2 && (a.mode != 2 || sane) && a.flow_xy && (g.in_stride % 2) == 0 &&
-                      g.W >= 2 * VEC && group * (int)sizeof(E) >= 4;
-    if (fast) {
-        // rows per thread (must divide the 2^rs rows of a flow cell)
-        static const int rows_env = getenv("HF_WARP_ROWS") ? atoi(getenv("HF_WARP_ROWS")) : 0;
-        int rows = 2;  // measured on MI355X, 2160p HDR blend: 1 row 25.9 us, 2 rows 24.3 us, 4 rows 30.2 us
-        if (rows_env == 1 || rows_env == 2 || (rows_env == 4 && g.rs >= 2)) rows = rows_env;
-        const int y_groups = (g.H + rows - 1) / rows, uv_groups = ((g.H >> 1) + rows - 1) / rows;
-        const int wpr = (g.W + 64 * VEC - 1) / (64 * VEC);
-        const int n_blocks = (wpr * (y_groups + uv_groups) + HF_WARP_WAVES - 1) / HF_WARP_WAVES;
-        const dim3 fg(((n_blocks + 7) / 8) * 8);
+                      g.W >= 2 * VEC && group * (int)sizeof(E) >= 4 && VEC % group == 0 && VEC / group <= 4;
+    if (!fast) return false;
+    // rows per thread (must divide the 2^rs rows of a flow cell)
+    static const int rows_env = getenv("HF_WARP_ROWS") ? atoi(getenv("HF_WARP_ROWS")) : 0;
+    int rows = 2;  // measured on MI355X, 2160p HDR blend: 1 row 25.9 us, 2 rows 24.3 us, 4 rows 30.2 us
+    if (ALL_ROWS && (rows_env == 1 || rows_env == 2 || (rows_env == 4 && g.rs >= 2))) rows = rows_env;
+    const int y_groups = (g.H + rows - 1) / rows, uv_groups = ((g.H >> 1) + rows - 1) / rows;
+    const int wpr = (g.W + 64 * VEC - 1) / (64 * VEC);
+    const int n_blocks = (wpr * (y_groups + uv_groups) + HF_WARP_WAVES - 1) / HF_WARP_WAVES;
+    const dim3 fg(((n_blocks + 7) / 8) * 8);
 #define HF_WARP_FAST(G, R)                                                                   \
     do {                                                                                     \
         /* ev0/ev1 (may be null): timestamps of the dispatch itself, like rocprof's kernel trace */ \
-        if (a.mode == 0) hipExtLaunchKernelGGL((warp_fast_kernel<E, G, R, 0>), fg, dim3(64 * HF_WARP_WAVES), 0, stream, ev0, ev1, 0, g, a, y_groups);      \
-        else if (a.mode == 1) hipExtLaunchKernelGGL((warp_fast_kernel<E, G, R, 1>), fg, dim3(64 * HF_WARP_WAVES), 0, stream, ev0, ev1, 0, g, a, y_groups); \
-        else hipExtLaunchKernelGGL((warp_fast_kernel<E, G, R, 2>), fg, dim3(64 * HF_WARP_WAVES), 0, stream, ev0, ev1, 0, g, a, y_groups);                  \
+        if (a.mode == 0) hipExtLaunchKernelGGL((warp_fast_kernel<E, G, R, 0, VB>), fg, dim3(64 * HF_WARP_WAVES), 0, stream, ev0, ev1, 0, g, a, y_groups);      \
+        else if (a.mode == 1) hipExtLaunchKernelGGL((warp_fast_kernel<E, G, R, 1, VB>), fg, dim3(64 * HF_WARP_WAVES), 0, stream, ev0, ev1, 0, g, a, y_groups); \
+        else hipExtLaunchKernelGGL((warp_fast_kernel<E, G, R, 2, VB>), fg, dim3(64 * HF_WARP_WAVES), 0, stream, ev0, ev1, 0, g, a, y_groups);                  \
     } while (0)
 #define HF_WARP_ROWS(R)                                   \
     do {                                                  \
@@ -591,13 +598,24 @@ static void launch_warp_t(const Geom& g, const WarpArgs& a, hipStream_t stream, 
         else if (group == VEC / 2) HF_WARP_FAST(VEC / 2, R); \
         else HF_WARP_FAST(VEC / 4, R);                    \
     } while (0)
-        if (rows == 4) HF_WARP_ROWS(4);
-        else if (rows == 2) HF_WARP_ROWS(2);
-        else HF_WARP_ROWS(1);
+    if (ALL_ROWS && rows == 4) HF_WARP_ROWS(4);
+    else if (ALL_ROWS && rows == 1) HF_WARP_ROWS(1);
+    else HF_WARP_ROWS(2);
 #undef HF_WARP_ROWS
 #undef HF_WARP_FAST
-        return;
-    }
+    return true;
+}
+
+template <typename E>
+static void launch_warp_t(const Geom& g, const WarpArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+    constexpr int VEC = 16 / sizeof(E);  // generic kernel: 16-byte stores
+    // frames up to 1080p: 8 bytes per thread (twice the waves); larger frames: 16 bytes per thread
+    static const int vb_env = getenv("HF_WARP_VB") ? atoi(getenv("HF_WARP_VB")) : 0;
+    const bool small = vb_env ? vb_env == 8 : (size_t)g.W * g.H * sizeof(E) <= (size_t)1920 * 1088;
+    if (small && launch_warp_fast<E, 8, false>(g, a, stream, ev0, ev1)) return;
+    if (launch_warp_fast<E, 16, true>(g, a, stream, ev0, ev1)) return;
+    const bool aligned = (g.out_stride % VEC) == 0 && (((uintptr_t)a.out) & 15) == 0;
+    const dim3 grd((g.W + 64 * VEC - 1) / (64 * VEC), (g.H + (g.H >> 1) + 3) / 4);
     if (aligned) hipExtLaunchKernelGGL((warp_kernel<E, VEC, true>), grd, dim3(256), 0, stream, ev0, ev1, 0, g, a);
     else hipExtLaunchKernelGGL((warp_kernel<E, VEC, false>), grd, dim3(256), 0, stream, ev0, ev1, 0, g, a);
 }
