@@ -204,3 +204,46 @@ def run_batched(frames, want, ts, flags):
             assert (a == b).all()
     for c in calcs:
         c.close()
+
+
+def test_rs4_4320p_matches_oracle(native_lib):
+    """7680x4320 (resolution scalar 4, the largest grid the reference's auto mode produces is still 480x270)."""
+    from hopperrender_amd import synth
+    from hopperrender_amd.calc import OpticalFlowCalcSDR
+    from oracle import oracle
+    H, W, R = 4320, 7680, 16
+    sc = synth.Scene(H, W, False, 404)
+    f = [sc.frame(k) for k in range(3)]
+    g = oracle.make_geom(0, H, W)
+    assert (g.rs, g.lw, g.lh) == (4, 480, 270)
+    off_o, blur_o, tot_o, oob = oracle.calculate_optical_flow(f[1], f[2], g, R)
+    c = OpticalFlowCalcSDR(H, W, search_radius=R)
+    for x in f:
+        c.updateFrame(x)
+    c.calculateOpticalFlow()
+    assert oob == 0
+    assert (c.readOffsets() == off_o).all() and (c.readBlurredFlow(1) == blur_o).all() and c.m_totalFrameDelta == tot_o
+    c.calculateOpticalFlow()
+    c.warpFrames(0.5994, 2)
+    assert (c.downloadFrame() == oracle.warp_frames(f[0], f[1], blur_o, g, 0.5994, 2)).all()
+    c.close()
+
+
+def test_calc_time_statistics_contract(native_lib):
+    """m_ofcCalcTime / Avg / Peak bookkeeping of opticalFlowCalcSDR.cpp:125-138 (CALC_TIME_INTERVAL = 240)."""
+    from hopperrender_amd import synth
+    from hopperrender_amd.calc import OpticalFlowCalcSDR
+    sc = synth.Scene(36, 64, False, 1)
+    c = OpticalFlowCalcSDR(36, 64)
+    for k in range(3):
+        c.updateFrame(sc.frame(k))
+    for i in range(240):
+        c.calculateOpticalFlow()
+    assert c.m_ofcCalcTime > 0 and c.m_ofcPeakCalcTime >= c.m_ofcCalcTime
+    assert c.m_ofcAvgCalcTime == 0.0           # the average is only published after 240 calls
+    c.calculateOpticalFlow()                   # 241st call closes the first interval
+    assert c.m_ofcAvgCalcTime > 0 and c.m_ofcPeakCalcTime == c.m_ofcCalcTime
+    c.warpFrames(0.5, 2)
+    c.downloadFrame()
+    assert c.m_warpCalcTime > 0                # first warp launch -> end of the readback (:36-41)
+    c.close()
