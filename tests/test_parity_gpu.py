@@ -247,3 +247,54 @@ def test_calc_time_statistics_contract(native_lib):
     c.downloadFrame()
     assert c.m_warpCalcTime > 0                # first warp launch -> end of the readback (:36-41)
     c.close()
+
+
+def test_recreate_on_format_change_and_threads(native_lib):
+    """The filter deletes and lazily recreates the calculator on every resolution/stride change
+    (HopperRender.cpp:762-765,856-859): construction/destruction must be cheap, leak-free and contexts must be
+    independent across host threads."""
+    import threading
+    import time
+    from hopperrender_amd import synth
+    from hopperrender_amd.calc import OpticalFlowCalcHDR, OpticalFlowCalcSDR
+    from oracle import oracle
+    sizes = [(0, 180, 320), (1, 360, 640), (0, 338, 600), (1, 180, 320)]
+    t0 = time.perf_counter()
+    for i in range(24):
+        hdr, H, W = sizes[i % len(sizes)]
+        c = (OpticalFlowCalcHDR if hdr else OpticalFlowCalcSDR)(H, W)
+        sc = synth.random_frame(H, W, bool(hdr), seed=i)
+        for _ in range(3):
+            c.updateFrame(sc)
+        c.calculateOpticalFlow()
+        c.warpFrames(0.5, 2)
+        c.downloadFrame()
+        c.close()
+    assert (time.perf_counter() - t0) / 24 < 0.5     # reference: hundreds of ms of OpenCL JIT per construction
+
+    results, errors = {}, []
+
+    def worker(idx, hdr, H, W, seed):
+        try:
+            sc = synth.Scene(H, W, bool(hdr), seed)
+            f = [sc.frame(k) for k in range(3)]
+            c = (OpticalFlowCalcHDR if hdr else OpticalFlowCalcSDR)(H, W, search_radius=10)
+            for _ in range(5):
+                c.m_frameCount = 0
+                for x in f:
+                    c.updateFrame(x)
+                c.calculateOpticalFlow()
+            results[idx] = (c.readOffsets(), c.m_totalFrameDelta, f, hdr, H, W)
+            c.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    th = [threading.Thread(target=worker, args=(i, i % 2, 180, 320, 50 + i)) for i in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    for idx, (off, tot, f, hdr, H, W) in results.items():
+        o, _, t_o, _ = oracle.calculate_optical_flow(f[1], f[2], oracle.make_geom(hdr, H, W), 10)
+        assert (off == o).all() and tot == t_o
