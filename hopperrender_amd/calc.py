@@ -134,6 +134,16 @@ class OpticalFlowCalc:
         outs = (C.c_void_p * n)(*[int(p) for p in out_ptrs[:n]])
         capi.check(self._lib.hf_interpolate_period(self._ctx, C.c_void_p(dev_frame_ptr or 0), n, ts, outs, int(mode)), self._ctx)
 
+    def updateFrameAsync(self, pinned):
+        """H2D on a side stream; `pinned` = PinnedArray (or its .array) that stays valid until sync()."""
+        a = pinned.array if hasattr(pinned, "array") else pinned
+        capi.check(self._lib.hf_update_frame_async(self._ctx, _ptr(a)), self._ctx)
+
+    def downloadFrameAsync(self, pinned):
+        """D2H of the frame just produced on a side stream; read `pinned` only after sync()."""
+        a = pinned.array if hasattr(pinned, "array") else pinned
+        capi.check(self._lib.hf_download_frame_async(self._ctx, _ptr(a)), self._ctx)
+
     def downloadFrameDevice(self, dev_ptr):
         capi.check(self._lib.hf_download_frame_device(self._ctx, C.c_void_p(dev_ptr)), self._ctx)
 

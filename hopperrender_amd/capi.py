@@ -64,6 +64,8 @@ SIGNATURES = {
     "hf_get_stats": (_i, [_vp, C.POINTER(HfStats)]),
     "hf_update_frame_device": (_i, [_vp, _vp]),
     "hf_update_frame_device_ref": (_i, [_vp, _vp]),
+    "hf_update_frame_async": (_i, [_vp, _vp]),
+    "hf_download_frame_async": (_i, [_vp, _vp]),
     "hf_interpolate_period": (_i, [_vp, _vp, _i, C.POINTER(C.c_float), C.POINTER(_vp), _i]),
     "hf_download_frame_device": (_i, [_vp, _vp]),
     "hf_set_output_buffer": (_i, [_vp, _vp]),

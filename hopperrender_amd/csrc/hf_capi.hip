@@ -99,6 +99,17 @@ struct hf_ctx {
     uint32_t* h_total_delta = nullptr;                 // pinned host slot the chain writes m_totalFrameDelta into
     float* d_probe = nullptr;
 
+    // asynchronous host I/O (hf_update_frame_async / hf_download_frame_async): side streams, created lazily
+    static constexpr int kOutRing = 3;
+    hipStream_t io_in = nullptr, io_out = nullptr;
+    hipEvent_t ev_h2d = nullptr, ev_last_launch = nullptr, ev_out_ready = nullptr;
+    hipEvent_t ev_slot_prep[3] = {nullptr, nullptr, nullptr};   // prep of ring_store[i] finished (rotates with the ring)
+    hipEvent_t ev_d2h[kOutRing] = {nullptr, nullptr, nullptr};
+    bool d2h_pending[kOutRing] = {false, false, false};
+    void* out_ring[kOutRing] = {nullptr, nullptr, nullptr};      // [0] == out_frame
+    int out_idx = 0;
+    bool have_last_launch = false;
+
     int ring_phase = 0;   // number of rotations mod 3 (graph key)
     int blur_phase = 0;   // number of swaps mod 2
     bool have_flow = false;
@@ -335,6 +346,7 @@ int leave_warp_stream(hf_ctx* c) {
 int sync_ctx(hf_ctx* c) {
     if (int rc = leave_warp_stream(c)) return rc;
     HF_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->io_in) { HF_HIP(c, hipStreamSynchronize(c->io_in)); HF_HIP(c, hipStreamSynchronize(c->io_out)); }
     collect_spans(c);
     if (c->delta_pending) { c->total_frame_delta = *c->h_total_delta; c->delta_pending = false; }
     finish_flow_timing(c);
@@ -346,6 +358,8 @@ int rotate_after_upload(hf_ctx* c) {
     void* f = c->ring[0];
     void* fs = c->ring_store[0];
     c->ring_store[0] = c->ring_store[1]; c->ring_store[1] = c->ring_store[2]; c->ring_store[2] = fs;
+    hipEvent_t es = c->ev_slot_prep[0];
+    c->ev_slot_prep[0] = c->ev_slot_prep[1]; c->ev_slot_prep[1] = c->ev_slot_prep[2]; c->ev_slot_prep[2] = es;
     uint8_t* y = c->py[0];
     uint16_t* uv = c->puv[0];
     c->ring[0] = c->ring[1]; c->py[0] = c->py[1]; c->puv[0] = c->puv[1];
@@ -353,6 +367,37 @@ int rotate_after_upload(hf_ctx* c) {
     c->ring[2] = f;          c->py[2] = y;        c->puv[2] = uv;
     c->ring_phase = (c->ring_phase + 1) % 3;
     c->p.frame_count++;
+    return HF_OK;
+}
+
+int io_init(hf_ctx* c) {
+    if (c->io_in) return HF_OK;
+    HF_HIP(c, hipStreamCreateWithFlags(&c->io_in, hipStreamNonBlocking));
+    HF_HIP(c, hipStreamCreateWithFlags(&c->io_out, hipStreamNonBlocking));
+    HF_HIP(c, hipEventCreateWithFlags(&c->ev_h2d, hipEventDisableTiming));
+    HF_HIP(c, hipEventCreateWithFlags(&c->ev_last_launch, hipEventDisableTiming));
+    HF_HIP(c, hipEventCreateWithFlags(&c->ev_out_ready, hipEventDisableTiming));
+    for (auto& e : c->ev_slot_prep) HF_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto& e : c->ev_d2h) HF_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    c->out_ring[0] = c->out_frame;
+    for (int i = 1; i < hf_ctx::kOutRing; i++) HF_HIP(c, hipMalloc(&c->out_ring[i], c->out_bytes));
+    return HF_OK;
+}
+
+// Before a warp/copy writes into an output-ring slot: wait for the asynchronous readback that still uses it.
+int guard_output_slot(hf_ctx* c, hipStream_t launch_stream) {
+    if (!c->io_out) return HF_OK;
+    for (int i = 0; i < hf_ctx::kOutRing; i++)
+        if (c->out_target == c->out_ring[i] && c->d2h_pending[i]) {
+            HF_HIP(c, hipStreamWaitEvent(launch_stream, c->ev_d2h[i], 0));
+            c->d2h_pending[i] = false;
+        }
+    return HF_OK;
+}
+int note_launch(hf_ctx* c, hipStream_t launch_stream) {   // remembers "the frames/flow of the ring are being read up to here"
+    if (!c->io_in) return HF_OK;
+    HF_HIP(c, hipEventRecord(c->ev_last_launch, launch_stream));
+    c->have_last_launch = true;
     return HF_OK;
 }
 
@@ -370,6 +415,7 @@ int update_common(hf_ctx* c, const void* src, hipMemcpyKind kind, bool by_refere
     }
     hf::launch_prep_frame(c->g, c->pl, c->ring[0], c->py[0], c->puv[0], c->stream);
     HF_HIP(c, hipGetLastError());
+    if (c->io_in) HF_HIP(c, hipEventRecord(c->ev_slot_prep[0], c->stream));
     rotate_after_upload(c);
     if (!c->async()) return sync_ctx(c);
     return HF_OK;
@@ -547,6 +593,11 @@ void hf_destroy(hf_ctx* c) {
     if (c->h_total_delta) hipHostFree(c->h_total_delta);
     for (auto& sp : c->spans) { hipEventDestroy(sp.b); hipEventDestroy(sp.e); }
     for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
+    if (c->io_in) { hipStreamSynchronize(c->io_in); hipStreamSynchronize(c->io_out); hipStreamDestroy(c->io_in); hipStreamDestroy(c->io_out); }
+    for (int i = 1; i < hf_ctx::kOutRing; i++) if (c->out_ring[i]) hipFree(c->out_ring[i]);
+    for (hipEvent_t e : {c->ev_h2d, c->ev_last_launch, c->ev_out_ready}) if (e) hipEventDestroy(e);
+    for (hipEvent_t e : c->ev_slot_prep) if (e) hipEventDestroy(e);
+    for (hipEvent_t e : c->ev_d2h) if (e) hipEventDestroy(e);
     for (hipEvent_t e : c->ev_flow) if (e) hipEventDestroy(e);
     if (c->ev_chain_done) hipEventDestroy(c->ev_chain_done);
     if (c->ev_warps_done) hipEventDestroy(c->ev_warps_done);
@@ -567,6 +618,50 @@ int hf_update_frame_device(hf_ctx* c, const void* device_frame) {
     HF_CHECK_CTX(c);
     if (!device_frame) return fail(c, HF_ERR_INVALID_ARGUMENT, "hf_update_frame_device: null frame");
     return update_common(c, device_frame, hipMemcpyDeviceToDevice);
+}
+
+int hf_update_frame_async(hf_ctx* c, const void* pinned_host_frame) {
+    HF_CHECK_CTX(c);
+    if (!pinned_host_frame) return fail(c, HF_ERR_INVALID_ARGUMENT, "hf_update_frame_async: null frame");
+    if (int rc = set_device(c)) return rc;
+    if (int rc = io_init(c)) return rc;
+    // the slot about to be overwritten holds the oldest frame: its last readers are the warp/copy launches
+    // issued so far and its own (three updates old) phase-plane build
+    if (c->have_last_launch) HF_HIP(c, hipStreamWaitEvent(c->io_in, c->ev_last_launch, 0));
+    HF_HIP(c, hipStreamWaitEvent(c->io_in, c->ev_slot_prep[0], 0));
+    HF_HIP(c, hipMemcpyAsync(c->ring_store[0], pinned_host_frame, c->in_bytes, hipMemcpyHostToDevice, c->io_in));
+    HF_HIP(c, hipEventRecord(c->ev_h2d, c->io_in));
+    if (int rc = leave_warp_stream(c)) return rc;
+    HF_HIP(c, hipEventRecord(c->ev_upload, c->stream));
+    c->upload_recorded = true;
+    HF_HIP(c, hipStreamWaitEvent(c->stream, c->ev_h2d, 0));
+    c->ring[0] = c->ring_store[0];
+    hf::launch_prep_frame(c->g, c->pl, c->ring[0], c->py[0], c->puv[0], c->stream);
+    HF_HIP(c, hipGetLastError());
+    HF_HIP(c, hipEventRecord(c->ev_slot_prep[0], c->stream));
+    rotate_after_upload(c);
+    return HF_OK;
+}
+
+int hf_download_frame_async(hf_ctx* c, void* pinned_host_out) {
+    HF_CHECK_CTX(c);
+    if (!pinned_host_out) return fail(c, HF_ERR_INVALID_ARGUMENT, "hf_download_frame_async: null buffer");
+    if (int rc = set_device(c)) return rc;
+    if (int rc = io_init(c)) return rc;
+    hipStream_t last = c->on_warp_stream ? c->warp_stream : c->stream;   // where the frame was just produced
+    HF_HIP(c, hipEventRecord(c->ev_out_ready, last));
+    HF_HIP(c, hipStreamWaitEvent(c->io_out, c->ev_out_ready, 0));
+    HF_HIP(c, hipMemcpyAsync(pinned_host_out, c->out_target, c->out_bytes, hipMemcpyDeviceToHost, c->io_out));
+    for (int i = 0; i < hf_ctx::kOutRing; i++)
+        if (c->out_target == c->out_ring[i]) {   // internal output: the next frame goes to the next ring slot
+            HF_HIP(c, hipEventRecord(c->ev_d2h[i], c->io_out));
+            c->d2h_pending[i] = true;
+            c->out_idx = (i + 1) % hf_ctx::kOutRing;
+            c->out_target = c->out_ring[c->out_idx];
+            break;
+        }
+    c->warp_started = false;
+    return HF_OK;
 }
 
 int hf_update_frame_device_ref(hf_ctx* c, const void* device_frame) {
@@ -647,6 +742,7 @@ int hf_warp_frames(hf_ctx* c, float t, int mode) {
     const float scale = c->g.hdr ? 256.0f : 1.0f;  // opticalFlowCalcHDR.cpp:151-152
     if (!c->warp_started) { HF_HIP(c, hipEventRecord(c->ev_warp_start, c->stream)); c->warp_started = true; }
     if (int rc = enter_warp_stream(c)) return rc;
+    if (int rc = guard_output_slot(c, c->warp_stream)) return rc;
     // frames N-2 / N-1 and the PREVIOUS flow (:154-156)
     // profiled launches carry start/stop events of the dispatch itself (hipExtLaunchKernel), i.e. the kernel's
     // execution time as rocprof reports it, not the time the launch spent queued behind other streams
@@ -655,6 +751,7 @@ int hf_warp_frames(hf_ctx* c, float t, int mode) {
                     c->p.black_level * scale, c->p.white_level * scale, c->warp_stream,
                     span >= 0 ? c->spans[span].b : nullptr, span >= 0 ? c->spans[span].e : nullptr);
     if (c->on_warp_stream && !c->in_period) HF_HIP(c, hipEventRecord(c->ev_warps_done, c->warp_stream));
+    if (int rc = note_launch(c, c->warp_stream)) return rc;
     HF_HIP(c, hipGetLastError());
     return HF_OK;
 }
@@ -666,11 +763,12 @@ int hf_copy_frame(hf_ctx* c) {
     const int idx = c->p.frame_count >= 3 ? 0 : c->p.frame_count >= 2 ? 1 : 2;  // opticalFlowCalcSDR.cpp:173
     if (int rc = leave_warp_stream(c)) return rc;
     if (!c->warp_started) { HF_HIP(c, hipEventRecord(c->ev_warp_start, c->stream)); c->warp_started = true; }
+    if (int rc = guard_output_slot(c, c->stream)) return rc;
     const int span = span_begin(c, 1);
     hf::launch_copy(c->g, c->ring[idx], c->out_target, c->p.black_level * scale, c->p.white_level * scale, c->stream);
     span_end(c, span);
     HF_HIP(c, hipGetLastError());
-    return HF_OK;
+    return note_launch(c, c->stream);
 }
 
 int hf_interpolate_period(hf_ctx* c, const void* device_frame, int n_out, const float* t, void* const* device_out, int mode) {

@@ -142,6 +142,13 @@ int hf_get_stats(hf_ctx* ctx, hf_stats* out);
 /* ---- device-resident variants (batch driver / benchmarks: inputs and outputs stay in HBM) ---- */
 /* Same as hf_update_frame but the source is a device pointer on ctx's device (device-to-device). */
 int hf_update_frame_device(hf_ctx* ctx, const void* device_frame);
+/* Asynchronous host I/O on side streams of the context (page-locked buffers, e.g. hf_host_malloc_pinned): the
+ * upload of frame N+1 and the readback of finished output frames overlap the flow chain and the warps; nothing
+ * blocks, hf_sync() waits for everything.  The host buffers must stay valid (and, for the readback, unread) until
+ * hf_sync().  Output frames rotate through an internal ring of three device buffers so that the next warp does
+ * not wait for the previous readback. */
+int hf_update_frame_async(hf_ctx* ctx, const void* pinned_host_frame);
+int hf_download_frame_async(hf_ctx* ctx, void* pinned_host_out);
 /* Zero-copy variant: the ring keeps a REFERENCE to device_frame (e.g. a decoder surface).  The caller must
  * leave the frame untouched until three further frames have been submitted (it stays in the 3-frame ring
  * as frame N, N-1 and N-2, opticalFlowCalcSDR.cpp:22-28). */

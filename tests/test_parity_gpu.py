@@ -298,3 +298,46 @@ def test_recreate_on_format_change_and_threads(native_lib):
     for idx, (off, tot, f, hdr, H, W) in results.items():
         o, _, t_o, _ = oracle.calculate_optical_flow(f[1], f[2], oracle.make_geom(hdr, H, W), 10)
         assert (off == o).all() and tot == t_o
+
+
+def test_async_host_io_pipeline_matches_blocking(native_lib):
+    """hf_update_frame_async / hf_download_frame_async (pinned buffers, side streams, output ring) against the
+    blocking reference-style sequence, single- and dual-stream contexts."""
+    from hopperrender_amd import capi, synth
+    from hopperrender_amd.calc import OpticalFlowCalcHDR, PinnedArray
+    H, W, n = 180, 320, 7
+    sc = synth.Scene(H, W, True, 77)
+    frames = [sc.frame(k) for k in range(n)]
+    ts = [0.0, 0.1998, 0.3996, 0.5994, 0.7992]
+    c = OpticalFlowCalcHDR(H, W, search_radius=9)
+    want = []
+    for k, f in enumerate(frames):
+        c.updateFrame(f)
+        if k >= 2:
+            c.calculateOpticalFlow()
+            for t in ts:
+                c.warpFrames(t, 2)
+                want.append(c.downloadFrame().copy())
+    c.close()
+    for flags in (capi.HF_FLAG_ASYNC, capi.HF_FLAG_ASYNC | capi.HF_FLAG_DUAL_STREAM):
+        c = OpticalFlowCalcHDR(H, W, search_radius=9, flags=flags)
+        pin_in = [PinnedArray(f.size, np.uint16) for f in frames]
+        for p, f in zip(pin_in, frames):
+            p.array[:] = f
+        n_el = c.output_frame_bytes // 2
+        pin_out = [PinnedArray(n_el, np.uint16) for _ in range(len(want))]
+        o = 0
+        for k in range(n):
+            c.updateFrameAsync(pin_in[k])
+            if k >= 2:
+                c.calculateOpticalFlow()
+                for t in ts:
+                    c.warpFrames(t, 2)
+                    c.downloadFrameAsync(pin_out[o])
+                    o += 1
+        c.sync()
+        for i, w in enumerate(want):
+            assert (pin_out[i].array == w).all(), f"flags {flags} output {i}"
+        c.close()
+        for p in pin_in + pin_out:
+            p.free()

@@ -34,4 +34,23 @@ for pinned in (False, True):
     dt = time.perf_counter() - t0
     res["pinned" if pinned else "pageable"] = {"frames_per_s": round(nout / dt, 1), "GB_per_s_d2h": round(nout * c.output_frame_bytes / dt / 1e9, 2)}
     c.close()
+# asynchronous pipeline: uploads/readbacks on side streams, pinned buffers, nothing blocks until the end
+from hopperrender_amd import capi
+c = cls(a.H, a.W, 0, 0, 8, 6, 0.0, 255.0, 270, search_radius=16, flags=capi.HF_FLAG_ASYNC | capi.HF_FLAG_DUAL_STREAM)
+n_el = c.output_frame_bytes // np.dtype(c.dtype).itemsize
+ins = [PinnedArray(f.size, c.dtype) for f in frames]
+for p, f in zip(ins, frames): p.array[:] = f
+outs = [PinnedArray(n_el, c.dtype) for _ in range(8)]
+plan = BlendSchedule(SOURCE_24, a.target).plan(a.n + 4)
+for k in range(3): c.updateFrameAsync(ins[k])
+c.calculateOpticalFlow(); c.sync()
+t0 = time.perf_counter(); nout = 0
+for i in range(a.n):
+    c.updateFrameAsync(ins[i % 4]); c.calculateOpticalFlow()
+    for t in plan[i + 3]:
+        c.warpFrames(t, 2); c.downloadFrameAsync(outs[nout % 8]); nout += 1
+    if i % 2 == 1: c.sync()     # bound the number of in-flight host buffers (8 outputs here)
+c.sync(); dt = time.perf_counter() - t0
+res["async_pinned_side_streams"] = {"frames_per_s": round(nout / dt, 1), "GB_per_s_d2h": round(nout * c.output_frame_bytes / dt / 1e9, 2)}
+c.close()
 print(json.dumps(res))
