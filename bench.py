@@ -51,6 +51,7 @@ def parse_args():
                     help="one HIP stream per pair stream (default: two -- the warps of a period overlap its flow chain)")
     ap.add_argument("--priority-streams", action="store_true",
                     help="per pair stream: flow chain on a high-priority stream, warps on a low-priority stream")
+    ap.add_argument("--no-fused-warp", action="store_true", help="one warp launch per output frame instead of one per source period")
     ap.add_argument("--shared-warp-stream", action="store_true",
                     help="issue the warp kernels of all pair streams on one shared stream per GPU (measured slower: 26.5k vs 33k frames/s)")
     ap.add_argument("--copy-in", action="store_true",
@@ -163,6 +164,8 @@ def main():
             c.updateFrameDeviceRef(ptr)
 
     flags = capi.HF_FLAG_ASYNC | (0 if a.no_profile else capi.HF_FLAG_PROFILE)
+    if a.no_fused_warp:
+        flags |= capi.HF_FLAG_NO_FUSED_WARP
     if a.shared_warp_stream:
         flags |= capi.HF_FLAG_SHARED_WARP_STREAM
     if a.priority_streams:
@@ -194,8 +197,7 @@ def main():
             ts = plans[s][i]
             if a.diagnose == "no-flow":
                 c.updateFrameDeviceRef(pools[s][(s + 3 + i) % a.pool].ptr)
-                for j, t in enumerate(ts):
-                    c.setOutputBuffer(out_ptrs[s][j]); c.warpFrames(t, 2)
+                c.interpolateOnly(ts, out_ptrs[s], 2)
             elif a.diagnose == "no-warp":
                 c.interpolatePeriod(pools[s][(s + 3 + i) % a.pool].ptr, [], [], 2)
             elif a.copy_in:
@@ -239,7 +241,7 @@ def main():
         dist.all_reduce(ft, op=dist.ReduceOp.SUM)
     elapsed_max, frames_total = float(tt.item()), float(ft.item())
 
-    prof = {"warp_launches": 0, "warp_ms": 0.0, "flow_chains": 0, "flow_ms": 0.0}
+    prof = {"warp_launches": 0, "warp_ms": 0.0, "flow_chains": 0, "flow_ms": 0.0, "warp_frames": 0}
     if not a.no_profile:
         for c in calcs:
             p = c.profile()
@@ -258,12 +260,10 @@ def main():
             c.updateFrameDeviceRef(pools[0][i % a.pool].ptr)
             c.calculateOpticalFlow()
             c.sync()                                   # chain alone ...
-            for j, t in enumerate(plans[0][i % len(plans[0])]):
-                c.setOutputBuffer(out_ptrs[0][j])
-                c.warpFrames(t, 2)
-            c.sync()                                   # ... then the warps alone
+            c.interpolateOnly(plans[0][i % len(plans[0])], out_ptrs[0], 2)
+            c.sync()                                   # ... then the warps of the period alone
         p = c.profile()
-        isolated = {"warp_us": 1e3 * p["warp_ms"] / max(p["warp_launches"], 1),
+        isolated = {"warp_us": 1e3 * p["warp_ms"] / max(p["warp_launches"], 1), "fpl": p["warp_frames"] / max(p["warp_launches"], 1),
                     "flow_chain_us": 1e3 * p["flow_ms"] / max(p["flow_chains"], 1)}
 
     if rank == 0:
@@ -275,7 +275,9 @@ def main():
         roof = None
         if prof["warp_launches"]:
             avg_ms = prof["warp_ms"] / prof["warp_launches"]
-            achieved = b_out / (avg_ms * 1e-3) / 1e9
+            fpl = prof["warp_frames"] / prof["warp_launches"]     # output frames per launch (a period is one fused launch)
+            b_launch = b_out * fpl                                 # per-unit bytes x units one launch processes
+            achieved = b_launch / (avg_ms * 1e-3) / 1e9
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
             if os.path.exists(tpath):
@@ -285,13 +287,14 @@ def main():
                     traffic = None
             roof = {"bound": "hbm", "kernel": "warp_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "algorithmic_bytes_per_launch": b_out, "avg_launch_us": round(avg_ms * 1e3, 2),
+                    "algorithmic_bytes_per_unit": b_out, "units_per_launch": round(fpl, 3),
+                    "algorithmic_bytes_per_launch": int(b_launch), "avg_launch_us": round(avg_ms * 1e3, 2),
                     "launches": prof["warp_launches"], "sampled_every": a.profile_every,
                     "frac_of_measured_copy_bw_6290": round(achieved / 6290.0, 4),
                     "note": "in the timed region (HIP events on the launching stream); pair streams overlap, so a launch "
                             "shares the GPU with up to pair_streams_per_gpu-1 others"}
             if isolated:
-                iso = b_out / (isolated["warp_us"] * 1e-6) / 1e9
+                iso = b_out * isolated["fpl"] / (isolated["warp_us"] * 1e-6) / 1e9
                 roof["isolated"] = {"avg_launch_us": round(isolated["warp_us"], 2), "achieved": round(iso, 1),
                                     "frac": round(iso / HBM_PEAK_GBS, 4), "frac_of_measured_copy_bw_6290": round(iso / 6290.0, 4),
                                     "note": "same kernel alone on the GPU (one stream), measured after the timed region"}

@@ -134,6 +134,13 @@ class OpticalFlowCalc:
         outs = (C.c_void_p * n)(*[int(p) for p in out_ptrs[:n]])
         capi.check(self._lib.hf_interpolate_period(self._ctx, C.c_void_p(dev_frame_ptr or 0), n, ts, outs, int(mode)), self._ctx)
 
+    def interpolateOnly(self, scalars, out_ptrs, mode=BlendedFrame):
+        """The warps of one period (one fused launch when eligible), without updateFrame / calculateOpticalFlow."""
+        n = len(scalars)
+        ts = (C.c_float * n)(*[float(x) for x in scalars])
+        outs = (C.c_void_p * n)(*[int(p) for p in out_ptrs[:n]])
+        capi.check(self._lib.hf_interpolate_period_ex(self._ctx, None, n, ts, outs, int(mode), 0), self._ctx)
+
     def updateFrameAsync(self, pinned):
         """H2D on a side stream; `pinned` = PinnedArray (or its .array) that stays valid until sync()."""
         a = pinned.array if hasattr(pinned, "array") else pinned

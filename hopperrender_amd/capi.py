@@ -15,6 +15,7 @@ HF_FLAG_NO_LAZY_ARGMIN = 0x8
 HF_FLAG_SHARED_WARP_STREAM = 0x10
 HF_FLAG_PRIORITY_STREAMS = 0x20
 HF_FLAG_DUAL_STREAM = 0x40
+HF_FLAG_NO_FUSED_WARP = 0x80
 
 (HF_OK, HF_ERR_INVALID_ARGUMENT, HF_ERR_NO_DEVICE, HF_ERR_OUT_OF_MEMORY, HF_ERR_HIP, HF_ERR_STATE) = (0, -1, -2, -3, -4, -5)
 
@@ -44,7 +45,7 @@ class HfStats(C.Structure):
 
 class HfProfile(C.Structure):
     _fields_ = [("warp_launches", C.c_uint64), ("warp_ms", C.c_double), ("copy_launches", C.c_uint64),
-                ("copy_ms", C.c_double), ("flow_chains", C.c_uint64), ("flow_ms", C.c_double)]
+                ("copy_ms", C.c_double), ("flow_chains", C.c_uint64), ("flow_ms", C.c_double), ("warp_frames", C.c_uint64)]
 
 
 # name -> (restype, argtypes); must list every symbol include/hopperflow.h declares (tests check this)
@@ -67,6 +68,7 @@ SIGNATURES = {
     "hf_update_frame_async": (_i, [_vp, _vp]),
     "hf_download_frame_async": (_i, [_vp, _vp]),
     "hf_interpolate_period": (_i, [_vp, _vp, _i, C.POINTER(C.c_float), C.POINTER(_vp), _i]),
+    "hf_interpolate_period_ex": (_i, [_vp, _vp, _i, C.POINTER(C.c_float), C.POINTER(_vp), _i, _i]),
     "hf_download_frame_device": (_i, [_vp, _vp]),
     "hf_set_output_buffer": (_i, [_vp, _vp]),
     "hf_sync": (_i, [_vp]),

@@ -124,7 +124,7 @@ struct hf_ctx {
     std::map<std::tuple<int, int, int, int, int>, hipGraphExec_t> graphs;
 
     // HF_FLAG_PROFILE: event pairs around warp / copy / flow-chain launches
-    struct Span { hipEvent_t b, e; int kind; hipStream_t stream; };
+    struct Span { hipEvent_t b, e; int kind; hipStream_t stream; int frames = 1; };
     std::vector<hipEvent_t> ev_pool;
     std::vector<Span> spans;
     hf_profile prof{};
@@ -284,7 +284,7 @@ hipEvent_t pool_event(hf_ctx* c) {
 int span_begin(hf_ctx* c, int kind, hipStream_t stream = nullptr) {
     if (!c->profiling()) return -1;
     if ((c->prof_seen[kind]++ % (unsigned)c->prof_every[kind]) != 0) return -1;
-    hf_ctx::Span s{pool_event(c), pool_event(c), kind, nullptr};
+    hf_ctx::Span s{pool_event(c), pool_event(c), kind, nullptr, 1};
     if (!s.b || !s.e) return -1;
     s.stream = stream ? stream : c->stream;
     hipEventRecord(s.b, s.stream);
@@ -295,7 +295,7 @@ int span_begin(hf_ctx* c, int kind, hipStream_t stream = nullptr) {
 int span_open(hf_ctx* c, int kind) {
     if (!c->profiling()) return -1;
     if ((c->prof_seen[kind]++ % (unsigned)c->prof_every[kind]) != 0) return -1;
-    hf_ctx::Span s{pool_event(c), pool_event(c), kind, nullptr};
+    hf_ctx::Span s{pool_event(c), pool_event(c), kind, nullptr, 1};
     if (!s.b || !s.e) return -1;
     c->spans.push_back(s);
     return (int)c->spans.size() - 1;
@@ -307,7 +307,7 @@ void collect_spans(hf_ctx* c) {  // stream must be idle
     for (auto& s : c->spans) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, s.b, s.e) == hipSuccess) {
-            if (s.kind == 0) { c->prof.warp_launches++; c->prof.warp_ms += ms; }
+            if (s.kind == 0) { c->prof.warp_launches++; c->prof.warp_ms += ms; c->prof.warp_frames += (uint64_t)s.frames; }
             else if (s.kind == 1) { c->prof.copy_launches++; c->prof.copy_ms += ms; }
             else { c->prof.flow_chains++; c->prof.flow_ms += ms; }
         }
@@ -772,20 +772,60 @@ int hf_copy_frame(hf_ctx* c) {
 }
 
 int hf_interpolate_period(hf_ctx* c, const void* device_frame, int n_out, const float* t, void* const* device_out, int mode) {
+    return hf_interpolate_period_ex(c, device_frame, n_out, t, device_out, mode, 1);
+}
+
+int hf_interpolate_period_ex(hf_ctx* c, const void* device_frame, int n_out, const float* t, void* const* device_out, int mode,
+                             int update_and_flow) {
     HF_CHECK_CTX(c);
     if (n_out < 0 || (n_out > 0 && (!t || !device_out))) return fail(c, HF_ERR_INVALID_ARGUMENT, "hf_interpolate_period: bad argument");
-    if (device_frame) if (int rc = hf_update_frame_device_ref(c, device_frame)) return rc;
-    if (int rc = hf_calculate_optical_flow(c)) return rc;
+    if (update_and_flow) {
+        if (device_frame) if (int rc = hf_update_frame_device_ref(c, device_frame)) return rc;
+        if (int rc = hf_calculate_optical_flow(c)) return rc;
+    }
+    if (int rc = set_device(c)) return rc;
+    if (mode < 0 || mode > 6) return fail(c, HF_ERR_INVALID_ARGUMENT, "warpFrames: frame output mode %d outside [0, 6]", mode);
+    for (int i = 0; i < n_out; i++)
+        if (t[i] > 1.0f) return fail(c, HF_ERR_INVALID_ARGUMENT, "Error in function warpFrames: blending scalar is greater than 1.0");
+    // All outputs of the period in one launch when the fast warp kernel applies: the flow is looked up once and
+    // the source rows of the later outputs come from L1/L2 instead of HBM (2F + nF bytes instead of n * 3F).
+    const bool fuse = n_out >= 2 && !(c->cfg.flags & HF_FLAG_NO_FUSED_WARP);
+    int done = 0;
+    if (fuse) {
+        const float scale = c->g.hdr ? 256.0f : 1.0f;
+        if (int rc = enter_warp_stream(c)) return rc;
+        while (done < n_out) {
+            const int n = n_out - done < hf::kMaxWarpOutputs ? n_out - done : hf::kMaxWarpOutputs;
+            void* outs[hf::kMaxWarpOutputs];
+            for (int i = 0; i < n; i++) outs[i] = device_out[done + i] ? device_out[done + i] : c->out_frame;
+            if (!c->warp_started) { HF_HIP(c, hipEventRecord(c->ev_warp_start, c->stream)); c->warp_started = true; }
+            const int span = span_open(c, 0);
+            const bool ok = hf::launch_warp_period(c->g, c->ring[0], c->ring[1], c->blurred[0], c->blurred_xy[0], n, outs, t + done, mode,
+                                                   c->p.black_level * scale, c->p.white_level * scale, c->warp_stream,
+                                                   span >= 0 ? c->spans[span].b : nullptr, span >= 0 ? c->spans[span].e : nullptr);
+            if (!ok) {   // shape not eligible: drop the unused span and fall back to one launch per output
+                if (span >= 0) { c->ev_pool.push_back(c->spans[span].b); c->ev_pool.push_back(c->spans[span].e); c->spans.pop_back(); }
+                break;
+            }
+            if (span >= 0) c->spans[span].frames = n;
+            HF_HIP(c, hipGetLastError());
+            done += n;
+        }
+        if (done > 0) {
+            if (c->on_warp_stream) HF_HIP(c, hipEventRecord(c->ev_warps_done, c->warp_stream));
+            if (int rc = note_launch(c, c->warp_stream)) return rc;
+        }
+    }
     void* const saved = c->out_target;
     c->in_period = true;
     int rc = HF_OK;
-    for (int i = 0; i < n_out && rc == HF_OK; i++) {
+    for (int i = done; i < n_out && rc == HF_OK; i++) {
         c->out_target = device_out[i] ? device_out[i] : c->out_frame;
         rc = hf_warp_frames(c, t[i], mode);
     }
     c->in_period = false;
     c->out_target = saved;
-    if (rc == HF_OK && c->on_warp_stream) HF_HIP(c, hipEventRecord(c->ev_warps_done, c->warp_stream));
+    if (rc == HF_OK && done < n_out && c->on_warp_stream) HF_HIP(c, hipEventRecord(c->ev_warps_done, c->warp_stream));
     return rc;
 }
 

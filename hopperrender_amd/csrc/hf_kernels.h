@@ -84,6 +84,12 @@ void launch_expand_offsets(const Geom& g, const FlowLevel& last, int16_t* out, h
 void launch_blur_flow(const Geom& g, const FlowLevel& last, int16_t* blurred, uint32_t* packed,
                       int radius, uint32_t* zero, int zero_count, hipStream_t stream);
 void launch_pack_flow(const Geom& g, const int16_t* flow, uint32_t* packed, hipStream_t stream);
+constexpr int kMaxWarpOutputs = 6;   // outputs of one source period at 24 -> 120 fps (HopperRender.cpp:944-948)
+// All outputs of one source period in ONE launch (fast path only: modes 0-2 etc.); returns false when the shape
+// does not qualify and the caller must fall back to one launch_warp per output.
+bool launch_warp_period(const Geom& g, const void* frame12, const void* frame21, const int16_t* flow, const uint32_t* flow_xy,
+                        int n_out, void* const* outs, const float* ts, int mode, float black, float white, hipStream_t stream,
+                        hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 // warpFrameKernel, both planes in one launch.  black/white already scaled for HDR.
 void launch_warp(const Geom& g, const void* frame12, const void* frame21, const int16_t* flow, const uint32_t* flow_xy,
                  void* out, float t, int mode, float black, float white, hipStream_t stream,

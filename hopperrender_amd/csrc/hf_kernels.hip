@@ -194,6 +194,11 @@ struct WarpArgs {
     float s12, s21;        // frameScalar12 = t, frameScalar21 = 1 - t (opticalFlowCalcSDR.cpp:149-150)
     int mode;
     float black, white;
+    // fast kernel: the outputs of one source period produced in ONE pass (flow looked up once, source rows
+    // re-read from L1/L2 instead of HBM).  n_out == 1 for a plain warpFrames call.
+    int n_out;
+    float s12v[kMaxWarpOutputs], s21v[kMaxWarpOutputs];
+    void* outv[kMaxWarpOutputs];
 };
 
 // One output element of warpFrameKernel (all modes).
@@ -319,10 +324,14 @@ __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a,
     const int dim_y = CZ ? (H >> 1) : H;
     const int nrows = min(ROWS, dim_y - cy0);
     const Levels lv = make_levels(a.black, a.white);
-    E* __restrict__ out = (E*)a.out + (size_t)CZ * H * So + (size_t)cy0 * So + cx0;
     if (cx0 + VEC > W) {  // ragged right edge
-        for (int r = 0; r < nrows; r++)
-            for (int i = 0; i < VEC && cx0 + i < W; i++) out[(size_t)r * So + i] = (E)warp_element<E>(g, a, lv, CZ, cx0 + i, cy0 + r);
+        for (int ti = 0; ti < a.n_out; ti++) {
+            WarpArgs at = a;
+            at.s12 = a.s12v[ti]; at.s21 = a.s21v[ti]; at.out = a.outv[ti];
+            E* __restrict__ o = (E*)at.out + (size_t)CZ * H * So + (size_t)cy0 * So + cx0;
+            for (int r = 0; r < nrows; r++)
+                for (int i = 0; i < VEC && cx0 + i < W; i++) o[(size_t)r * So + i] = (E)warp_element<E>(g, at, lv, CZ, cx0 + i, cy0 + r);
+        }
         return;
     }
     const E* __restrict__ A = (const E*)a.frame12 + (size_t)CZ * H * Si;
@@ -330,25 +339,35 @@ __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a,
     const int ly = CZ ? ((cy0 >> rs) << 1) : (cy0 >> rs);    // same for all ROWS rows
     constexpr bool need_a = MODE != 1, need_b = MODE != 0;
 
-    int xa[NG], xb[NG], dya[NG], dyb[NG];
+    // flow of the thread's cells: looked up once, shared by every output of the period
+    int ox12[NG], oy12[NG], ox21[NG], oy21[NG];
 #pragma unroll
     for (int k = 0; k < NG; k++) {
         const int cx = cx0 + k * GROUP;
         const int lx = CZ ? ((cx >> rs) & ~1) : (cx >> rs);
         const uint32_t f12 = a.flow_xy[(size_t)ly * lw + lx];
-        const int ox12 = (int)(int16_t)(f12 & 0xFFFFu), oy12 = (int)(int16_t)(f12 >> 16);
-        const int py = clampi(ly - (oy12 >> rs), 0, lh - 1);
-        const int px = clampi(lx - (ox12 >> rs), 0, lw - 1);
+        ox12[k] = (int)(int16_t)(f12 & 0xFFFFu); oy12[k] = (int)(int16_t)(f12 >> 16);
+        const int py = clampi(ly - (oy12[k] >> rs), 0, lh - 1);
+        const int px = clampi(lx - (ox12[k] >> rs), 0, lw - 1);
         const uint32_t f21 = a.flow_xy[(size_t)py * lw + px];
-        const int ox21 = (int)(int16_t)(f21 & 0xFFFFu), oy21 = (int)(int16_t)(f21 >> 16);
-        xa[k] = cx + (int)roundf((float)ox12 * a.s12);
-        xb[k] = cx - (int)roundf((float)ox21 * a.s21);
+        ox21[k] = (int)(int16_t)(f21 & 0xFFFFu); oy21[k] = (int)(int16_t)(f21 >> 16);
+    }
+
+  for (int ti = 0; ti < a.n_out; ti++) {
+    const float s12t = a.s12v[ti], s21t = a.s21v[ti];
+    E* __restrict__ out = (E*)a.outv[ti] + (size_t)CZ * H * So + (size_t)cy0 * So + cx0;
+    int xa[NG], xb[NG], dya[NG], dyb[NG];
+#pragma unroll
+    for (int k = 0; k < NG; k++) {
+        const int cx = cx0 + k * GROUP;
+        xa[k] = cx + (int)roundf((float)ox12[k] * s12t);
+        xb[k] = cx - (int)roundf((float)ox21[k] * s21t);
         if (CZ) {
-            dya[k] = (int)roundf((float)oy12 * a.s12 * 0.5f);
-            dyb[k] = -(int)roundf((float)oy21 * a.s21 * 0.5f);
+            dya[k] = (int)roundf((float)oy12[k] * s12t * 0.5f);
+            dyb[k] = -(int)roundf((float)oy21[k] * s21t * 0.5f);
         } else {
-            dya[k] = (int)roundf((float)oy12 * a.s12);
-            dyb[k] = -(int)roundf((float)oy21 * a.s21);
+            dya[k] = (int)roundf((float)oy12[k] * s12t);
+            dyb[k] = -(int)roundf((float)oy21[k] * s21t);
         }
     }
 
@@ -442,7 +461,7 @@ __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a,
     }
 #pragma unroll
     for (int r = 0; r < ROWS; r++) {
-        if (r >= nrows) break;
+        if (r >= nrows) continue;
         __attribute__((aligned(VB))) E v[VEC];
 #pragma unroll
         for (int k = 0; k < NG; k++) {
@@ -462,7 +481,7 @@ __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a,
                 for (int i = 0; i < GROUP; i += 2) {
                     const float2v fa = {(float)ra[r][k].v[i], (float)ra[r][k].v[i + 1]};
                     const float2v fb = {(float)rb[r][k].v[i], (float)rb[r][k].v[i + 1]};
-                    const float2v s12 = {a.s12, a.s12}, s21 = {a.s21, a.s21};
+                    const float2v s12 = {s12t, s12t}, s21 = {s21t, s21t};
                     float2v bl = __builtin_elementwise_fma(fa, s21, fb * s12);          // :176-177 as compiled on gfx950
                     bl.x = __builtin_truncf(bl.x);
                     bl.y = __builtin_truncf(bl.y);
@@ -481,6 +500,7 @@ __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a,
         }
         *(SV*)(out + (size_t)r * So) = *(const SV*)v;
     }
+  }   // outputs of the period
 }
 
 // Thread = VEC consecutive elements x ROWS consecutive rows that share one flow-cell row (ROWS
@@ -625,8 +645,30 @@ void launch_warp(const Geom& g, const void* frame12, const void* frame21, const 
     WarpArgs a;
     a.frame12 = frame12; a.frame21 = frame21; a.flow = flow; a.flow_xy = flow_xy; a.out = out;
     a.s12 = t; a.s21 = 1.0f - t; a.mode = mode; a.black = black; a.white = white;
+    a.n_out = 1; a.s12v[0] = a.s12; a.s21v[0] = a.s21; a.outv[0] = out;
     if (g.hdr) launch_warp_t<uint16_t>(g, a, stream, ev0, ev1);
     else launch_warp_t<uint8_t>(g, a, stream, ev0, ev1);
+}
+
+bool launch_warp_period(const Geom& g, const void* frame12, const void* frame21, const int16_t* flow, const uint32_t* flow_xy,
+                        int n_out, void* const* outs, const float* ts, int mode, float black, float white, hipStream_t stream,
+                        hipEvent_t ev0, hipEvent_t ev1) {
+    if (n_out < 1 || n_out > kMaxWarpOutputs) return false;
+    WarpArgs a;
+    a.frame12 = frame12; a.frame21 = frame21; a.flow = flow; a.flow_xy = flow_xy; a.out = outs[0];
+    a.mode = mode; a.black = black; a.white = white;
+    a.n_out = n_out;
+    // the eligibility test looks at (s12, out): every output must pass it
+    for (int i = 0; i < n_out; i++) {
+        a.s12v[i] = ts[i]; a.s21v[i] = 1.0f - ts[i]; a.outv[i] = outs[i];
+        if (!(ts[i] >= 0.0f && ts[i] <= 1.0f) || (((uintptr_t)outs[i]) & 15)) return false;
+    }
+    a.s12 = a.s12v[0]; a.s21 = a.s21v[0];
+    const size_t el = g.hdr ? 2 : 1;
+    static const int vb_env = getenv("HF_WARP_VB") ? atoi(getenv("HF_WARP_VB")) : 0;
+    const bool small = vb_env ? vb_env == 8 : (size_t)g.W * g.H * el <= (size_t)1920 * 1088;
+    if (g.hdr) return (small && launch_warp_fast<uint16_t, 8, false>(g, a, stream, ev0, ev1)) || launch_warp_fast<uint16_t, 16, true>(g, a, stream, ev0, ev1);
+    return (small && launch_warp_fast<uint8_t, 8, false>(g, a, stream, ev0, ev1)) || launch_warp_fast<uint8_t, 16, true>(g, a, stream, ev0, ev1);
 }
 
 template <typename E>

@@ -64,6 +64,7 @@ typedef enum hf_output_mode {
                                     PREVIOUS flow and frames N-2/N-1 (opticalFlowCalcSDR.cpp:154-156) while
                                     calculateOpticalFlow produces the next flow from N-1/N into the other buffer, so the two
                                     overlap inside one context; events keep every other ordering intact */
+#define HF_FLAG_NO_FUSED_WARP 0x80 /* hf_interpolate_period: one warp launch per output frame (debug / A-B timing) */
 #define HF_FLAG_PROFILE 0x4  /* bracket every warp/copy launch and every flow chain with HIP events on ctx's
                                 stream; totals are read with hf_get_profile() (bench.py's live roofline figure) */
 
@@ -157,6 +158,9 @@ int hf_update_frame_device_ref(hf_ctx* ctx, const void* device_frame);
  * non-NULL, hf_calculate_optical_flow(), then for i < n_out: hf_warp_frames(t[i], mode) written to
  * device_out[i].  Same results as the individual calls; only the host overhead differs. */
 int hf_interpolate_period(hf_ctx* ctx, const void* device_frame, int n_out, const float* t, void* const* device_out, int mode);
+/* update_and_flow = 0: only the warps of the period (no updateFrame, no calculateOpticalFlow). */
+int hf_interpolate_period_ex(hf_ctx* ctx, const void* device_frame, int n_out, const float* t, void* const* device_out, int mode,
+                             int update_and_flow);
 /* Device-to-device copy of the output frame into caller-owned device memory. */
 int hf_download_frame_device(hf_ctx* ctx, void* device_out);
 /* Redirect warp/copy output into caller-owned device memory (NULL restores the internal buffer). */
@@ -187,6 +191,7 @@ typedef struct hf_profile {
     double copy_ms;
     uint64_t flow_chains;     /* calculateOpticalFlow chains (16 steps + blur) */
     double flow_ms;           /* summed device time first kernel start -> blur end */
+    uint64_t warp_frames;     /* output frames produced by the counted warp launches (hf_interpolate_period fuses a period) */
 } hf_profile;
 int hf_get_profile(hf_ctx* ctx, hf_profile* out); /* synchronises ctx */
 /* Bracket only every n-th warp/copy launch and every m-th flow chain (default 1/1): event records perturb

@@ -178,6 +178,7 @@ def test_batched_async_contexts_match_blocking_path(native_lib):
         c.close()
     run_batched(frames, want, ts, capi.HF_FLAG_ASYNC | capi.HF_FLAG_SHARED_WARP_STREAM)
     run_batched(frames, want, ts, capi.HF_FLAG_ASYNC | capi.HF_FLAG_DUAL_STREAM)
+    run_batched(frames, want, ts, capi.HF_FLAG_ASYNC | capi.HF_FLAG_NO_FUSED_WARP)
 
 
 def run_batched(frames, want, ts, flags):
