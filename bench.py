@@ -45,10 +45,11 @@ def parse_args():
     ap.add_argument("--radius", type=int, default=16)
     ap.add_argument("--neighbor", type=int, default=6)
     ap.add_argument("--blur-radius", type=int, default=4)
-    ap.add_argument("--streams", type=int, default=4, help="independent frame-pair streams per GPU")
+    ap.add_argument("--streams", type=int, default=6, help="independent frame-pair streams per GPU")
     ap.add_argument("--pool", type=int, default=6, help="distinct synthetic source frames resident in HBM, per pair stream")
-    ap.add_argument("--single-stream-contexts", action="store_true",
-                    help="one HIP stream per pair stream (default: two -- the warps of a period overlap its flow chain)")
+    ap.add_argument("--dual-stream-contexts", action="store_true",
+                    help="two HIP streams per pair stream: the warps of a period overlap its flow chain (measured equal "
+                         "throughput at 4 pair streams, lower per-launch roofline; default: one stream per pair stream)")
     ap.add_argument("--priority-streams", action="store_true",
                     help="per pair stream: flow chain on a high-priority stream, warps on a low-priority stream")
     ap.add_argument("--no-fused-warp", action="store_true", help="one warp launch per output frame instead of one per source period")
@@ -170,7 +171,7 @@ def main():
         flags |= capi.HF_FLAG_SHARED_WARP_STREAM
     if a.priority_streams:
         flags |= capi.HF_FLAG_PRIORITY_STREAMS
-    if not a.single_stream_contexts and not a.shared_warp_stream and not a.priority_streams:
+    if a.dual_stream_contexts:
         flags |= capi.HF_FLAG_DUAL_STREAM
     cls = OpticalFlowCalcHDR if hdr else OpticalFlowCalcSDR
     calcs, outbufs, plans = [], [], []
@@ -309,7 +310,7 @@ def main():
             "dtype": "u16" if hdr else "u8", "data": "synthetic",
             "config": {"workload": a.workload, "description": desc, "search_radius": a.radius,
                        "delta_scalar": 8, "neighbor_scalar": a.neighbor, "blur_radius": a.blur_radius,
-                       "pair_streams_per_gpu": a.streams, "warp_stream": "shared per GPU" if a.shared_warp_stream else ("own stream, overlapping the context's flow chain" if not a.single_stream_contexts else "same stream as the flow chain"), "source_frames": "copied into the ring" if a.copy_in else "referenced in place (zero-copy)", "source_periods_per_step": a.streams,
+                       "pair_streams_per_gpu": a.streams, "warp_stream": "shared per GPU" if a.shared_warp_stream else ("own stream, overlapping the context's flow chain" if a.dual_stream_contexts else "same stream as the flow chain"), "source_frames": "copied into the ring" if a.copy_in else "referenced in place (zero-copy)", "source_periods_per_step": a.streams,
                        "output_frames_total": int(frames_total), "parallelism": f"pair-sharded x{n_gpus}, no collective",
                        "frame_bytes": F, "flow_grid": [st["low_width"], st["low_height"]], "res_scalar": st["res_scalar"]},
             "ms_per_flow_calc": round(prof["flow_ms"] / prof["flow_chains"], 4) if prof["flow_chains"] else None,

@@ -51,3 +51,12 @@ for _ in range(3): c.updateFrameDevice(db.ptr)
 c.sync(); c.timerBegin()
 for _ in range(a.n): c.updateFrameDevice(db.ptr)
 print(f"{'updateFrameDevice (D2D + prep)':34s} {1e3*c.timerEnd()/a.n:8.2f} us")
+# fused period: 5 outputs in one launch
+outs5 = [DeviceBuffer(c.output_frame_bytes) for _ in range(5)]
+ptrs5 = [o.ptr for o in outs5]
+ts5 = [0.0, 0.1998, 0.3996, 0.5994, 0.7992]
+for _ in range(3): c.interpolateOnly(ts5, ptrs5, 2)
+c.resetProfile()
+for _ in range(a.n): c.interpolateOnly(ts5, ptrs5, 2)
+p = c.profile(); us = 1e3 * p["warp_ms"] / p["warp_launches"]
+print(f"{'fused period (5 outputs, mode 2)':34s} {us:8.2f} us  {5*3*F/us/1e3:8.1f} GB/s algorithmic, {7*F/us/1e3:8.1f} GB/s compulsory (2F + 5F)")
