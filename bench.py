@@ -91,6 +91,32 @@ def cpu_baseline(hdr, H, W, target, radius, neighbor, frames, n_pairs):
             "sample": f"{n_pairs} source pairs ({outs} output frames) of the same workload, oracle/hf_oracle.c, 1 thread, {dt:.1f} s"}
 
 
+def cpu_baseline_all_cores(hdr, H, W, target, radius, neighbor, frames, pairs_per_thread=2, max_threads=64):
+    """The same oracle port with one source pair per host thread at a time (pairs are independent units, SURVEY.md
+    section 8(e); the C calls release the GIL)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from hopperrender_amd.protocol import SOURCE_24, BlendSchedule
+    from oracle import oracle
+    g = oracle.make_geom(hdr, H, W)
+    threads = max(1, min(len(os.sched_getaffinity(0)), max_threads))
+    n_pairs = threads * pairs_per_thread
+    plan = BlendSchedule(SOURCE_24, target).plan(n_pairs + 1)[1:]
+
+    def one(i):
+        f0, f1, f2 = frames[i % len(frames)], frames[(i + 1) % len(frames)], frames[(i + 2) % len(frames)]
+        _, blur, _, _ = oracle.calculate_optical_flow(f1, f2, g, radius, 0, 8, neighbor, 4)
+        for t in plan[i]:
+            oracle.warp_frames(f0, f1, blur, g, t, 2)
+        return len(plan[i])
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(threads) as ex:
+        outs = sum(ex.map(one, range(n_pairs)))
+    dt = time.perf_counter() - t0
+    return {"value": outs / dt, "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"{n_pairs} source pairs ({outs} output frames), one pair per thread at a time, {threads} threads, {dt:.1f} s"}
+
+
 def reference_opencl(hdr, H, W, target, radius, neighbor, frames):
     """The reference's own OpenCL path on this GPU (child process; outside the timed region)."""
     from hopperrender_amd.protocol import SOURCE_24
@@ -322,6 +348,7 @@ def main():
             try:
                 out["cpu_baseline"] = cpu_baseline(hdr, H, W, target, a.radius, a.neighbor, host_frames, a.cpu_sample_pairs)
                 out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+                out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(hdr, H, W, target, a.radius, a.neighbor, host_frames)
             except Exception as e:  # the checker must never take the measurement down
                 out["cpu_baseline"] = {"error": repr(e)}
         if not a.no_reference:
