@@ -24,6 +24,7 @@
 //     and Y of a level run in ONE launch (5 launches for levels 32..2).  Larger windows take two
 //     launches per axis (partial sums with one atomic per candidate per workgroup, then a tiny argmin).
 #include "hf_kernels.h"
+#include <cstdlib>
 
 namespace hf {
 
@@ -456,12 +457,16 @@ template <> struct Map<2> {    // 2 lanes = one 2x2 window; wave = 8x4 windows; 
 };
 
 // One level, X step then Y step, windows <= 32.
-template <int WS>
-__global__ __launch_bounds__(256) void flow_level_small_kernel(const Geom g, const FlowStep a) {
+// SPLIT (windows <= 16, where a window never spans waves): the four waves of a tile are four one-wave workgroups
+// (blockIdx.z = wave).  A 480x270 grid has only 135 tiles for 256 CUs; split, every CU's L1 takes a share of the
+// candidate rows' cache lines (a Y step pulls ~16 x 8 row segments per wave, 32 useful bytes per 128-byte line).
+template <int WS, bool SPLIT>
+__global__ __launch_bounds__(SPLIT ? 64 : 256) void flow_level_small_kernel(const Geom g, const FlowStep a) {
     using M = Map<WS>;
     constexpr int PX = M::PX, G = M::G;
-    __shared__ uint32_t s_part[2][4][16];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    static_assert(!SPLIT || WS <= 16, "a 32x32 window is shared by the four waves of a workgroup");
+    __shared__ uint32_t s_part[SPLIT ? 1 : 2][SPLIT ? 1 : 4][16];
+    const int tid = SPLIT ? (int)(blockIdx.z * 64 + threadIdx.x) : (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;
     int lx, ly;
     M::at(tid, lx, ly);
     const int cx0 = blockIdx.x * M::TW + lx, cy = blockIdx.y * M::TH + ly;
@@ -486,7 +491,7 @@ __global__ __launch_bounds__(256) void flow_level_small_kernel(const Geom g, con
         uint32_t sad[16];
         strip_sads<PX>(sad, g, a, strip, off[0], off[1], axis);
         int first = group_reduce<G>(sad, lane);
-        if (WS == 32) {   // four waves share the window
+        if constexpr (WS == 32) {   // four waves share the window
             if ((lane & 3) == 0) s_part[axis][wave][first] = sad[0];
             __syncthreads();
             sad[0] = s_part[axis][0][first] + s_part[axis][1][first] + s_part[axis][2][first] + s_part[axis][3][first];
@@ -620,12 +625,23 @@ void launch_flow_level_small(const Geom& g, const FlowStep& a, hipStream_t strea
     const int ws = a.cur.window;
     const int tw = ws == 2 ? 16 : 32;
     const dim3 grd((g.lw + tw - 1) / tw, (g.lh + 31) / 32);
+    static const bool split = !(getenv("HF_FLOW_SPLIT") && atoi(getenv("HF_FLOW_SPLIT")) == 0);
+    const dim3 sgrd(grd.x, grd.y, 4);
+    if (split && ws <= 16) {
+        switch (ws) {
+            case 16: flow_level_small_kernel<16, true><<<sgrd, 64, 0, stream>>>(g, a); break;
+            case 8: flow_level_small_kernel<8, true><<<sgrd, 64, 0, stream>>>(g, a); break;
+            case 4: flow_level_small_kernel<4, true><<<sgrd, 64, 0, stream>>>(g, a); break;
+            default: flow_level_small_kernel<2, true><<<sgrd, 64, 0, stream>>>(g, a); break;
+        }
+        return;
+    }
     switch (ws) {
-        case 32: flow_level_small_kernel<32><<<grd, 256, 0, stream>>>(g, a); break;
-        case 16: flow_level_small_kernel<16><<<grd, 256, 0, stream>>>(g, a); break;
-        case 8: flow_level_small_kernel<8><<<grd, 256, 0, stream>>>(g, a); break;
-        case 4: flow_level_small_kernel<4><<<grd, 256, 0, stream>>>(g, a); break;
-        default: flow_level_small_kernel<2><<<grd, 256, 0, stream>>>(g, a); break;
+        case 32: flow_level_small_kernel<32, false><<<grd, 256, 0, stream>>>(g, a); break;
+        case 16: flow_level_small_kernel<16, false><<<grd, 256, 0, stream>>>(g, a); break;
+        case 8: flow_level_small_kernel<8, false><<<grd, 256, 0, stream>>>(g, a); break;
+        case 4: flow_level_small_kernel<4, false><<<grd, 256, 0, stream>>>(g, a); break;
+        default: flow_level_small_kernel<2, false><<<grd, 256, 0, stream>>>(g, a); break;
     }
 }
 

@@ -313,6 +313,9 @@ template <int VB> struct StoreVec;
 template <> struct StoreVec<16> { using type = uint4; };
 template <> struct StoreVec<8> { using type = uint2; };
 
+#ifndef HF_WARP_PIPELINE
+#define HF_WARP_PIPELINE 1   // request the source runs of output ti + 1 before blending output ti
+#endif
 template <typename E, int GROUP, int ROWS, int MODE, int CZ, int VB>
 __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a, int cy0, int cx0) {
     using T = ElemTraits<E>;
@@ -353,9 +356,11 @@ __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a,
         ox21[k] = (int)(int16_t)(f21 & 0xFFFFu); oy21[k] = (int)(int16_t)(f21 >> 16);
     }
 
-  for (int ti = 0; ti < a.n_out; ti++) {
+  // Source runs of one output.  The period loop is software-pipelined: the runs of output ti + 1 are requested
+  // before output ti is blended and stored, so the loads' latency overlaps the fp32 work and the stores.
+  struct Src { Run<E, GROUP> ra[ROWS][NG], rb[ROWS][NG]; };
+  auto issue = [&](const int ti, Src& S) {
     const float s12t = a.s12v[ti], s21t = a.s21v[ti];
-    E* __restrict__ out = (E*)a.outv[ti] + (size_t)CZ * H * So + (size_t)cy0 * So + cx0;
     int xa[NG], xb[NG], dya[NG], dyb[NG];
 #pragma unroll
     for (int k = 0; k < NG; k++) {
@@ -371,7 +376,6 @@ __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a,
         }
     }
 
-    Run<E, GROUP> ra[ROWS][NG], rb[ROWS][NG];
     // mirrorCoordinate is the identity on [1, W-2]: a run that stays inside is contiguous.  The test is
     // made wave-uniform so that interior waves (all but the first/last of a row) carry no edge code.
     bool interior = true;
@@ -398,7 +402,7 @@ __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a,
 #pragma unroll
                 for (int k = 0; k < NG; k++)
 #pragma unroll
-                    for (int i = 0; i < GROUP; i++) ra[r][k].v[i] = w.v[k * GROUP + i];
+                    for (int i = 0; i < GROUP; i++) S.ra[r][k].v[i] = w.v[k * GROUP + i];
             }
             if (need_b) {
                 const E* rowp = B + (size_t)mirror_warp(cy + dyb[0], dim_y) * Si;
@@ -406,7 +410,7 @@ __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a,
 #pragma unroll
                 for (int k = 0; k < NG; k++)
 #pragma unroll
-                    for (int i = 0; i < GROUP; i++) rb[r][k].v[i] = w.v[k * GROUP + i];
+                    for (int i = 0; i < GROUP; i++) S.rb[r][k].v[i] = w.v[k * GROUP + i];
             }
         }
     } else if (__builtin_amdgcn_ballot_w64(!interior) == 0) {
@@ -417,11 +421,11 @@ __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a,
             for (int k = 0; k < NG; k++) {
                 if (need_a) {
                     const E* rowp = A + (size_t)mirror_warp(cy + dya[k], dim_y) * Si;
-                    ra[r][k] = CZ ? load_run_uv<E, GROUP>(rowp, xa[k]) : load_run<E, GROUP>(rowp + xa[k]);
+                    S.ra[r][k] = CZ ? load_run_uv<E, GROUP>(rowp, xa[k]) : load_run<E, GROUP>(rowp + xa[k]);
                 }
                 if (need_b) {
                     const E* rowp = B + (size_t)mirror_warp(cy + dyb[k], dim_y) * Si;
-                    rb[r][k] = CZ ? load_run_uv<E, GROUP>(rowp, xb[k]) : load_run<E, GROUP>(rowp + xb[k]);
+                    S.rb[r][k] = CZ ? load_run_uv<E, GROUP>(rowp, xb[k]) : load_run<E, GROUP>(rowp + xb[k]);
                 }
             }
         }
@@ -435,30 +439,34 @@ __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a,
                 if (need_a) {
                     const E* rowp = A + (size_t)mirror_warp(cy + dya[k], dim_y) * Si;
                     if (xa[k] >= 1 && xa[k] + GROUP - 1 <= W - 2) {
-                        ra[r][k] = CZ ? load_run_uv<E, GROUP>(rowp, xa[k]) : load_run<E, GROUP>(rowp + xa[k]);
+                        S.ra[r][k] = CZ ? load_run_uv<E, GROUP>(rowp, xa[k]) : load_run<E, GROUP>(rowp + xa[k]);
                     } else {
 #pragma unroll
                         for (int i = 0; i < GROUP; i++) {
                             const int x = mirror_warp(xa[k] + i, W);
-                            ra[r][k].v[i] = rowp[CZ ? (x & ~1) + (i & 1) : x];
+                            S.ra[r][k].v[i] = rowp[CZ ? (x & ~1) + (i & 1) : x];
                         }
                     }
                 }
                 if (need_b) {
                     const E* rowp = B + (size_t)mirror_warp(cy + dyb[k], dim_y) * Si;
                     if (xb[k] >= 1 && xb[k] + GROUP - 1 <= W - 2) {
-                        rb[r][k] = CZ ? load_run_uv<E, GROUP>(rowp, xb[k]) : load_run<E, GROUP>(rowp + xb[k]);
+                        S.rb[r][k] = CZ ? load_run_uv<E, GROUP>(rowp, xb[k]) : load_run<E, GROUP>(rowp + xb[k]);
                     } else {
 #pragma unroll
                         for (int i = 0; i < GROUP; i++) {
                             const int x = mirror_warp(xb[k] + i, W);
-                            rb[r][k].v[i] = rowp[CZ ? (x & ~1) + (i & 1) : x];
+                            S.rb[r][k].v[i] = rowp[CZ ? (x & ~1) + (i & 1) : x];
                         }
                     }
                 }
             }
         }
     }
+  };
+  auto finish = [&](const int ti, const Src& S) {
+    const float s12t = a.s12v[ti], s21t = a.s21v[ti];
+    E* __restrict__ out = (E*)a.outv[ti] + (size_t)CZ * H * So + (size_t)cy0 * So + cx0;
 #pragma unroll
     for (int r = 0; r < ROWS; r++) {
         if (r >= nrows) continue;
@@ -467,10 +475,10 @@ __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a,
         for (int k = 0; k < NG; k++) {
             if (MODE == 0) {
 #pragma unroll
-                for (int i = 0; i < GROUP; i++) v[k * GROUP + i] = ra[r][k].v[i];
+                for (int i = 0; i < GROUP; i++) v[k * GROUP + i] = S.ra[r][k].v[i];
             } else if (MODE == 1) {
 #pragma unroll
-                for (int i = 0; i < GROUP; i++) v[k * GROUP + i] = rb[r][k].v[i];
+                for (int i = 0; i < GROUP; i++) v[k * GROUP + i] = S.rb[r][k].v[i];
             } else {
                 // Blend + levels two elements at a time on the packed fp32 pipe (v_pk_mul/fma/add_f32: the
                 // same IEEE operations per element as the scalar form).  The launcher only selects this
@@ -479,8 +487,8 @@ __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a,
                 //   fmax(fmin(f, max), 0)    == med3(f, 0, max)               (f is never NaN).
 #pragma unroll
                 for (int i = 0; i < GROUP; i += 2) {
-                    const float2v fa = {(float)ra[r][k].v[i], (float)ra[r][k].v[i + 1]};
-                    const float2v fb = {(float)rb[r][k].v[i], (float)rb[r][k].v[i + 1]};
+                    const float2v fa = {(float)S.ra[r][k].v[i], (float)S.ra[r][k].v[i + 1]};
+                    const float2v fb = {(float)S.rb[r][k].v[i], (float)S.rb[r][k].v[i + 1]};
                     const float2v s12 = {s12t, s12t}, s21 = {s21t, s21t};
                     float2v bl = __builtin_elementwise_fma(fa, s21, fb * s12);          // :176-177 as compiled on gfx950
                     bl.x = __builtin_truncf(bl.x);
@@ -500,7 +508,22 @@ __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a,
         }
         *(SV*)(out + (size_t)r * So) = *(const SV*)v;
     }
-  }   // outputs of the period
+  };
+#if HF_WARP_PIPELINE
+  Src nxt;
+  issue(0, nxt);
+  for (int ti = 0; ti < a.n_out; ti++) {
+    const Src cur = nxt;
+    if (ti + 1 < a.n_out) issue(ti + 1, nxt);
+    finish(ti, cur);
+  }
+#else
+  for (int ti = 0; ti < a.n_out; ti++) {
+    Src cur;
+    issue(ti, cur);
+    finish(ti, cur);
+  }
+#endif
 }
 
 // Thread = VEC consecutive elements x ROWS consecutive rows that share one flow-cell row (ROWS
