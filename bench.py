@@ -46,6 +46,9 @@ def parse_args():
     ap.add_argument("--neighbor", type=int, default=6)
     ap.add_argument("--blur-radius", type=int, default=4)
     ap.add_argument("--streams", type=int, default=6, help="independent frame-pair streams per GPU")
+    ap.add_argument("--batch", type=int, default=1,
+                    help="pair streams per flow batch (hf_batch): the refinement chains of `batch` independent pairs run as one "
+                         "set of launches on one HIP stream; streams/batch batches run side by side")
     ap.add_argument("--pool", type=int, default=6, help="distinct synthetic source frames resident in HBM, per pair stream")
     ap.add_argument("--dual-stream-contexts", action="store_true",
                     help="two HIP streams per pair stream: the warps of a period overlap its flow chain (measured equal "
@@ -217,8 +220,33 @@ def main():
         c.sync()
 
     out_ptrs = [[b.ptr for b in bufs] for bufs in outbufs]
+    batches = []
+    if a.batch > 1:
+        from hopperrender_amd.calc import FlowBatch
+        if a.streams % a.batch:
+            raise SystemExit("--streams must be a multiple of --batch")
+        batches = [FlowBatch(calcs[k:k + a.batch]) for k in range(0, a.streams, a.batch)]
+
+    def run_step_batched(i):
+        """Per batch: the new source frame of every member pair, ONE batched flow calculation, then every member's
+        outputs of the period (one fused warp launch each) -- all on the batch's stream."""
+        n = 0
+        for bi, b in enumerate(batches):
+            lo = bi * a.batch
+            for s in range(lo, lo + a.batch):
+                update(calcs[s], pools[s][(s + 3 + i) % a.pool].ptr)
+            if a.diagnose != "no-flow":
+                b.calculateOpticalFlow()
+            for s in range(lo, lo + a.batch):
+                ts = plans[s][i]
+                if a.diagnose != "no-warp":
+                    calcs[s].interpolateOnly(ts, out_ptrs[s], 2)
+                n += len(ts)
+        return n
 
     def run_step(i):
+        if batches:
+            return run_step_batched(i)
         n = 0
         for s, c in enumerate(calcs):
             ts = plans[s][i]
@@ -336,7 +364,7 @@ def main():
             "dtype": "u16" if hdr else "u8", "data": "synthetic",
             "config": {"workload": a.workload, "description": desc, "search_radius": a.radius,
                        "delta_scalar": 8, "neighbor_scalar": a.neighbor, "blur_radius": a.blur_radius,
-                       "pair_streams_per_gpu": a.streams, "warp_stream": "shared per GPU" if a.shared_warp_stream else ("own stream, overlapping the context's flow chain" if a.dual_stream_contexts else "same stream as the flow chain"), "source_frames": "copied into the ring" if a.copy_in else "referenced in place (zero-copy)", "source_periods_per_step": a.streams,
+                       "pair_streams_per_gpu": a.streams, "flow_batch": a.batch, "warp_stream": "shared per GPU" if a.shared_warp_stream else ("own stream, overlapping the context's flow chain" if a.dual_stream_contexts else "same stream as the flow chain"), "source_frames": "copied into the ring" if a.copy_in else "referenced in place (zero-copy)", "source_periods_per_step": a.streams,
                        "output_frames_total": int(frames_total), "parallelism": f"pair-sharded x{n_gpus}, no collective",
                        "frame_bytes": F, "flow_grid": [st["low_width"], st["low_height"]], "res_scalar": st["res_scalar"]},
             "ms_per_flow_calc": round(prof["flow_ms"] / prof["flow_chains"], 4) if prof["flow_chains"] else None,
@@ -361,6 +389,8 @@ def main():
                 out["reference_opencl"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
 
+    for b in batches:
+        b.close()
     for c in calcs:
         c.close()
     if world > 1:

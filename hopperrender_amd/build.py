@@ -48,9 +48,11 @@ def build_flow(force=False):
     deps = srcs + [os.path.join(CSRC, "hf_kernels.h"), os.path.join(INCLUDE, "hopperflow.h")]
     if force or _stale(LIB_FLOW, deps):
         objs = []
+        hdrs = deps[len(srcs):]
         for s in srcs:
             o = os.path.join(LIBDIR, os.path.basename(s) + ".o")
-            _run([HIPCC] + HIP_FLAGS + extra + ["-I", INCLUDE, "-c", s, "-o", o])
+            if force or _stale(o, [s] + hdrs):   # objects are git-ignored; only changed sources are recompiled
+                _run([HIPCC] + HIP_FLAGS + extra + ["-I", INCLUDE, "-c", s, "-o", o])
             objs.append(o)
         _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_FLOW] + objs +
              ["-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined"])

@@ -278,3 +278,38 @@ class PinnedArray:
             self.array = None
             self._lib.hf_host_free_pinned(C.c_void_p(self.ptr))
             self.ptr = None
+
+
+class FlowBatch:
+    """hf_batch: calculateOpticalFlow() of up to 8 contexts (independent frame pairs, same geometry and parameters)
+    as one set of launches.  While the batch exists its members issue on one stream; close() it before them."""
+
+    def __init__(self, members):
+        self._lib = capi.load()
+        self.members = list(members)
+        arr = (C.c_void_p * len(self.members))(*[m._ctx for m in self.members])
+        out = C.c_void_p()
+        rc = self._lib.hf_batch_create(arr, len(self.members), C.byref(out))
+        if rc != 0:
+            raise capi.HopperFlowError(rc, (self._lib.hf_batch_last_error(None) or b"").decode())
+        self._b = out
+
+    def calculateOpticalFlow(self):
+        rc = self._lib.hf_batch_calculate_optical_flow(self._b)
+        if rc != 0:
+            raise capi.HopperFlowError(rc, (self._lib.hf_batch_last_error(self._b) or b"").decode())
+
+    def __len__(self):
+        return self._lib.hf_batch_size(self._b)
+
+    def close(self):
+        if self._b:
+            self._lib.hf_batch_destroy(self._b)
+            self._b = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+

@@ -69,6 +69,11 @@ SIGNATURES = {
     "hf_download_frame_async": (_i, [_vp, _vp]),
     "hf_interpolate_period": (_i, [_vp, _vp, _i, C.POINTER(C.c_float), C.POINTER(_vp), _i]),
     "hf_interpolate_period_ex": (_i, [_vp, _vp, _i, C.POINTER(C.c_float), C.POINTER(_vp), _i, _i]),
+    "hf_batch_create": (_i, [C.POINTER(_vp), _i, C.POINTER(_vp)]),
+    "hf_batch_destroy": (None, [_vp]),
+    "hf_batch_calculate_optical_flow": (_i, [_vp]),
+    "hf_batch_size": (_i, [_vp]),
+    "hf_batch_last_error": (C.c_char_p, [_vp]),
     "hf_download_frame_device": (_i, [_vp, _vp]),
     "hf_set_output_buffer": (_i, [_vp, _vp]),
     "hf_sync": (_i, [_vp]),
@@ -94,7 +99,8 @@ _lib = None
 
 
 def lib_path():
-    return _build.LIB_FLOW
+    # HF_LIB: another build of the SAME library (kernel experiments); never an alternative implementation
+    return os.environ.get("HF_LIB") or _build.LIB_FLOW
 
 
 def load():

@@ -59,7 +59,8 @@ struct hf_ctx {
     hf::Geom g{};
     hf_config cfg{};
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;                      // stream the context issues on (a batch's shared stream while it is a member)
+    hipStream_t own_stream = nullptr;                  // the stream this context created and destroys
     hipStream_t warp_stream = nullptr;                 // == stream unless HF_FLAG_SHARED_WARP_STREAM / HF_FLAG_PRIORITY_STREAMS
     hipStream_t own_warp_stream = nullptr;             // HF_FLAG_PRIORITY_STREAMS: this context's low-priority warp stream
     hipEvent_t ev_chain_done = nullptr, ev_warps_done = nullptr;
@@ -190,70 +191,95 @@ int effective_iterations(const hf_ctx* c) {
     return iters;
 }
 
-// Enqueue the refinement chain + blur (opticalFlowCalcSDR.cpp:44-116).  Capturable.
-int enqueue_flow_chain(hf_ctx* c) {
+// Enqueue the refinement chains + blur (opticalFlowCalcSDR.cpp:44-116) of n contexts with identical geometry and
+// parameters as ONE set of launches on stream s (hf_kernels.h FlowBatch; n == 1: the plain call).  Capturable.
+int enqueue_flow_chain(hf_ctx* const* cs, int n, hipStream_t s) {
+    hf_ctx* c = cs[0];
     const hf::Geom& g = c->g;
-    hipStream_t s = c->stream;
     const int iters = effective_iterations(c);
-    c->initial_window = initial_window(g.lw, g.lh);
-    c->last_iterations = iters;
     bool any_big = false;
     for (int k = 0; k < iters; k++) any_big |= c->levels[k].window > 32;
     // the window sums are zero on entry: zeroed at creation and re-zeroed by the blur kernel of every chain
 
-    hf::FlowStep a{};
-    a.py1 = c->py[1]; a.puv1 = c->puv[1];                         // :79 frame N-1
-    a.py2 = c->py[2]; a.puv2 = c->puv[2];                         // :80 frame N
-    a.pl = c->pl;
-    a.total_delta = c->d_total_delta;
-    a.R = c->p.search_radius;
-    a.delta_scalar = c->p.delta_scalar;
-    a.neighbor_scalar = c->p.neighbor_scalar;
-    a.delta_divisor = (uint32_t)(g.lh * g.lw * (g.hdr ? 6 : 10));  // :93 / HDR :93
+    hf::FlowBatch a{};
+    a.n = n;
+    for (int i = 0; i < n; i++) {
+        hf_ctx* m = cs[i];
+        m->initial_window = initial_window(g.lw, g.lh);
+        m->last_iterations = iters;
+        hf::FlowStep& f = a.s[i];
+        f.py1 = m->py[1]; f.puv1 = m->puv[1];                         // :79 frame N-1
+        f.py2 = m->py[2]; f.puv2 = m->puv[2];                         // :80 frame N
+        f.pl = m->pl;
+        f.total_delta = m->d_total_delta;
+        f.R = c->p.search_radius;
+        f.delta_scalar = c->p.delta_scalar;
+        f.neighbor_scalar = c->p.neighbor_scalar;
+        f.delta_divisor = (uint32_t)(g.lh * g.lw * (g.hdr ? 6 : 10));  // :93 / HDR :93
+    }
     hf::FlowLevel none{};
-    hf::PendingArgmin pending{};   // large-window step whose argmin the next launch takes (hf_kernels.h)
+    hf::PendingArgmin pending[hf::kMaxFlowBatch] = {};   // large-window step whose argmin the next launch takes (hf_kernels.h)
     int step_index = 0;
     auto flush_pending = [&]() {   // explicit argmin launch for a pending step nobody can resolve lazily
-        if (!pending.active) return;
-        hf::FlowStep b = a;
-        b.cur = pending.lvl; b.prev = pending.lvl_prev; b.axis = pending.axis; b.capture_delta = pending.capture_delta;
-        b.sums = const_cast<uint32_t*>(pending.sums); b.use_neighbors = 0; b.pend = hf::PendingArgmin{};
+        if (!pending[0].active) return;
+        hf::FlowBatch b = a;
+        for (int i = 0; i < n; i++) {
+            hf::FlowStep& f = b.s[i];
+            const hf::PendingArgmin& p = pending[i];
+            f.cur = p.lvl; f.prev = p.lvl_prev; f.axis = p.axis; f.capture_delta = p.capture_delta;
+            f.sums = const_cast<uint32_t*>(p.sums); f.use_neighbors = 0; f.pend = hf::PendingArgmin{};
+            pending[i] = hf::PendingArgmin{};
+        }
         hf::launch_flow_big_argmin(g, b, s);
-        pending = hf::PendingArgmin{};
     };
     const bool lazy = !(c->cfg.flags & HF_FLAG_NO_LAZY_ARGMIN);
     for (int k = 0; k < iters; k++) {                             // window halves every level (:110)
-        a.cur = c->levels[k];
-        a.prev = k ? c->levels[k - 1] : none;                     // :68-69: the chain starts from zero offsets
-        a.use_neighbors = k >= 4;                                 // calcDeltaSumsKernelSDR.h:3,112
-        if (a.use_neighbors) flush_pending();                     // a launch with a neighbour term reads other windows' entries
-        if (a.cur.window <= 32) {
-            a.capture_delta = k == 0;                             // :91
-            a.axis = 0;
-            a.pend = pending;
-            hf::launch_flow_level_small(g, a, s);
-            pending = hf::PendingArgmin{};
-        } else {
-            for (int axis = 0; axis < 2; axis++, step_index++) {
-                a.axis = axis;
-                a.capture_delta = (k == 0 && axis == 0);
-                a.sums = c->sums + (size_t)step_index * c->sums_stride;
-                a.pend = pending;
+        const bool use_neighbors = k >= 4;                        // calcDeltaSumsKernelSDR.h:3,112
+        if (use_neighbors) flush_pending();                       // a launch with a neighbour term reads other windows' entries
+        const bool small = c->levels[k].window <= 32;
+        for (int axis = 0; axis < (small ? 1 : 2); axis++) {
+            for (int i = 0; i < n; i++) {
+                hf_ctx* m = cs[i];
+                hf::FlowStep& f = a.s[i];
+                f.cur = m->levels[k];
+                f.prev = k ? m->levels[k - 1] : none;             // :68-69: the chain starts from zero offsets
+                f.use_neighbors = use_neighbors;
+                f.axis = axis;
+                f.capture_delta = (k == 0 && axis == 0);          // :91
+                f.pend = pending[i];
+                if (!small) f.sums = m->sums + (size_t)step_index * m->sums_stride;
+                pending[i] = hf::PendingArgmin{};
+            }
+            if (small) {
+                hf::launch_flow_level_small(g, a, s);
+            } else {
                 hf::launch_flow_big_partial(g, a, s);
-                pending = hf::PendingArgmin{};
-                pending.active = 1; pending.axis = axis; pending.capture_delta = a.capture_delta;
-                pending.lvl = a.cur; pending.lvl_prev = a.prev; pending.sums = a.sums;
-                if (!lazy || a.use_neighbors) flush_pending();
+                for (int i = 0; i < n; i++) {
+                    const hf::FlowStep& f = a.s[i];
+                    pending[i].active = 1; pending[i].axis = axis; pending[i].capture_delta = f.capture_delta;
+                    pending[i].lvl = f.cur; pending[i].lvl_prev = f.prev; pending[i].sums = f.sums;
+                }
+                step_index++;
+                if (!lazy || use_neighbors) flush_pending();
             }
         }
     }
     flush_pending();
-    c->last_level = iters ? c->levels[iters - 1] : none;
-    hf::launch_blur_flow(g, c->last_level, c->blurred[0], c->blurred_xy[0], c->cfg.blur_radius,
-                         any_big ? c->sums : nullptr, (int)(c->sums_bytes / sizeof(uint32_t)), s);  // :115-116
+    hf::BlurBatch bb{};
+    bb.n = n;
+    for (int i = 0; i < n; i++) {
+        hf_ctx* m = cs[i];
+        m->last_level = iters ? m->levels[iters - 1] : none;
+        bb.s[i].last = m->last_level;
+        bb.s[i].blurred = m->blurred[0];
+        bb.s[i].packed = m->blurred_xy[0];
+        bb.s[i].zero = any_big ? m->sums : nullptr;
+    }
+    hf::launch_blur_flow(g, bb, c->cfg.blur_radius, (int)(c->sums_bytes / sizeof(uint32_t)), s);  // :115-116
     HF_HIP(c, hipGetLastError());
     return HF_OK;
 }
+int enqueue_flow_chain(hf_ctx* c) { return enqueue_flow_chain(&c, 1, c->stream); }
 
 void finish_flow_timing(hf_ctx* c) {
     // opticalFlowCalcSDR.cpp:125-138
@@ -309,7 +335,7 @@ void collect_spans(hf_ctx* c) {  // stream must be idle
         if (hipEventElapsedTime(&ms, s.b, s.e) == hipSuccess) {
             if (s.kind == 0) { c->prof.warp_launches++; c->prof.warp_ms += ms; c->prof.warp_frames += (uint64_t)s.frames; }
             else if (s.kind == 1) { c->prof.copy_launches++; c->prof.copy_ms += ms; }
-            else { c->prof.flow_chains++; c->prof.flow_ms += ms; }
+            else { c->prof.flow_chains += (uint64_t)s.frames; c->prof.flow_ms += ms; }   // a batch span covers n chains
         }
         c->ev_pool.push_back(s.b);
         c->ev_pool.push_back(s.e);
@@ -523,6 +549,7 @@ int hf_create(const hf_config* cfg, hf_ctx** out_ctx) {
     } else {
         HF_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     }
+    c->own_stream = c->stream;
     c->warp_stream = c->own_warp_stream ? c->own_warp_stream : c->stream;
     if (cfg->flags & HF_FLAG_SHARED_WARP_STREAM) {
         c->warp_stream = shared_warp_stream(c->device);
@@ -604,7 +631,7 @@ void hf_destroy(hf_ctx* c) {
     hipEvent_t evs[] = {c->ev_upload, c->ev_flow_end, c->ev_warp_start, c->ev_warp_end, c->ev_user0, c->ev_user1};
     for (hipEvent_t e : evs) if (e) hipEventDestroy(e);
     if (c->own_warp_stream) hipStreamDestroy(c->own_warp_stream);
-    if (c->stream) hipStreamDestroy(c->stream);
+    if (c->own_stream) hipStreamDestroy(c->own_stream);   // c->stream may be a batch's shared stream (not ours)
     delete c;
 }
 
@@ -670,13 +697,46 @@ int hf_update_frame_device_ref(hf_ctx* c, const void* device_frame) {
     return update_common(c, device_frame, hipMemcpyDeviceToDevice, true);
 }
 
-int hf_calculate_optical_flow(hf_ctx* c) {
-    HF_CHECK_CTX(c);
-    if (int rc = set_device(c)) return rc;
+static int check_flow_params(hf_ctx* c) {
     const int R = c->p.search_radius;
     if (R < 2 || R > kMaxSearchRadius) return fail(c, HF_ERR_INVALID_ARGUMENT, "calculateOpticalFlow: search radius %d outside [2, 16]", R);
     if (c->p.delta_scalar < 0 || c->p.delta_scalar > 24 || c->p.neighbor_scalar < 0 || c->p.neighbor_scalar > 24)
         return fail(c, HF_ERR_INVALID_ARGUMENT, "calculateOpticalFlow: delta/neighbor scalar outside [0, 24]");
+    return HF_OK;
+}
+
+// Bookkeeping behind an enqueued chain (eager, graph replay or batch): timing event, flow buffer swap.
+static int after_flow_enqueued(hf_ctx* c, hipStream_t s) {
+    // a graph replay / batch leader skips enqueue_flow_chain()'s bookkeeping for this context: redo it
+    const int iters = effective_iterations(c);
+    c->initial_window = initial_window(c->g.lw, c->g.lh);
+    c->last_iterations = iters;
+    c->last_level = iters ? c->levels[iters - 1] : hf::FlowLevel{};
+    HF_HIP(c, hipEventRecord(c->ev_flow_end, s));
+    c->delta_pending = c->last_iterations > 0;
+    c->flow_timing_pending = true;
+    if (c->dual()) {   // tag the flow buffer just written, the tag travels with the buffer through the swap below
+        HF_HIP(c, hipEventRecord(c->ev_flow[0], s));
+        c->ev_flow_valid[0] = true;
+        hipEvent_t te = c->ev_flow[0]; c->ev_flow[0] = c->ev_flow[1]; c->ev_flow[1] = te;
+        bool tv = c->ev_flow_valid[0]; c->ev_flow_valid[0] = c->ev_flow_valid[1]; c->ev_flow_valid[1] = tv;
+    }
+    // opticalFlowCalcSDR.cpp:121-123 : swap so that [1] = newest flow, [0] = previous flow
+    int16_t* t = c->blurred[0];
+    c->blurred[0] = c->blurred[1];
+    c->blurred[1] = t;
+    uint32_t* txy = c->blurred_xy[0];
+    c->blurred_xy[0] = c->blurred_xy[1];
+    c->blurred_xy[1] = txy;
+    c->blur_phase ^= 1;
+    c->have_flow = true;
+    return HF_OK;
+}
+
+int hf_calculate_optical_flow(hf_ctx* c) {
+    HF_CHECK_CTX(c);
+    if (int rc = set_device(c)) return rc;
+    if (int rc = check_flow_params(c)) return rc;
     if (int rc = leave_warp_stream(c)) return rc;
 
     int span = -1;
@@ -684,7 +744,7 @@ int hf_calculate_optical_flow(hf_ctx* c) {
         span = span_begin(c, 2);
         if (int rc = enqueue_flow_chain(c)) return rc;
     } else {
-        const auto key = std::make_tuple(c->ring_phase, c->blur_phase, R, c->p.delta_scalar, c->p.neighbor_scalar);
+        const auto key = std::make_tuple(c->ring_phase, c->blur_phase, c->p.search_radius, c->p.delta_scalar, c->p.neighbor_scalar);
         auto it = c->graphs.find(key);
         if (it == c->graphs.end()) {
             hipGraph_t graph = nullptr;
@@ -701,38 +761,123 @@ int hf_calculate_optical_flow(hf_ctx* c) {
                 c->graphs.clear();
             }
             it = c->graphs.emplace(key, exec).first;
-        } else {
-            // replay path: recompute the bookkeeping enqueue_flow_chain() would have set
-            const int iters = effective_iterations(c);
-            c->initial_window = initial_window(c->g.lw, c->g.lh);
-            c->last_iterations = iters;
-            c->last_level = iters ? c->levels[iters - 1] : hf::FlowLevel{};
         }
         span = span_begin(c, 2);
         HF_HIP(c, hipGraphLaunch(it->second, c->stream));
     }
     span_end(c, span);
-    HF_HIP(c, hipEventRecord(c->ev_flow_end, c->stream));
-    c->delta_pending = c->last_iterations > 0;
-    c->flow_timing_pending = true;
-    if (c->dual()) {   // tag the flow buffer just written, the tag travels with the buffer through the swap below
-        HF_HIP(c, hipEventRecord(c->ev_flow[0], c->stream));
-        c->ev_flow_valid[0] = true;
-        hipEvent_t te = c->ev_flow[0]; c->ev_flow[0] = c->ev_flow[1]; c->ev_flow[1] = te;
-        bool tv = c->ev_flow_valid[0]; c->ev_flow_valid[0] = c->ev_flow_valid[1]; c->ev_flow_valid[1] = tv;
-    }
-    // opticalFlowCalcSDR.cpp:121-123 : swap so that [1] = newest flow, [0] = previous flow
-    int16_t* t = c->blurred[0];
-    c->blurred[0] = c->blurred[1];
-    c->blurred[1] = t;
-    uint32_t* txy = c->blurred_xy[0];
-    c->blurred_xy[0] = c->blurred_xy[1];
-    c->blurred_xy[1] = txy;
-    c->blur_phase ^= 1;
-    c->have_flow = true;
+    if (int rc = after_flow_enqueued(c, c->stream)) return rc;
     if (!c->async()) return sync_ctx(c);
     return HF_OK;
 }
+
+// ---- batched flow calculation (throughput drivers; include/hopperflow.h) ----
+struct hf_batch {
+    std::vector<hf_ctx*> members;
+    std::vector<hipStream_t> own_streams;   // the members' own streams, restored by hf_batch_destroy
+    hipStream_t stream = nullptr;           // = members[0]'s stream, shared by all members while the batch exists
+    std::map<std::vector<int>, hipGraphExec_t> graphs;
+    std::string err;
+};
+
+static std::string g_batch_error;
+static int batch_fail(hf_batch* b, int code, const std::string& msg) {
+    (b ? b->err : g_batch_error) = "[HopperRender] " + msg;
+    return code;
+}
+
+const char* hf_batch_last_error(const hf_batch* b) { return b ? b->err.c_str() : g_batch_error.c_str(); }
+
+int hf_batch_create(hf_ctx* const* members, int n, hf_batch** out) {
+    if (!members || !out || n < 1) return batch_fail(nullptr, HF_ERR_INVALID_ARGUMENT, "hf_batch_create: bad argument");
+    *out = nullptr;
+    if (n > hf::kMaxFlowBatch) return batch_fail(nullptr, HF_ERR_INVALID_ARGUMENT, "hf_batch_create: at most " + std::to_string(hf::kMaxFlowBatch) + " members");
+    hf_ctx* l = members[0];
+    for (int i = 0; i < n; i++) {
+        hf_ctx* m = members[i];
+        if (!m) return batch_fail(nullptr, HF_ERR_INVALID_ARGUMENT, "hf_batch_create: null member");
+        for (int j = 0; j < i; j++) if (members[j] == m) return batch_fail(nullptr, HF_ERR_INVALID_ARGUMENT, "hf_batch_create: duplicate member");
+        const hf::Geom &a = l->g, &b = m->g;
+        const bool same = a.hdr == b.hdr && a.H == b.H && a.W == b.W && a.in_stride == b.in_stride && a.out_stride == b.out_stride &&
+                          a.rs == b.rs && m->device == l->device && m->cfg.iterations == l->cfg.iterations &&
+                          m->cfg.blur_radius == l->cfg.blur_radius;
+        if (!same) return batch_fail(nullptr, HF_ERR_INVALID_ARGUMENT, "hf_batch_create: members differ in geometry, device, iterations or blur radius");
+        if (!m->async() || m->warp_stream != m->stream || m->io_in)
+            return batch_fail(nullptr, HF_ERR_INVALID_ARGUMENT, "hf_batch_create: members must be HF_FLAG_ASYNC single-stream contexts without async host I/O");
+    }
+    if (hipSetDevice(l->device) != hipSuccess) return batch_fail(nullptr, HF_ERR_HIP, "hf_batch_create: hipSetDevice failed");
+    hf_batch* b = new (std::nothrow) hf_batch();
+    if (!b) return batch_fail(nullptr, HF_ERR_OUT_OF_MEMORY, "hf_batch_create: host allocation failed");
+    b->stream = l->stream;
+    for (int i = 0; i < n; i++) {
+        hf_ctx* m = members[i];
+        if (int rc = sync_ctx(m)) { delete b; return batch_fail(nullptr, rc, "hf_batch_create: member sync failed"); }
+        b->members.push_back(m);
+        b->own_streams.push_back(m->stream);
+        // one stream for the whole batch: the members' prep / warp launches and the batched chain stay in program order
+        for (auto& kv : m->graphs) hipGraphExecDestroy(kv.second);   // captured on the member's own stream
+        m->graphs.clear();
+        m->stream = b->stream;
+        m->warp_stream = b->stream;
+    }
+    *out = b;
+    return HF_OK;
+}
+
+void hf_batch_destroy(hf_batch* b) {
+    if (!b) return;
+    if (!b->members.empty()) hipSetDevice(b->members[0]->device);
+    if (b->stream) hipStreamSynchronize(b->stream);
+    for (auto& kv : b->graphs) hipGraphExecDestroy(kv.second);
+    for (size_t i = 0; i < b->members.size(); i++) {
+        hf_ctx* m = b->members[i];
+        for (auto& kv : m->graphs) hipGraphExecDestroy(kv.second);
+        m->graphs.clear();
+        m->stream = b->own_streams[i];
+        m->warp_stream = m->stream;
+    }
+    delete b;
+}
+
+int hf_batch_calculate_optical_flow(hf_batch* b) {
+    if (!b) return batch_fail(nullptr, HF_ERR_INVALID_ARGUMENT, "null batch");
+    hf_ctx* l = b->members[0];
+    const int n = (int)b->members.size();
+    if (hipSetDevice(l->device) != hipSuccess) return batch_fail(b, HF_ERR_HIP, "hipSetDevice failed");
+    std::vector<int> key = {l->p.search_radius, l->p.delta_scalar, l->p.neighbor_scalar};
+    for (hf_ctx* m : b->members) {
+        if (int rc = check_flow_params(m)) return batch_fail(b, rc, m->err);
+        if (m->p.search_radius != l->p.search_radius || m->p.delta_scalar != l->p.delta_scalar || m->p.neighbor_scalar != l->p.neighbor_scalar)
+            return batch_fail(b, HF_ERR_INVALID_ARGUMENT, "hf_batch_calculate_optical_flow: members differ in search radius / delta / neighbor scalar");
+        key.push_back(m->ring_phase * 2 + m->blur_phase);
+    }
+    auto it = b->graphs.find(key);
+    if (it == b->graphs.end()) {
+        hipGraph_t graph = nullptr;
+        if (hipStreamBeginCapture(b->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return batch_fail(b, HF_ERR_HIP, "hipStreamBeginCapture failed");
+        const int rc = enqueue_flow_chain(b->members.data(), n, b->stream);
+        const hipError_t e = hipStreamEndCapture(b->stream, &graph);
+        if (rc || e != hipSuccess) { if (graph) hipGraphDestroy(graph); return batch_fail(b, rc ? rc : HF_ERR_HIP, rc ? l->err : "hipStreamEndCapture failed"); }
+        hipGraphExec_t exec = nullptr;
+        const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        hipGraphDestroy(graph);
+        if (ei != hipSuccess) return batch_fail(b, HF_ERR_HIP, "hipGraphInstantiate failed");
+        if (b->graphs.size() >= 96) {
+            for (auto& kv : b->graphs) hipGraphExecDestroy(kv.second);
+            b->graphs.clear();
+        }
+        it = b->graphs.emplace(key, exec).first;
+    }
+    const int span = span_begin(l, 2);   // the leader's profile carries the batch (one span = n chains)
+    if (hipGraphLaunch(it->second, b->stream) != hipSuccess) return batch_fail(b, HF_ERR_HIP, "hipGraphLaunch failed");
+    span_end(l, span);
+    if (span >= 0) l->spans[span].frames = n;
+    for (hf_ctx* m : b->members)
+        if (int rc = after_flow_enqueued(m, b->stream)) return batch_fail(b, rc, m->err);
+    return HF_OK;
+}
+
+int hf_batch_size(const hf_batch* b) { return b ? (int)b->members.size() : 0; }
 
 int hf_warp_frames(hf_ctx* c, float t, int mode) {
     HF_CHECK_CTX(c);

@@ -280,6 +280,9 @@ __device__ __forceinline__ void strip_sads(uint32_t* sad, const Geom& g, const F
     using TUV = typename StripTypes<PX>::UV;
     const PhaseLayout& pl = a.pl;
     const int sx = s.cx0 << g.rs, sy = s.cy << g.rs;
+#ifdef HF_EXP_XONLY
+    axis = 0;
+#endif
     const int searched0 = axis ? oy : ox;
     TY y1[16];
     TUV uv1[16];
@@ -362,7 +365,7 @@ __device__ __forceinline__ int group_reduce(uint32_t* sad, int lane) {
 // `captured` (optional) receives the full cost sum of candidate cap_cz.
 template <int G>
 __device__ __forceinline__ int group_argmin(const uint32_t* tot, int first, const FlowStep& a, int searched0,
-                                            const int* nb, uint32_t npix, int cap_cz, uint32_t* captured) {
+                                            const int* nb, uint32_t npix, int cap_cz, bool want_cap, uint32_t& captured) {
     Best b{0xFFFFFFFFu, 16};
     uint32_t cap = 0;
 #pragma unroll
@@ -379,12 +382,12 @@ __device__ __forceinline__ int group_argmin(const uint32_t* tot, int first, cons
     else if (G == 16) { best_xor(b, 1); best_xor(b, 2); best_xor(b, 4); best_xor(b, 8); }
     else if (G == 4) { best_xor(b, 1); best_xor(b, 2); }
     else { best_xor(b, 1); }
-    if (captured) {
+    if (want_cap) {
         if (G == 64) { cap |= shfl_xor_u32(cap, 4); cap |= shfl_xor_u32(cap, 8); cap |= shfl_xor_u32(cap, 16); cap |= shfl_xor_u32(cap, 32); }
         else if (G == 16) { cap |= shfl_xor_u32(cap, 1); cap |= shfl_xor_u32(cap, 2); cap |= shfl_xor_u32(cap, 4); cap |= shfl_xor_u32(cap, 8); }
         else if (G == 4) { cap |= shfl_xor_u32(cap, 1); cap |= shfl_xor_u32(cap, 2); }
         else { cap |= shfl_xor_u32(cap, 1); }
-        *captured = cap;
+        captured = cap;
     }
     return b.cz;
 }
@@ -417,6 +420,35 @@ __device__ __forceinline__ int resolve_pending(const Geom& g, const FlowStep& a,
     }
     if (origin_leader) (p.axis ? p.lvl.ty : p.lvl.tx)[w] = (int16_t)value;
     return value;
+}
+
+// ------------------------------------------------------------------------------------------
+// workgroup -> tile mapping, XCD-aware
+// ------------------------------------------------------------------------------------------
+// The chain kernels use 1-D grids.  Consecutive workgroup ids go to consecutive XCDs (MI355X_MICROARCH.md "Workgroup
+// dispatch": id % 8), each with its own L2, and neighbouring tiles read overlapping candidate rows of the phase planes
+// (a Y step reaches +-8 grid rows).  With the natural order every XCD ends up fetching nearly the whole footprint of a
+// step (measured with rocprofv3 FETCH_SIZE: 6.7 MB for a launch whose footprint is ~2 MB, 129 MB per 2160p chain).
+// So unit u = (id % 8) * per_xcd + id / 8: XCD k works on the k-th contiguous eighth of the units, ordered
+// (pair, tile row, tile column, wave) -- a band of one pair's grid, or whole pairs of a batch.
+struct TileId { int pair, tx, ty, wave; bool valid; };
+__device__ __forceinline__ TileId decode_tile(int tiles_x, int tiles_y, int waves_per_tile, int n_pairs) {
+    const int total = tiles_x * tiles_y * waves_per_tile * n_pairs;
+    const int per = (total + 7) >> 3;                       // the grid is exactly 8 * per workgroups
+    const int u = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    TileId t;
+    t.valid = u < total;
+    t.wave = u % waves_per_tile;
+    const int v = u / waves_per_tile;
+    const int n_tiles = tiles_x * tiles_y;
+    t.pair = min(v / n_tiles, n_pairs - 1);
+    const int tile = v % n_tiles;
+    t.ty = tile / tiles_x;
+    t.tx = tile - t.ty * tiles_x;
+    return t;
+}
+inline int xcd_grid(int tiles_x, int tiles_y, int waves_per_tile, int n_pairs) {
+    return ((tiles_x * tiles_y * waves_per_tile * n_pairs + 7) >> 3) << 3;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -458,25 +490,28 @@ template <> struct Map<2> {    // 2 lanes = one 2x2 window; wave = 8x4 windows; 
 
 // One level, X step then Y step, windows <= 32.
 // SPLIT (windows <= 16, where a window never spans waves): the four waves of a tile are four one-wave workgroups
-// (blockIdx.z = wave).  A 480x270 grid has only 135 tiles for 256 CUs; split, every CU's L1 takes a share of the
+// (TileId::wave).  A 480x270 grid has only 135 tiles for 256 CUs; split, every CU's L1 takes a share of the
 // candidate rows' cache lines (a Y step pulls ~16 x 8 row segments per wave, 32 useful bytes per 128-byte line).
 template <int WS, bool SPLIT>
-__global__ __launch_bounds__(SPLIT ? 64 : 256) void flow_level_small_kernel(const Geom g, const FlowStep a) {
+__global__ __launch_bounds__(SPLIT ? 64 : 256) void flow_level_small_kernel(const Geom g, const FlowBatch batch) {
     using M = Map<WS>;
+    const TileId tile = decode_tile((g.lw + M::TW - 1) / M::TW, (g.lh + M::TH - 1) / M::TH, SPLIT ? 4 : 1, batch.n);
+    if (!tile.valid) return;
+    const FlowStep& a = batch.s[tile.pair];
     constexpr int PX = M::PX, G = M::G;
     static_assert(!SPLIT || WS <= 16, "a 32x32 window is shared by the four waves of a workgroup");
     __shared__ uint32_t s_part[SPLIT ? 1 : 2][SPLIT ? 1 : 4][16];
-    const int tid = SPLIT ? (int)(blockIdx.z * 64 + threadIdx.x) : (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = SPLIT ? (int)(tile.wave * 64 + threadIdx.x) : (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;
     int lx, ly;
     M::at(tid, lx, ly);
-    const int cx0 = blockIdx.x * M::TW + lx, cy = blockIdx.y * M::TH + ly;
+    const int cx0 = tile.tx * M::TW + lx, cy = tile.ty * M::TH + ly;
     const int wx = cx0 >> a.cur.log2w, wy = cy >> a.cur.log2w;
     const bool win_in = (wx << a.cur.log2w) < g.lw && (wy << a.cur.log2w) < g.lh;   // whole lane group agrees
 
     WinConst wc{};
     if (win_in) wc = load_win_const(g, a, wx, wy, false);
     if (a.pend.active) {   // the last large-window step (Y of the previous level) is resolved here
-        const int tx0 = blockIdx.x * M::TW, ty0 = blockIdx.y * M::TH;   // tile origin: inside the grid
+        const int tx0 = tile.tx * M::TW, ty0 = tile.ty * M::TH;   // tile origin: inside the grid
         const bool leader = tid == 0 && (tx0 & (a.pend.lvl.window - 1)) == 0 && (ty0 & (a.pend.lvl.window - 1)) == 0;
         const int v = resolve_pending(g, a, tx0, ty0, lane, leader);
         if (a.pend.axis) wc.oy = v; else wc.ox = v;
@@ -497,7 +532,7 @@ __global__ __launch_bounds__(SPLIT ? 64 : 256) void flow_level_small_kernel(cons
             sad[0] = s_part[axis][0][first] + s_part[axis][1][first] + s_part[axis][2][first] + s_part[axis][3][first];
         }
         const int best = group_argmin<G>(sad, first, a, off[axis], axis ? wc.nby : wc.nbx, wc.npix, cap_cz,
-                                         (axis == 0 && a.capture_delta) ? &captured : nullptr);
+                                         axis == 0 && a.capture_delta, captured);
         off[axis] = (int)(int16_t)(off[axis] + rel_offset(best, a.R));   // adjustOffsetArrayKernelSDR.h:13-19
     }
 
@@ -509,22 +544,28 @@ __global__ __launch_bounds__(SPLIT ? 64 : 256) void flow_level_small_kernel(cons
     }
 }
 
-// Windows > 32, one axis: raw SAD sums of a 32x32 tile -> one atomic per candidate.
-__global__ __launch_bounds__(256) void flow_big_partial_kernel(const Geom g, const FlowStep a) {
+// Windows > 32, one axis: raw SAD sums of a 32 x (8 * WPB) tile -> one atomic per candidate.
+// WPB = waves per workgroup.  Fewer waves per workgroup = more workgroups for the 256 CUs (a 480x270 grid has 135
+// 32x32 tiles) at the price of more atomics on the same R addresses of each window.
+template <int WPB>
+__global__ __launch_bounds__(64 * WPB) void flow_big_partial_kernel(const Geom g, const FlowBatch batch) {
+    const TileId tile = decode_tile((g.lw + 31) / 32, (g.lh + 8 * WPB - 1) / (8 * WPB), 1, batch.n);
+    if (!tile.valid) return;
+    const FlowStep& a = batch.s[tile.pair];
     using M = Map<32>;
-    __shared__ uint32_t s_part[4][16];
+    __shared__ uint32_t s_part[WPB][16];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     int lx, ly;
     M::at(tid, lx, ly);
-    const int cx0 = blockIdx.x * 32 + lx, cy = blockIdx.y * 32 + ly;
-    const int wx = (blockIdx.x * 32) >> a.cur.log2w, wy = (blockIdx.y * 32) >> a.cur.log2w;   // tile lies in one window
+    const int tx0 = tile.tx * 32, ty0 = tile.ty * (8 * WPB);   // 8 * WPB divides 32: the tile lies in one window
+    const int cx0 = tx0 + lx, cy = ty0 + ly;
+    const int wx = tx0 >> a.cur.log2w, wy = ty0 >> a.cur.log2w;
     int ox = 0, oy = 0;
     if (a.prev.tx) {
         ox = table_at(a.prev.tx, a.prev, wx << a.cur.log2w, wy << a.cur.log2w);
         oy = table_at(a.prev.ty, a.prev, wx << a.cur.log2w, wy << a.cur.log2w);
     }
     if (a.pend.active) {   // argmin of the previous large-window step, taken here instead of in a launch of its own
-        const int tx0 = blockIdx.x * 32, ty0 = blockIdx.y * 32;
         const bool leader = tid == 0 && (tx0 & (a.pend.lvl.window - 1)) == 0 && (ty0 & (a.pend.lvl.window - 1)) == 0;
         const int v = resolve_pending(g, a, tx0, ty0, lane, leader);
         if (a.pend.axis) oy = v; else ox = v;
@@ -535,14 +576,24 @@ __global__ __launch_bounds__(256) void flow_big_partial_kernel(const Geom g, con
     uint32_t sad[16];
     strip_sads<4>(sad, g, a, strip, ox, oy, a.axis);
     const int first = group_reduce<64>(sad, lane);
-    if ((lane & 3) == 0) s_part[wave][first] = sad[0];
-    __syncthreads();
-    if (tid < a.R)
-        atomicAdd(&a.sums[(wy * a.cur.nwx + wx) * 16 + tid], s_part[0][tid] + s_part[1][tid] + s_part[2][tid] + s_part[3][tid]);
+    uint32_t* dst = &a.sums[(wy * a.cur.nwx + wx) * 16];
+    if constexpr (WPB == 1) {
+        if ((lane & 3) == 0 && first < a.R) atomicAdd(dst + first, sad[0]);
+    } else {
+        if ((lane & 3) == 0) s_part[wave][first] = sad[0];
+        __syncthreads();
+        if (tid < a.R) {
+            uint32_t t = 0;
+#pragma unroll
+            for (int w = 0; w < WPB; w++) t += s_part[w][tid];
+            atomicAdd(dst + tid, t);
+        }
+    }
 }
 
 // Windows > 32, one axis: 16 lanes per window finish the sums, pick the winner, update the table.
-__global__ __launch_bounds__(256) void flow_big_argmin_kernel(const Geom g, const FlowStep a) {
+__global__ __launch_bounds__(256) void flow_big_argmin_kernel(const Geom g, const FlowBatch batch) {
+    const FlowStep& a = batch.s[blockIdx.y];
     const int lane16 = threadIdx.x & 15;
     const int nwin = a.cur.nwx * a.cur.nwy;
     for (int w = blockIdx.x * 16 + (threadIdx.x >> 4); w < nwin; w += gridDim.x * 16) {
@@ -621,38 +672,44 @@ void launch_prep_frame(const Geom& g, const PhaseLayout& pl, const void* frame, 
     else prep_phase_kernel<uint8_t><<<rows, 256, smem, stream>>>((const uint8_t*)frame, py, puv, g.H, g.W, g.in_stride, pl);
 }
 
-void launch_flow_level_small(const Geom& g, const FlowStep& a, hipStream_t stream) {
-    const int ws = a.cur.window;
+void launch_flow_level_small(const Geom& g, const FlowBatch& b, hipStream_t stream) {
+    const int ws = b.s[0].cur.window;
     const int tw = ws == 2 ? 16 : 32;
-    const dim3 grd((g.lw + tw - 1) / tw, (g.lh + 31) / 32);
+    const int tiles_x = (g.lw + tw - 1) / tw, tiles_y = (g.lh + 31) / 32;
+    const dim3 grd(xcd_grid(tiles_x, tiles_y, 1, b.n));
     static const bool split = !(getenv("HF_FLOW_SPLIT") && atoi(getenv("HF_FLOW_SPLIT")) == 0);
-    const dim3 sgrd(grd.x, grd.y, 4);
+    const dim3 sgrd(xcd_grid(tiles_x, tiles_y, 4, b.n));
     if (split && ws <= 16) {
         switch (ws) {
-            case 16: flow_level_small_kernel<16, true><<<sgrd, 64, 0, stream>>>(g, a); break;
-            case 8: flow_level_small_kernel<8, true><<<sgrd, 64, 0, stream>>>(g, a); break;
-            case 4: flow_level_small_kernel<4, true><<<sgrd, 64, 0, stream>>>(g, a); break;
-            default: flow_level_small_kernel<2, true><<<sgrd, 64, 0, stream>>>(g, a); break;
+            case 16: flow_level_small_kernel<16, true><<<sgrd, 64, 0, stream>>>(g, b); break;
+            case 8: flow_level_small_kernel<8, true><<<sgrd, 64, 0, stream>>>(g, b); break;
+            case 4: flow_level_small_kernel<4, true><<<sgrd, 64, 0, stream>>>(g, b); break;
+            default: flow_level_small_kernel<2, true><<<sgrd, 64, 0, stream>>>(g, b); break;
         }
         return;
     }
     switch (ws) {
-        case 32: flow_level_small_kernel<32, false><<<grd, 256, 0, stream>>>(g, a); break;
-        case 16: flow_level_small_kernel<16, false><<<grd, 256, 0, stream>>>(g, a); break;
-        case 8: flow_level_small_kernel<8, false><<<grd, 256, 0, stream>>>(g, a); break;
-        case 4: flow_level_small_kernel<4, false><<<grd, 256, 0, stream>>>(g, a); break;
-        default: flow_level_small_kernel<2, false><<<grd, 256, 0, stream>>>(g, a); break;
+        case 32: flow_level_small_kernel<32, false><<<grd, 256, 0, stream>>>(g, b); break;
+        case 16: flow_level_small_kernel<16, false><<<grd, 256, 0, stream>>>(g, b); break;
+        case 8: flow_level_small_kernel<8, false><<<grd, 256, 0, stream>>>(g, b); break;
+        case 4: flow_level_small_kernel<4, false><<<grd, 256, 0, stream>>>(g, b); break;
+        default: flow_level_small_kernel<2, false><<<grd, 256, 0, stream>>>(g, b); break;
     }
 }
 
-void launch_flow_big_partial(const Geom& g, const FlowStep& a, hipStream_t stream) {
-    const dim3 grd((g.lw + 31) / 32, (g.lh + 31) / 32);
-    flow_big_partial_kernel<<<grd, 256, 0, stream>>>(g, a);
+void launch_flow_big_partial(const Geom& g, const FlowBatch& b, hipStream_t stream) {
+    // measured on MI355X (2160p HDR chain): 4 waves per workgroup 108.2 us, 2: 109.0 us, 1: 111.9 us (more atomics)
+    static const int wpb = getenv("HF_FLOW_BIG_WPB") ? atoi(getenv("HF_FLOW_BIG_WPB")) : 4;
+    const int th = 8 * (wpb == 1 || wpb == 2 ? wpb : 4);
+    const dim3 grd(xcd_grid((g.lw + 31) / 32, (g.lh + th - 1) / th, 1, b.n));
+    if (wpb == 1) flow_big_partial_kernel<1><<<grd, 64, 0, stream>>>(g, b);
+    else if (wpb == 2) flow_big_partial_kernel<2><<<grd, 128, 0, stream>>>(g, b);
+    else flow_big_partial_kernel<4><<<grd, 256, 0, stream>>>(g, b);
 }
 
-void launch_flow_big_argmin(const Geom& g, const FlowStep& a, hipStream_t stream) {
-    const int nwin = a.cur.nwx * a.cur.nwy;
-    flow_big_argmin_kernel<<<(nwin + 15) / 16, 256, 0, stream>>>(g, a);
+void launch_flow_big_argmin(const Geom& g, const FlowBatch& b, hipStream_t stream) {
+    const int nwin = b.s[0].cur.nwx * b.s[0].cur.nwy;
+    flow_big_argmin_kernel<<<dim3((nwin + 15) / 16, b.n), 256, 0, stream>>>(g, b);
 }
 
 void launch_expand_offsets(const Geom& g, const FlowLevel& last, int16_t* out, hipStream_t stream) {

@@ -69,20 +69,39 @@ struct FlowStep {
     PendingArgmin pend;      // previous large-window step still to be resolved (see above)
 };
 
+// The refinement chains of up to kMaxFlowBatch independent frame pairs of the SAME geometry and parameters run as
+// one set of launches: every kernel of the chain takes the whole batch and blockIdx.z selects the pair.  One
+// 480x270 chain is 135..1080 workgroups of latency-bound work per launch -- far too little for 256 CUs -- and
+// the device runs at most a handful of HW queues side by side, so a throughput driver (SURVEY.md 8(e):
+// independent pairs) gets its parallelism from the batch, not from more streams.  n == 1 is the drop-in path.
+constexpr int kMaxFlowBatch = 8;
+struct FlowBatch {
+    int n;
+    FlowStep s[kMaxFlowBatch];
+};
+struct BlurItem {
+    FlowLevel last;          // offsets of the last level (tx == nullptr: all zero)
+    int16_t* blurred;        // out [2][lh][lw]
+    uint32_t* packed;        // out x | y << 16 per grid point (what the fast warp kernel reads)
+    uint32_t* zero;          // window sums the (last) kernel of the chain clears for the next chain, or nullptr
+};
+struct BlurBatch {
+    int n;
+    BlurItem s[kMaxFlowBatch];
+};
+
 // Re-lay a freshly uploaded frame as phase planes (once per frame).
 void launch_prep_frame(const Geom& g, const PhaseLayout& pl, const void* frame, uint8_t* py, uint16_t* puv, hipStream_t stream);
 // Windows <= 32: X and Y step of one level in a single launch.
-void launch_flow_level_small(const Geom& g, const FlowStep& a, hipStream_t stream);
+void launch_flow_level_small(const Geom& g, const FlowBatch& b, hipStream_t stream);
 // Windows > 32, one axis: partial SAD sums (atomics), then argmin + table update.
-void launch_flow_big_partial(const Geom& g, const FlowStep& a, hipStream_t stream);
-void launch_flow_big_argmin(const Geom& g, const FlowStep& a, hipStream_t stream);
+void launch_flow_big_partial(const Geom& g, const FlowBatch& b, hipStream_t stream);
+void launch_flow_big_argmin(const Geom& g, const FlowBatch& b, hipStream_t stream);
 // m_offsetArray view ([2][lh][lw] int16) of the last level, for parity taps.
 void launch_expand_offsets(const Geom& g, const FlowLevel& last, int16_t* out, hipStream_t stream);
 // blurFlowKernel with a runtime radius (4 == reference); in: offsets of the last level, out: [2][lh][lw].
-// Also writes `packed` = x | y << 16 per grid point (what the fast warp kernel reads).
-// zero/zero_count: buffer this (last) kernel of the chain clears for the next chain (window sums).
-void launch_blur_flow(const Geom& g, const FlowLevel& last, int16_t* blurred, uint32_t* packed,
-                      int radius, uint32_t* zero, int zero_count, hipStream_t stream);
+// zero_count: elements of BlurItem::zero to clear.
+void launch_blur_flow(const Geom& g, const BlurBatch& b, int radius, int zero_count, hipStream_t stream);
 void launch_pack_flow(const Geom& g, const int16_t* flow, uint32_t* packed, hipStream_t stream);
 constexpr int kMaxWarpOutputs = 6;   // outputs of one source period at 24 -> 120 fps (HopperRender.cpp:944-948)
 // All outputs of one source period in ONE launch (fast path only: modes 0-2 etc.); returns false when the shape

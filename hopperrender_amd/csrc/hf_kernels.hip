@@ -56,9 +56,12 @@ __device__ __forceinline__ int mirror_flow(int pos, int dim) {  // blurFlowKerne
 
 // Both planes per workgroup (sequentially through the same LDS tile) so that the kernel can also
 // emit the packed (x | y << 16) copy of the blurred flow that warp_fast_kernel reads with one load.
-__global__ __launch_bounds__(256) void blur_flow_kernel(const FlowLevel L, int16_t* __restrict__ blurred,
-                                                         uint32_t* __restrict__ packed, int lw, int lh, int r,
-                                                         uint32_t* __restrict__ zero, int zero_count) {
+__global__ __launch_bounds__(256) void blur_flow_kernel(const BlurBatch batch, int lw, int lh, int r, int zero_count) {
+    const BlurItem& it = batch.s[blockIdx.z];   // blockIdx.z: pair of the batch
+    const FlowLevel& L = it.last;
+    int16_t* __restrict__ blurred = it.blurred;
+    uint32_t* __restrict__ packed = it.packed;
+    uint32_t* __restrict__ zero = it.zero;
     if (zero) {   // the refinement steps are done with the window sums: clear them for the next chain
         const int nthreads = gridDim.x * gridDim.y * 256;
         for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < zero_count; i += nthreads) zero[i] = 0u;
@@ -593,12 +596,11 @@ __global__ void rcp_probe_kernel(const float* in, float* out, int n) {
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-void launch_blur_flow(const Geom& g, const FlowLevel& last, int16_t* blurred, uint32_t* packed,
-                      int radius, uint32_t* zero, int zero_count, hipStream_t stream) {
-    const dim3 grd((g.lw + 15) / 16, (g.lh + 15) / 16, 1);
+void launch_blur_flow(const Geom& g, const BlurBatch& b, int radius, int zero_count, hipStream_t stream) {
+    const dim3 grd((g.lw + 15) / 16, (g.lh + 15) / 16, b.n);
     const int T = 16 + 2 * radius;
     const size_t smem = (size_t)T * 16 * sizeof(int) + (size_t)T * T * sizeof(int16_t);
-    blur_flow_kernel<<<grd, 256, smem, stream>>>(last, blurred, packed, g.lw, g.lh, radius, zero, zero_count);
+    blur_flow_kernel<<<grd, 256, smem, stream>>>(b, g.lw, g.lh, radius, zero_count);
 }
 
 void launch_pack_flow(const Geom& g, const int16_t* flow, uint32_t* packed, hipStream_t stream) {

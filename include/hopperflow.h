@@ -161,6 +161,25 @@ int hf_interpolate_period(hf_ctx* ctx, const void* device_frame, int n_out, cons
 /* update_and_flow = 0: only the warps of the period (no updateFrame, no calculateOpticalFlow). */
 int hf_interpolate_period_ex(hf_ctx* ctx, const void* device_frame, int n_out, const float* t, void* const* device_out, int mode,
                              int update_and_flow);
+/* ---- Batched flow calculation (throughput drivers) -------------------------------------------------------------
+ * The reference computes one pair at a time (opticalFlowCalcSDR.cpp:44-139: 66 enqueues per call).  Its flow grid is
+ * at most 480x270, so one refinement chain is a sequence of small latency-bound launches that cannot fill 256 CUs.
+ * A driver that converts INDEPENDENT frame pairs groups up to 8 contexts of identical
+ * geometry/parameters into a batch: hf_batch_calculate_optical_flow() runs the calculateOpticalFlow() of every
+ * member as ONE set of launches (each kernel handles all pairs).  Results per member are bit-identical to
+ * hf_calculate_optical_flow(member).
+ *   - members: HF_FLAG_ASYNC contexts, one stream each (no DUAL/SHARED/PRIORITY flags, no async host I/O), same
+ *     device, frame geometry, iterations, blur radius; at call time the same search radius / delta / neighbor scalar.
+ *   - while the batch exists all members issue on ONE stream (the first member's): their hf_update_frame_device*,
+ *     hf_interpolate_period_ex(..., update_and_flow = 0), hf_sync ... calls keep working and stay in program order
+ *     with the batched chain.  Destroy the batch before its members. */
+typedef struct hf_batch hf_batch;
+int hf_batch_create(hf_ctx* const* members, int n, hf_batch** out_batch);
+void hf_batch_destroy(hf_batch* batch);
+int hf_batch_calculate_optical_flow(hf_batch* batch);
+int hf_batch_size(const hf_batch* batch);
+const char* hf_batch_last_error(const hf_batch* batch);   /* batch == NULL: error of the last failed hf_batch_create */
+
 /* Device-to-device copy of the output frame into caller-owned device memory. */
 int hf_download_frame_device(hf_ctx* ctx, void* device_out);
 /* Redirect warp/copy output into caller-owned device memory (NULL restores the internal buffer). */

@@ -1,0 +1,111 @@
+"""GPU: hf_batch (calculateOpticalFlow of several contexts as one set of launches, include/hopperflow.h) must give
+every member exactly what its own hf_calculate_optical_flow gives -- and through it the reference's results."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def calc_for(hdr, H, W, **kw):
+    from hopperrender_amd import capi
+    from hopperrender_amd.calc import OpticalFlowCalcHDR, OpticalFlowCalcSDR
+    return (OpticalFlowCalcHDR if hdr else OpticalFlowCalcSDR)(H, W, 0, 0, 8, 6, 0.0, 255.0, 270, flags=capi.HF_FLAG_ASYNC, **kw)
+
+
+@pytest.mark.parametrize("hdr,H,W,n,R", [(0, 360, 640, 3, 8), (1, 360, 640, 8, 16), (0, 1080, 1920, 4, 16), (1, 2160, 3840, 2, 5),
+                                        (0, 274, 486, 5, 16)])
+def test_batch_equals_single_contexts(native_lib, hdr, H, W, n, R):
+    from hopperrender_amd import synth
+    from hopperrender_amd.calc import DeviceBuffer, FlowBatch
+    scenes = [synth.Scene(H, W, bool(hdr), 100 + 7 * i) for i in range(n)]
+    frames = [[sc.frame(k) for k in range(6)] for sc in scenes]
+    singles = [calc_for(hdr, H, W, search_radius=R) for _ in range(n)]
+    members = [calc_for(hdr, H, W, search_radius=R) for _ in range(n)]
+    batch = FlowBatch(members)
+    assert len(batch) == n
+    ts = [0.0, 0.3996, 0.7992]
+    outs_s = [[DeviceBuffer(singles[0].output_frame_bytes) for _ in ts] for _ in range(n)]
+    outs_b = [[DeviceBuffer(singles[0].output_frame_bytes) for _ in ts] for _ in range(n)]
+    for i in range(n):
+        for k in range(2):
+            singles[i].updateFrame(frames[i][k])
+            members[i].updateFrame(frames[i][k])
+    for k in range(2, 6):            # four rounds: every ring phase / flow ping-pong phase, graph capture and replay
+        for i in range(n):
+            singles[i].updateFrame(frames[i][k])
+            singles[i].calculateOpticalFlow()
+            members[i].updateFrame(frames[i][k])
+        batch.calculateOpticalFlow()
+        for i in range(n):
+            singles[i].interpolateOnly(ts, [b.ptr for b in outs_s[i]], 2)
+            members[i].interpolateOnly(ts, [b.ptr for b in outs_b[i]], 2)
+        for i in range(n):
+            singles[i].sync()
+            members[i].sync()
+            assert members[i].m_totalFrameDelta == singles[i].m_totalFrameDelta, (k, i)
+            assert (members[i].readOffsets() == singles[i].readOffsets()).all(), (k, i)
+            assert (members[i].readBlurredFlow(1) == singles[i].readBlurredFlow(1)).all(), (k, i)
+            assert (members[i].readBlurredFlow(0) == singles[i].readBlurredFlow(0)).all(), (k, i)
+            dt = np.uint16 if hdr else np.uint8
+            for a, b in zip(outs_s[i], outs_b[i]):
+                assert (a.download(dt) == b.download(dt)).all(), (k, i)
+    # distinct scenes must give distinct flows (the members are not aliased to one pair)
+    assert any((members[0].readBlurredFlow(1) != members[i].readBlurredFlow(1)).any() for i in range(1, n))
+    batch.close()
+    # after the batch is gone the members are ordinary contexts again
+    members[0].updateFrame(frames[0][0]); members[0].calculateOpticalFlow()
+    singles[0].updateFrame(frames[0][0]); singles[0].calculateOpticalFlow()
+    members[0].sync(); singles[0].sync()
+    assert (members[0].readBlurredFlow(1) == singles[0].readBlurredFlow(1)).all()
+    for c in singles + members:
+        c.close()
+
+
+def test_batch_matches_reference_golden(native_lib):
+    """Members fed with the golden case's frames reproduce the reference's flow (pins the batch to the reference)."""
+    from helpers import ALL_GOLDEN, Golden
+    from hopperrender_amd import capi
+    from hopperrender_amd.calc import FlowBatch, OpticalFlowCalcHDR, OpticalFlowCalcSDR
+    name = [n for n in ALL_GOLDEN if "180" in n or "360" in n][0]
+    g = Golden(name)
+    frames = g.frames()
+    key = g.keys[0]
+    R, delta, nb = g.params(key)
+    cls = OpticalFlowCalcHDR if g.case["hdr"] else OpticalFlowCalcSDR
+    ms = [cls(g.case["H"], g.case["W"], g.case["si"], g.case["so"], delta, nb, 0.0, 255.0, 270, flags=capi.HF_FLAG_ASYNC, search_radius=R)
+          for _ in range(3)]
+    b = FlowBatch(ms)
+    for m in ms:
+        for f in frames[:3]:
+            m.updateFrame(f)
+    b.calculateOpticalFlow()
+    for m in ms:
+        m.sync()
+        assert m.m_totalFrameDelta == g.meta[key]["stats_a"]["total_frame_delta"]
+        assert (m.readOffsets() == g.arr(key, "off_a")).all()
+        assert (m.readBlurredFlow(1) == g.arr(key, "blur_a")).all()
+    b.close()
+    for m in ms:
+        m.close()
+
+
+def test_batch_rejects_incompatible_members(native_lib):
+    from hopperrender_amd import capi
+    from hopperrender_amd.calc import FlowBatch, OpticalFlowCalcSDR
+    a = calc_for(0, 360, 640)
+    b = calc_for(0, 180, 320)
+    with pytest.raises(capi.HopperFlowError):
+        FlowBatch([a, b])
+    with pytest.raises(capi.HopperFlowError):
+        FlowBatch([a, a])
+    sync_ctx = OpticalFlowCalcSDR(360, 640, 0, 0, 8, 6, 0.0, 255.0, 270)   # blocking context: not batchable
+    with pytest.raises(capi.HopperFlowError):
+        FlowBatch([a, sync_ctx])
+    c = calc_for(0, 360, 640)
+    bt = FlowBatch([a, c])
+    c.m_opticalFlowSearchRadius = 9          # members must agree on the parameters at call time
+    with pytest.raises(capi.HopperFlowError):
+        bt.calculateOpticalFlow()
+    bt.close()
+    for x in (a, b, c, sync_ctx):
+        x.close()

@@ -22,5 +22,9 @@ for flags in (capi.HF_FLAG_ASYNC, capi.HF_FLAG_ASYNC | capi.HF_FLAG_NO_GRAPH):
     t0 = time.perf_counter()
     for i in range(n): c.interpolatePeriod(pool[i % 4].ptr, ts, ptrs, 2)
     t1 = time.perf_counter(); c.sync(); t2 = time.perf_counter()
+    t3 = time.perf_counter()
+    for i in range(n): c.interpolatePeriod(pool[i % 4].ptr, [], [], 2)
+    t4 = time.perf_counter(); c.sync(); t5 = time.perf_counter()
+    print(f"flags {flags}: chain only: host enqueue {1e6*(t4-t3)/n:.1f} us per period; total incl. GPU {1e6*(t5-t3)/n:.1f} us per period")
     print(f"flags {flags}: host enqueue {1e6*(t1-t0)/n:.1f} us per period; total incl. GPU {1e6*(t2-t0)/n:.1f} us per period")
     c.close()
