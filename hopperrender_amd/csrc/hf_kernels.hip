@@ -12,6 +12,7 @@
 // (measured, tests/golden/levels_ramp.npz): "a*u + b*t" is contracted to fma(a, u, b*t); the
 // division in apply_levels* is x * v_rcp_f32(y); "q*max + mid" is fma(q, max, mid).
 #include "hf_kernels.h"
+#include <type_traits>
 
 #include <cstdlib>
 
@@ -308,6 +309,64 @@ __device__ __forceinline__ Run<E, GROUP> load_run_uv(const E* __restrict__ row, 
     return r;
 }
 
+// The same runs through DWORD-ALIGNED loads + a funnel shift.  Measured on MI355X (tools/ubench/gather_rate.hip,
+// L1-resident data, clocks per wave instruction): global_load_dwordx4 at a 4-byte aligned address 17.5, at a
+// 2-byte aligned one 65.8; dword 6.1 vs 17.3; dwordx2 17.3 vs 33.4 -- every access that is not dword-aligned takes
+// a slow path in the texture addresser.  A displaced run starts at an arbitrary element, so half (16-bit) or three
+// quarters (8-bit) of the plain loads were slow ones.  Here: NDW + 1 aligned dwords, v_alignbit_b32 per dword.
+// Requires a dword-aligned frame base and row pitch, and W * sizeof(E) % 4 == 0 (every dword that holds a needed
+// byte then lies inside the row; the one extra dword that holds none when the run IS aligned is redirected).
+template <typename E, int GROUP>
+__device__ __forceinline__ Run<E, GROUP> load_run_dw(const unsigned char* __restrict__ row, int x) {
+    constexpr int NDW = GROUP * (int)sizeof(E) / 4;
+    const unsigned boff = (unsigned)x * (unsigned)sizeof(E);
+    const unsigned sh = (boff & 3u) * 8u;
+    const uint32_t* __restrict__ p = (const uint32_t*)(row + (boff & ~3u));
+    struct __attribute__((aligned(4))) DW { uint32_t d[NDW]; } w;
+    __builtin_memcpy(&w, p, sizeof(w));
+    const uint32_t ext = p[sh ? NDW : 0];
+    uint32_t o[NDW];
+#pragma unroll
+    for (int j = 0; j < NDW; j++) o[j] = __builtin_amdgcn_alignbit(j + 1 < NDW ? w.d[j + 1] : ext, w.d[j], sh);
+    Run<E, GROUP> r;
+    __builtin_memcpy(r.v, o, sizeof(o));
+    return r;
+}
+// Chroma: elements [e, e + GROUP + 1] (the run at e plus the pair behind it) are always inside the row for an
+// interior run; slot i takes element e + i (i even) or e + 2o + i (i odd): one v_perm_b32 per dword.
+template <typename E, int GROUP>
+__device__ __forceinline__ Run<E, GROUP> load_run_uv_dw(const unsigned char* __restrict__ row, int x_first) {
+    constexpr int NDW = GROUP * (int)sizeof(E) / 4;
+    const int e = x_first & ~1;
+    const unsigned odd = (unsigned)x_first & 1u;
+    const unsigned boff = (unsigned)e * (unsigned)sizeof(E);
+    const unsigned sh = (boff & 3u) * 8u;          // 0 for 16-bit elements, 0 or 16 for 8-bit ones
+    const uint32_t* __restrict__ p = (const uint32_t*)(row + (boff & ~3u));
+    struct __attribute__((aligned(4))) DW { uint32_t d[NDW + 1]; } w;
+    __builtin_memcpy(&w, p, sizeof(w));
+    uint32_t L[NDW + 1];
+#pragma unroll
+    for (int j = 0; j < NDW; j++) L[j] = __builtin_amdgcn_alignbit(w.d[j + 1], w.d[j], sh);
+    L[NDW] = w.d[NDW] >> sh;
+    const uint32_t sel = sizeof(E) == 2 ? (odd ? 0x07060100u : 0x03020100u) : (odd ? 0x05020300u : 0x03020100u);
+    uint32_t o[NDW];
+#pragma unroll
+    for (int j = 0; j < NDW; j++) o[j] = __builtin_amdgcn_perm(L[j + 1], L[j], sel);
+    Run<E, GROUP> r;
+    __builtin_memcpy(r.v, o, sizeof(o));
+    return r;
+}
+
+// GROUP elements of a plane row starting at element x (luma) / the chroma run for x_first = x
+template <typename E, int G, int CZ, bool DW>
+__device__ __forceinline__ Run<E, G> get_run(const E* __restrict__ rowp, int x) {
+    if constexpr (DW && G * sizeof(E) >= 4) {   // (smaller groups are never launched on the fast path)
+        return CZ ? load_run_uv_dw<E, G>((const unsigned char*)rowp, x) : load_run_dw<E, G>((const unsigned char*)rowp, x);
+    } else {
+        return CZ ? load_run_uv<E, G>(rowp, x) : load_run<E, G>(rowp + x);
+    }
+}
+
 // Body of the fast path for one plane (CZ = 0 luma, 1 chroma), everything plane-dependent is
 // compile-time so the per-element code is straight-line.
 typedef float float2v __attribute__((ext_vector_type(2)));
@@ -319,7 +378,7 @@ template <> struct StoreVec<8> { using type = uint2; };
 #ifndef HF_WARP_PIPELINE
 #define HF_WARP_PIPELINE 1   // request the source runs of output ti + 1 before blending output ti
 #endif
-template <typename E, int GROUP, int ROWS, int MODE, int CZ, int VB>
+template <typename E, int GROUP, int ROWS, int MODE, int CZ, int VB, bool DW>
 __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a, int cy0, int cx0) {
     using T = ElemTraits<E>;
     using SV = typename StoreVec<VB>::type;
@@ -401,7 +460,7 @@ __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a,
             const int cy = min(cy0 + r, dim_y - 1);
             if (need_a) {
                 const E* rowp = A + (size_t)mirror_warp(cy + dya[0], dim_y) * Si;
-                const Run<E, VEC> w = CZ ? load_run_uv<E, VEC>(rowp, xa[0]) : load_run<E, VEC>(rowp + xa[0]);
+                const Run<E, VEC> w = get_run<E, VEC, CZ, DW>(rowp, xa[0]);
 #pragma unroll
                 for (int k = 0; k < NG; k++)
 #pragma unroll
@@ -409,7 +468,7 @@ __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a,
             }
             if (need_b) {
                 const E* rowp = B + (size_t)mirror_warp(cy + dyb[0], dim_y) * Si;
-                const Run<E, VEC> w = CZ ? load_run_uv<E, VEC>(rowp, xb[0]) : load_run<E, VEC>(rowp + xb[0]);
+                const Run<E, VEC> w = get_run<E, VEC, CZ, DW>(rowp, xb[0]);
 #pragma unroll
                 for (int k = 0; k < NG; k++)
 #pragma unroll
@@ -424,11 +483,11 @@ __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a,
             for (int k = 0; k < NG; k++) {
                 if (need_a) {
                     const E* rowp = A + (size_t)mirror_warp(cy + dya[k], dim_y) * Si;
-                    S.ra[r][k] = CZ ? load_run_uv<E, GROUP>(rowp, xa[k]) : load_run<E, GROUP>(rowp + xa[k]);
+                    S.ra[r][k] = get_run<E, GROUP, CZ, DW>(rowp, xa[k]);
                 }
                 if (need_b) {
                     const E* rowp = B + (size_t)mirror_warp(cy + dyb[k], dim_y) * Si;
-                    S.rb[r][k] = CZ ? load_run_uv<E, GROUP>(rowp, xb[k]) : load_run<E, GROUP>(rowp + xb[k]);
+                    S.rb[r][k] = get_run<E, GROUP, CZ, DW>(rowp, xb[k]);
                 }
             }
         }
@@ -442,7 +501,7 @@ __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a,
                 if (need_a) {
                     const E* rowp = A + (size_t)mirror_warp(cy + dya[k], dim_y) * Si;
                     if (xa[k] >= 1 && xa[k] + GROUP - 1 <= W - 2) {
-                        S.ra[r][k] = CZ ? load_run_uv<E, GROUP>(rowp, xa[k]) : load_run<E, GROUP>(rowp + xa[k]);
+                        S.ra[r][k] = get_run<E, GROUP, CZ, DW>(rowp, xa[k]);
                     } else {
 #pragma unroll
                         for (int i = 0; i < GROUP; i++) {
@@ -454,7 +513,7 @@ __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a,
                 if (need_b) {
                     const E* rowp = B + (size_t)mirror_warp(cy + dyb[k], dim_y) * Si;
                     if (xb[k] >= 1 && xb[k] + GROUP - 1 <= W - 2) {
-                        S.rb[r][k] = CZ ? load_run_uv<E, GROUP>(rowp, xb[k]) : load_run<E, GROUP>(rowp + xb[k]);
+                        S.rb[r][k] = get_run<E, GROUP, CZ, DW>(rowp, xb[k]);
                     } else {
 #pragma unroll
                         for (int i = 0; i < GROUP; i++) {
@@ -504,8 +563,15 @@ __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a,
                         const float2v bk = {lv.black, lv.black}, rcp = {lv.rcp_y, lv.rcp_y}, mx = {T::maxv, T::maxv};
                         f = ((bl - bk) * rcp) * mx;                                       // warpFrameKernelSDR.h:3-5
                     }
-                    v[k * GROUP + i] = (E)(unsigned)__builtin_amdgcn_fmed3f(f.x, 0.0f, T::maxv);
-                    v[k * GROUP + i + 1] = (E)(unsigned)__builtin_amdgcn_fmed3f(f.y, 0.0f, T::maxv);
+                    if (sizeof(E) == 2) {   // v_cvt_u32_f32 truncates and clamps negatives to 0, the pack saturates at 65535
+                        typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
+                        const ushort2v pk = __builtin_amdgcn_cvt_pk_u16((unsigned)f.x, (unsigned)f.y);
+                        v[k * GROUP + i] = (E)pk.x;
+                        v[k * GROUP + i + 1] = (E)pk.y;
+                    } else {
+                        v[k * GROUP + i] = (E)(unsigned)__builtin_amdgcn_fmed3f(f.x, 0.0f, T::maxv);
+                        v[k * GROUP + i + 1] = (E)(unsigned)__builtin_amdgcn_fmed3f(f.y, 0.0f, T::maxv);
+                    }
                 }
             }
         }
@@ -537,7 +603,7 @@ __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a,
 #endif
 // VB = bytes of output per thread and row: 16, or 8 for small frames (<= 1080p 8-bit), where 16-byte threads
 // leave too few waves to hide the per-wave latency chain (one round of fat waves: 9.4 us for 9.3 MB).
-template <typename E, int GROUP, int ROWS, int MODE, int VB>
+template <typename E, int GROUP, int ROWS, int MODE, int VB, bool DW>
 __global__ __launch_bounds__(64 * HF_WARP_WAVES) void warp_fast_kernel(const Geom g, const WarpArgs a, int y_groups) {
     constexpr int VEC = VB / sizeof(E);
     // row group: luma groups first, then chroma; one row group per wave => the plane test is a scalar branch
@@ -558,8 +624,8 @@ __global__ __launch_bounds__(64 * HF_WARP_WAVES) void warp_fast_kernel(const Geo
     const int cx0 = ((tile - rg * wpr) * 64 + (threadIdx.x & 63)) * VEC;
     const int uv_groups = ((g.H >> 1) + ROWS - 1) / ROWS;
     if (rg >= y_groups + uv_groups || cx0 >= g.W) return;
-    if (rg >= y_groups) warp_fast_body<E, GROUP, ROWS, MODE, 1, VB>(g, a, (rg - y_groups) * ROWS, cx0);
-    else warp_fast_body<E, GROUP, ROWS, MODE, 0, VB>(g, a, rg * ROWS, cx0);
+    if (rg >= y_groups) warp_fast_body<E, GROUP, ROWS, MODE, 1, VB, DW>(g, a, (rg - y_groups) * ROWS, cx0);
+    else warp_fast_body<E, GROUP, ROWS, MODE, 0, VB, DW>(g, a, rg * ROWS, cx0);
 }
 
 template <typename E, int VEC, bool ALIGNED>
@@ -622,31 +688,31 @@ static bool launch_warp_fast(const Geom& g, const WarpArgs& a, hipStream_t strea
     const bool fast = aligned && a.mode >= 0 && a.mode <= 2 && (a.mode != 2 || sane) && a.flow_xy && (g.in_stride % 2) == 0 &&
                       g.W >= 2 * VEC && group * (int)sizeof(E) >= 4 && VEC % group == 0 && VEC / group <= 4;
     if (!fast) return false;
-    // rows per thread (must divide the 2^rs rows of a flow cell)
-    static const int rows_env = getenv("HF_WARP_ROWS") ? atoi(getenv("HF_WARP_ROWS")) : 0;
-    int rows = 2;  // measured on MI355X, 2160p HDR blend: 1 row 25.9 us, 2 rows 24.3 us, 4 rows 30.2 us
-    if (ALL_ROWS && (rows_env == 1 || rows_env == 2 || (rows_env == 4 && g.rs >= 2))) rows = rows_env;
+    const int rows = 2;  // rows per thread (divides the 2^rs rows of a flow cell); measured on MI355X, 2160p HDR blend: 1 row 25.9 us, 2 rows 24.3 us, 4 rows 30.2 us
     const int y_groups = (g.H + rows - 1) / rows, uv_groups = ((g.H >> 1) + rows - 1) / rows;
     const int wpr = (g.W + 64 * VEC - 1) / (64 * VEC);
     const int n_blocks = (wpr * (y_groups + uv_groups) + HF_WARP_WAVES - 1) / HF_WARP_WAVES;
     const dim3 fg(((n_blocks + 7) / 8) * 8);
-#define HF_WARP_FAST(G, R)                                                                   \
+#define HF_WARP_FAST(G, D)                                                                   \
     do {                                                                                     \
         /* ev0/ev1 (may be null): timestamps of the dispatch itself, like rocprof's kernel trace */ \
-        if (a.mode == 0) hipExtLaunchKernelGGL((warp_fast_kernel<E, G, R, 0, VB>), fg, dim3(64 * HF_WARP_WAVES), 0, stream, ev0, ev1, 0, g, a, y_groups);      \
-        else if (a.mode == 1) hipExtLaunchKernelGGL((warp_fast_kernel<E, G, R, 1, VB>), fg, dim3(64 * HF_WARP_WAVES), 0, stream, ev0, ev1, 0, g, a, y_groups); \
-        else hipExtLaunchKernelGGL((warp_fast_kernel<E, G, R, 2, VB>), fg, dim3(64 * HF_WARP_WAVES), 0, stream, ev0, ev1, 0, g, a, y_groups);                  \
+        if (a.mode == 0) hipExtLaunchKernelGGL((warp_fast_kernel<E, G, 2, 0, VB, D>), fg, dim3(64 * HF_WARP_WAVES), 0, stream, ev0, ev1, 0, g, a, y_groups);      \
+        else if (a.mode == 1) hipExtLaunchKernelGGL((warp_fast_kernel<E, G, 2, 1, VB, D>), fg, dim3(64 * HF_WARP_WAVES), 0, stream, ev0, ev1, 0, g, a, y_groups); \
+        else hipExtLaunchKernelGGL((warp_fast_kernel<E, G, 2, 2, VB, D>), fg, dim3(64 * HF_WARP_WAVES), 0, stream, ev0, ev1, 0, g, a, y_groups);                  \
     } while (0)
-#define HF_WARP_ROWS(R)                                   \
+#define HF_WARP_GROUP(D)                                  \
     do {                                                  \
-        if (group == VEC) HF_WARP_FAST(VEC, R);           \
-        else if (group == VEC / 2) HF_WARP_FAST(VEC / 2, R); \
-        else HF_WARP_FAST(VEC / 4, R);                    \
+        if (group == VEC) HF_WARP_FAST(VEC, D);           \
+        else if (group == VEC / 2) HF_WARP_FAST(VEC / 2, D); \
+        else HF_WARP_FAST(VEC / 4, D);                    \
     } while (0)
-    if (ALL_ROWS && rows == 4) HF_WARP_ROWS(4);
-    else if (ALL_ROWS && rows == 1) HF_WARP_ROWS(1);
-    else HF_WARP_ROWS(2);
-#undef HF_WARP_ROWS
+    // dword-aligned source loads (load_run_dw) need dword-aligned frames and rows that end on a dword
+    static const bool dw_env = !(getenv("HF_WARP_DW") && atoi(getenv("HF_WARP_DW")) == 0);
+    const bool dw = dw_env && (((uintptr_t)a.frame12 | (uintptr_t)a.frame21) & 3) == 0 && ((size_t)g.in_stride * sizeof(E)) % 4 == 0 &&
+                    ((size_t)g.W * sizeof(E)) % 4 == 0 && ((size_t)g.H * g.in_stride * sizeof(E)) % 4 == 0;
+    if (dw) HF_WARP_GROUP(true);
+    else HF_WARP_GROUP(false);
+#undef HF_WARP_GROUP
 #undef HF_WARP_FAST
     return true;
 }

@@ -5,6 +5,8 @@
 #include <cstring>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
+template <typename T> __device__ __forceinline__ unsigned long long sum(T v) { return (unsigned long long)v; }
+template <> __device__ __forceinline__ unsigned long long sum<uint4>(uint4 v) { return v.x + v.y + v.z + v.w; }
 template <typename T> __device__ __forceinline__ T ld(const unsigned char* p) { T v; __builtin_memcpy(&v, p, sizeof(T)); return v; }
 
 // every lane issues ITER x 16 independent loads at base + lane * lane_stride + k * k_stride + shift  (all inside a 32 KB window)
@@ -21,7 +23,7 @@ __global__ __launch_bounds__(256) void k_gather(const unsigned char* __restrict_
             v[k] = ld<T>(base + off);
         }
 #pragma unroll
-        for (int k = 0; k < 16; k++) acc += (unsigned long long)v[k];
+        for (int k = 0; k < 16; k++) acc += sum(v[k]);
     }
     if (acc == 0x1234567ull) out[0] = acc;
 }
@@ -56,6 +58,10 @@ int main() {
     run<unsigned long long>("u64 contiguous lanes +1 byte", buf, out, 8, 64, 1);
     run<unsigned long long>("u64 contiguous lanes +4 bytes", buf, out, 8, 64, 4);
 
+    run<uint4>("u128 contiguous lanes aligned", buf, out, 16, 1024, 0);
+    run<uint4>("u128 contiguous lanes +2 bytes", buf, out, 16, 1024, 2);
+    run<uint4>("u128 contiguous lanes +4 bytes", buf, out, 16, 1024, 4);
+    run<uint4>("u128 contiguous lanes +8 bytes", buf, out, 16, 1024, 8);
     // flow-kernel-like: 8 lanes per row (4 B apart), rows 640 B apart
     run<unsigned>("u32 8 lanes/row, rows 640B, aligned", buf, out, 4 + 0, 640, 0);
     // each lane its own row (stride 644: rows + 4 B)
