@@ -25,6 +25,13 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# HIP multiplexes all streams of a process onto GPU_MAX_HW_QUEUES hardware queues (default 4, one of which the
+# null stream takes): two HIP streams that share a queue run strictly one after the other.  Measured on MI355X
+# (tools/scan3.sh): 4 pair streams on 4 queues of their own 44.0k frames/s vs 40.0k on 3 shared ones; with 6 or more
+# queues in use the device gets slower again (31k).  So: 5 queues = 1 (null stream) + 4 for the pair streams /
+# batches.  Must be set before the HIP runtime initialises; an explicit setting by the caller wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "5")
+
 WORKLOADS = {
     # name: (hdr, H, W, target frame time in 100ns units, description)   source = 23.976 fps
     "hdr2160_24to120": (1, 2160, 3840, 83333, "3840x2160 HDR (P010), 24->120 fps, R=16, full pyramid, blend"),
@@ -45,8 +52,8 @@ def parse_args():
     ap.add_argument("--radius", type=int, default=16)
     ap.add_argument("--neighbor", type=int, default=6)
     ap.add_argument("--blur-radius", type=int, default=4)
-    ap.add_argument("--streams", type=int, default=6, help="independent frame-pair streams per GPU")
-    ap.add_argument("--batch", type=int, default=1,
+    ap.add_argument("--streams", type=int, default=8, help="independent frame-pair streams per GPU")
+    ap.add_argument("--batch", type=int, default=2,
                     help="pair streams per flow batch (hf_batch): the refinement chains of `batch` independent pairs run as one "
                          "set of launches on one HIP stream; streams/batch batches run side by side")
     ap.add_argument("--pool", type=int, default=6, help="distinct synthetic source frames resident in HBM, per pair stream")
@@ -221,6 +228,8 @@ def main():
 
     out_ptrs = [[b.ptr for b in bufs] for bufs in outbufs]
     batches = []
+    if a.batch > 1 and (a.dual_stream_contexts or a.shared_warp_stream or a.priority_streams):
+        a.batch = 1          # hf_batch members are single-stream contexts
     if a.batch > 1:
         from hopperrender_amd.calc import FlowBatch
         if a.streams % a.batch:
@@ -364,11 +373,12 @@ def main():
             "dtype": "u16" if hdr else "u8", "data": "synthetic",
             "config": {"workload": a.workload, "description": desc, "search_radius": a.radius,
                        "delta_scalar": 8, "neighbor_scalar": a.neighbor, "blur_radius": a.blur_radius,
-                       "pair_streams_per_gpu": a.streams, "flow_batch": a.batch, "warp_stream": "shared per GPU" if a.shared_warp_stream else ("own stream, overlapping the context's flow chain" if a.dual_stream_contexts else "same stream as the flow chain"), "source_frames": "copied into the ring" if a.copy_in else "referenced in place (zero-copy)", "source_periods_per_step": a.streams,
+                       "pair_streams_per_gpu": a.streams, "flow_batch": a.batch, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "warp_stream": "shared per GPU" if a.shared_warp_stream else ("own stream, overlapping the context's flow chain" if a.dual_stream_contexts else "same stream as the flow chain"), "source_frames": "copied into the ring" if a.copy_in else "referenced in place (zero-copy)", "source_periods_per_step": a.streams,
                        "output_frames_total": int(frames_total), "parallelism": f"pair-sharded x{n_gpus}, no collective",
                        "frame_bytes": F, "flow_grid": [st["low_width"], st["low_height"]], "res_scalar": st["res_scalar"]},
             "ms_per_flow_calc": round(prof["flow_ms"] / prof["flow_chains"], 4) if prof["flow_chains"] else None,
-            "ms_per_flow_calc_note": "device time of one refinement chain + blur while the other pair streams keep the GPU busy",
+            "ms_per_flow_calc_note": "device time of one refinement chain + blur while the other pair streams keep the GPU busy"
+                                     + (f"; chains run {a.batch} pairs per launch (hf_batch): this is the batch's time / {a.batch}" if a.batch > 1 else ""),
             "ms_per_flow_calc_isolated": round(isolated["flow_chain_us"] / 1e3, 4) if isolated else None,
             "roofline": roof,
         }

@@ -357,6 +357,12 @@ __device__ __forceinline__ Run<E, GROUP> load_run_uv_dw(const unsigned char* __r
     return r;
 }
 
+// mirrorCoordinate without branches (same values as mirror_warp): low side max(p, 1 - p), high side min(., 2d - 4 - p)
+__device__ __forceinline__ int mirror_warp_bl(int pos, int dim) {
+    const int r = min(max(pos, 1 - pos), 2 * dim - 4 - pos);
+    return min(max(r, 1), dim - 2);
+}
+
 // GROUP elements of a plane row starting at element x (luma) / the chroma run for x_first = x
 template <typename E, int G, int CZ, bool DW>
 __device__ __forceinline__ Run<E, G> get_run(const E* __restrict__ rowp, int x) {
@@ -454,12 +460,23 @@ __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a,
         if (need_a) merged = merged && xa[k] == xa[0] + k * GROUP && dya[k] == dya[0];
         if (need_b) merged = merged && xb[k] == xb[0] + k * GROUP && dyb[k] == dyb[0];
     }
+    // rows: mirrorCoordinate is the identity on [1, dim_y - 2] -- one wave-uniform test per output instead of a
+    // reflection per row and frame
+    bool y_inside = true;
+    const int cy_lo = cy0, cy_hi = min(cy0 + ROWS - 1, dim_y - 1);
+#pragma unroll
+    for (int k = 0; k < NG; k++) {
+        if (need_a) y_inside = y_inside && cy_lo + dya[k] >= 1 && cy_hi + dya[k] <= dim_y - 2;
+        if (need_b) y_inside = y_inside && cy_lo + dyb[k] >= 1 && cy_hi + dyb[k] <= dim_y - 2;
+    }
+    const bool all_y_inside = __builtin_amdgcn_ballot_w64(!y_inside) == 0;
+    auto row_of = [&](const int p) { return all_y_inside ? p : mirror_warp_bl(p, dim_y); };
     if (NG > 1 && __builtin_amdgcn_ballot_w64(!(interior && merged)) == 0) {
 #pragma unroll
         for (int r = 0; r < ROWS; r++) {
             const int cy = min(cy0 + r, dim_y - 1);
             if (need_a) {
-                const E* rowp = A + (size_t)mirror_warp(cy + dya[0], dim_y) * Si;
+                const E* rowp = A + (size_t)row_of(cy + dya[0]) * Si;
                 const Run<E, VEC> w = get_run<E, VEC, CZ, DW>(rowp, xa[0]);
 #pragma unroll
                 for (int k = 0; k < NG; k++)
@@ -467,7 +484,7 @@ __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a,
                     for (int i = 0; i < GROUP; i++) S.ra[r][k].v[i] = w.v[k * GROUP + i];
             }
             if (need_b) {
-                const E* rowp = B + (size_t)mirror_warp(cy + dyb[0], dim_y) * Si;
+                const E* rowp = B + (size_t)row_of(cy + dyb[0]) * Si;
                 const Run<E, VEC> w = get_run<E, VEC, CZ, DW>(rowp, xb[0]);
 #pragma unroll
                 for (int k = 0; k < NG; k++)
@@ -482,11 +499,11 @@ __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a,
 #pragma unroll
             for (int k = 0; k < NG; k++) {
                 if (need_a) {
-                    const E* rowp = A + (size_t)mirror_warp(cy + dya[k], dim_y) * Si;
+                    const E* rowp = A + (size_t)row_of(cy + dya[k]) * Si;
                     S.ra[r][k] = get_run<E, GROUP, CZ, DW>(rowp, xa[k]);
                 }
                 if (need_b) {
-                    const E* rowp = B + (size_t)mirror_warp(cy + dyb[k], dim_y) * Si;
+                    const E* rowp = B + (size_t)row_of(cy + dyb[k]) * Si;
                     S.rb[r][k] = get_run<E, GROUP, CZ, DW>(rowp, xb[k]);
                 }
             }
@@ -499,7 +516,7 @@ __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a,
 #pragma unroll
             for (int k = 0; k < NG; k++) {
                 if (need_a) {
-                    const E* rowp = A + (size_t)mirror_warp(cy + dya[k], dim_y) * Si;
+                    const E* rowp = A + (size_t)row_of(cy + dya[k]) * Si;
                     if (xa[k] >= 1 && xa[k] + GROUP - 1 <= W - 2) {
                         S.ra[r][k] = get_run<E, GROUP, CZ, DW>(rowp, xa[k]);
                     } else {
@@ -511,7 +528,7 @@ __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a,
                     }
                 }
                 if (need_b) {
-                    const E* rowp = B + (size_t)mirror_warp(cy + dyb[k], dim_y) * Si;
+                    const E* rowp = B + (size_t)row_of(cy + dyb[k]) * Si;
                     if (xb[k] >= 1 && xb[k] + GROUP - 1 <= W - 2) {
                         S.rb[r][k] = get_run<E, GROUP, CZ, DW>(rowp, xb[k]);
                     } else {
@@ -579,12 +596,17 @@ __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a,
     }
   };
 #if HF_WARP_PIPELINE
-  Src nxt;
-  issue(0, nxt);
-  for (int ti = 0; ti < a.n_out; ti++) {
-    const Src cur = nxt;
-    if (ti + 1 < a.n_out) issue(ti + 1, nxt);
-    finish(ti, cur);
+  // (requesting the runs of two outputs ahead, or of all outputs up front, measured no faster: 52.8 / 53.8 us vs 49.9 us)
+  Src S0, S1;   // two register sets: no copies between the stages of the pipeline
+  issue(0, S0);
+  for (int ti = 0; ti < a.n_out; ti += 2) {
+    const bool more = ti + 1 < a.n_out;
+    if (more) issue(ti + 1, S1);
+    finish(ti, S0);
+    if (more) {
+      if (ti + 2 < a.n_out) issue(ti + 2, S0);
+      finish(ti + 1, S1);
+    }
   }
 #else
   for (int ti = 0; ti < a.n_out; ti++) {

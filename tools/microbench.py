@@ -60,3 +60,21 @@ c.resetProfile()
 for _ in range(a.n): c.interpolateOnly(ts5, ptrs5, 2)
 p = c.profile(); us = 1e3 * p["warp_ms"] / p["warp_launches"]
 print(f"{'fused period (5 outputs, mode 2)':34s} {us:8.2f} us  {5*3*F/us/1e3:8.1f} GB/s algorithmic, {7*F/us/1e3:8.1f} GB/s compulsory (2F + 5F)")
+# the same fused period HBM-cold: rotate over enough source frames / output sets that nothing survives in the 256 MB MALL
+K = 6
+srcs = [DeviceBuffer(fr[0].nbytes) for _ in range(K + 2)]
+for i, b in enumerate(srcs): b.upload(fr[i % 4])
+outsK = [[DeviceBuffer(c.output_frame_bytes) for _ in range(5)] for _ in range(K)]
+real = c.readBlurredFlow(0)
+for k in range(3): c.updateFrameDeviceRef(srcs[k].ptr)
+c.sync(); c.writeBlurredFlow(0, real)
+def cold_pass(n, mode):
+    for i in range(n):
+        c.updateFrameDeviceRef(srcs[(i + 3) % (K + 2)].ptr)      # rotates the ring (prep kernel runs too; not in the warp span)
+        c.interpolateOnly(ts5, [o.ptr for o in outsK[i % K]], mode)
+for mode in (2, 0):
+    cold_pass(K, mode); c.sync(); c.resetProfile()
+    cold_pass(3 * K, mode); c.sync()
+    p = c.profile(); us = 1e3 * p["warp_ms"] / p["warp_launches"]
+    nsrc = 2 if mode == 2 else 1
+    print(f"{'fused period mode %d, HBM-cold' % mode:34s} {us:8.2f} us  {(nsrc+5)*F/us/1e3:8.1f} GB/s compulsory ({nsrc}F + 5F)")
