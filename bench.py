@@ -228,7 +228,7 @@ def main():
 
     out_ptrs = [[b.ptr for b in bufs] for bufs in outbufs]
     batches = []
-    if a.batch > 1 and (a.dual_stream_contexts or a.shared_warp_stream or a.priority_streams):
+    if a.batch > 1 and (a.shared_warp_stream or a.priority_streams):
         a.batch = 1          # hf_batch members are single-stream contexts
     if a.batch > 1:
         from hopperrender_amd.calc import FlowBatch

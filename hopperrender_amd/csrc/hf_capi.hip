@@ -775,6 +775,8 @@ int hf_calculate_optical_flow(hf_ctx* c) {
 struct hf_batch {
     std::vector<hf_ctx*> members;
     std::vector<hipStream_t> own_streams;   // the members' own streams, restored by hf_batch_destroy
+    std::vector<hipStream_t> own_warp_streams;
+    std::vector<hipStream_t> warp_streams;  // HF_FLAG_DUAL_STREAM members: shared streams their warps are issued on
     hipStream_t stream = nullptr;           // = members[0]'s stream, shared by all members while the batch exists
     std::map<std::vector<int>, hipGraphExec_t> graphs;
     std::string err;
@@ -802,23 +804,39 @@ int hf_batch_create(hf_ctx* const* members, int n, hf_batch** out) {
                           a.rs == b.rs && m->device == l->device && m->cfg.iterations == l->cfg.iterations &&
                           m->cfg.blur_radius == l->cfg.blur_radius;
         if (!same) return batch_fail(nullptr, HF_ERR_INVALID_ARGUMENT, "hf_batch_create: members differ in geometry, device, iterations or blur radius");
-        if (!m->async() || m->warp_stream != m->stream || m->io_in)
-            return batch_fail(nullptr, HF_ERR_INVALID_ARGUMENT, "hf_batch_create: members must be HF_FLAG_ASYNC single-stream contexts without async host I/O");
+        if (!m->async() || (m->warp_stream != m->stream && !m->dual()) || m->io_in || m->dual() != l->dual())
+            return batch_fail(nullptr, HF_ERR_INVALID_ARGUMENT, "hf_batch_create: members must be HF_FLAG_ASYNC contexts (all single-stream or all HF_FLAG_DUAL_STREAM) without async host I/O");
     }
     if (hipSetDevice(l->device) != hipSuccess) return batch_fail(nullptr, HF_ERR_HIP, "hf_batch_create: hipSetDevice failed");
     hf_batch* b = new (std::nothrow) hf_batch();
     if (!b) return batch_fail(nullptr, HF_ERR_OUT_OF_MEMORY, "hf_batch_create: host allocation failed");
     b->stream = l->stream;
+    if (l->dual()) {
+        // the members' warps go to a few shared streams (round robin) instead of one stream per member: the device
+        // runs only a handful of hardware queues side by side (DESIGN.md "Hardware queues")
+        static const int ws_env = getenv("HF_BATCH_WARP_STREAMS") ? atoi(getenv("HF_BATCH_WARP_STREAMS")) : 0;
+        const int nws = ws_env > 0 ? ws_env : (n < 3 ? n : 3);
+        for (int i = 0; i < nws; i++) {
+            hipStream_t ws = nullptr;
+            if (hipStreamCreateWithFlags(&ws, hipStreamNonBlocking) != hipSuccess) {
+                for (hipStream_t x : b->warp_streams) hipStreamDestroy(x);
+                delete b;
+                return batch_fail(nullptr, HF_ERR_HIP, "hf_batch_create: cannot create a warp stream");
+            }
+            b->warp_streams.push_back(ws);
+        }
+    }
     for (int i = 0; i < n; i++) {
         hf_ctx* m = members[i];
         if (int rc = sync_ctx(m)) { delete b; return batch_fail(nullptr, rc, "hf_batch_create: member sync failed"); }
         b->members.push_back(m);
         b->own_streams.push_back(m->stream);
+        b->own_warp_streams.push_back(m->warp_stream);
         // one stream for the whole batch: the members' prep / warp launches and the batched chain stay in program order
         for (auto& kv : m->graphs) hipGraphExecDestroy(kv.second);   // captured on the member's own stream
         m->graphs.clear();
         m->stream = b->stream;
-        m->warp_stream = b->stream;
+        m->warp_stream = m->dual() ? b->warp_streams[(size_t)i % b->warp_streams.size()] : b->stream;
     }
     *out = b;
     return HF_OK;
@@ -827,15 +845,19 @@ int hf_batch_create(hf_ctx* const* members, int n, hf_batch** out) {
 void hf_batch_destroy(hf_batch* b) {
     if (!b) return;
     if (!b->members.empty()) hipSetDevice(b->members[0]->device);
+    for (hf_ctx* m : b->members) leave_warp_stream(m);   // the batch stream waits for every member's last warps
     if (b->stream) hipStreamSynchronize(b->stream);
+    for (hipStream_t ws : b->warp_streams) hipStreamSynchronize(ws);
     for (auto& kv : b->graphs) hipGraphExecDestroy(kv.second);
     for (size_t i = 0; i < b->members.size(); i++) {
         hf_ctx* m = b->members[i];
         for (auto& kv : m->graphs) hipGraphExecDestroy(kv.second);
         m->graphs.clear();
         m->stream = b->own_streams[i];
-        m->warp_stream = m->stream;
+        m->warp_stream = b->own_warp_streams[i];
+        m->on_warp_stream = false;
     }
+    for (hipStream_t ws : b->warp_streams) hipStreamDestroy(ws);
     delete b;
 }
 
@@ -846,6 +868,7 @@ int hf_batch_calculate_optical_flow(hf_batch* b) {
     if (hipSetDevice(l->device) != hipSuccess) return batch_fail(b, HF_ERR_HIP, "hipSetDevice failed");
     std::vector<int> key = {l->p.search_radius, l->p.delta_scalar, l->p.neighbor_scalar};
     for (hf_ctx* m : b->members) {
+        if (int rc = leave_warp_stream(m)) return batch_fail(b, rc, m->err);
         if (int rc = check_flow_params(m)) return batch_fail(b, rc, m->err);
         if (m->p.search_radius != l->p.search_radius || m->p.delta_scalar != l->p.delta_scalar || m->p.neighbor_scalar != l->p.neighbor_scalar)
             return batch_fail(b, HF_ERR_INVALID_ARGUMENT, "hf_batch_calculate_optical_flow: members differ in search radius / delta / neighbor scalar");

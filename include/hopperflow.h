@@ -168,8 +168,10 @@ int hf_interpolate_period_ex(hf_ctx* ctx, const void* device_frame, int n_out, c
  * geometry/parameters into a batch: hf_batch_calculate_optical_flow() runs the calculateOpticalFlow() of every
  * member as ONE set of launches (each kernel handles all pairs).  Results per member are bit-identical to
  * hf_calculate_optical_flow(member).
- *   - members: HF_FLAG_ASYNC contexts, one stream each (no DUAL/SHARED/PRIORITY flags, no async host I/O), same
- *     device, frame geometry, iterations, blur radius; at call time the same search radius / delta / neighbor scalar.
+ *   - members: HF_FLAG_ASYNC contexts without async host I/O, all single-stream or all HF_FLAG_DUAL_STREAM (no
+ *     SHARED/PRIORITY flags), same device, frame geometry, iterations, blur radius; at call time the same search
+ *     radius / delta / neighbor scalar.  DUAL_STREAM members issue their warps on up to 3 streams the batch shares
+ *     out round robin (they overlap the batched chain; measured slower than 4 single-stream batches of 2).
  *   - while the batch exists all members issue on ONE stream (the first member's): their hf_update_frame_device*,
  *     hf_interpolate_period_ex(..., update_and_flow = 0), hf_sync ... calls keep working and stay in program order
  *     with the batched chain.  Destroy the batch before its members. */

@@ -6,21 +6,24 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def calc_for(hdr, H, W, **kw):
+def calc_for(hdr, H, W, dual=False, **kw):
     from hopperrender_amd import capi
     from hopperrender_amd.calc import OpticalFlowCalcHDR, OpticalFlowCalcSDR
-    return (OpticalFlowCalcHDR if hdr else OpticalFlowCalcSDR)(H, W, 0, 0, 8, 6, 0.0, 255.0, 270, flags=capi.HF_FLAG_ASYNC, **kw)
+    flags = capi.HF_FLAG_ASYNC | (capi.HF_FLAG_DUAL_STREAM if dual else 0)
+    return (OpticalFlowCalcHDR if hdr else OpticalFlowCalcSDR)(H, W, 0, 0, 8, 6, 0.0, 255.0, 270, flags=flags, **kw)
 
 
-@pytest.mark.parametrize("hdr,H,W,n,R", [(0, 360, 640, 3, 8), (1, 360, 640, 8, 16), (0, 1080, 1920, 4, 16), (1, 2160, 3840, 2, 5),
-                                        (0, 274, 486, 5, 16)])
-def test_batch_equals_single_contexts(native_lib, hdr, H, W, n, R):
+@pytest.mark.parametrize("hdr,H,W,n,R,dual", [(0, 360, 640, 3, 8, False), (1, 360, 640, 8, 16, False), (0, 1080, 1920, 4, 16, False),
+                                             (1, 2160, 3840, 2, 5, False), (0, 274, 486, 5, 16, False),
+                                             (1, 360, 640, 5, 16, True), (0, 1080, 1920, 4, 9, True)])
+def test_batch_equals_single_contexts(native_lib, hdr, H, W, n, R, dual):
+    """dual: HF_FLAG_DUAL_STREAM members -- their warps go to the batch's shared warp streams and overlap the chain."""
     from hopperrender_amd import synth
     from hopperrender_amd.calc import DeviceBuffer, FlowBatch
     scenes = [synth.Scene(H, W, bool(hdr), 100 + 7 * i) for i in range(n)]
     frames = [[sc.frame(k) for k in range(6)] for sc in scenes]
     singles = [calc_for(hdr, H, W, search_radius=R) for _ in range(n)]
-    members = [calc_for(hdr, H, W, search_radius=R) for _ in range(n)]
+    members = [calc_for(hdr, H, W, dual=dual, search_radius=R) for _ in range(n)]
     batch = FlowBatch(members)
     assert len(batch) == n
     ts = [0.0, 0.3996, 0.7992]
