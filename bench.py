@@ -65,6 +65,8 @@ def parse_args():
     ap.add_argument("--no-fused-warp", action="store_true", help="one warp launch per output frame instead of one per source period")
     ap.add_argument("--shared-warp-stream", action="store_true",
                     help="issue the warp kernels of all pair streams on one shared stream per GPU (measured slower: 26.5k vs 33k frames/s)")
+    ap.add_argument("--warp-turnstile", action="store_true",
+                    help="HF_FLAG_WARP_TURNSTILE: the warp launches of all pair streams run one at a time")
     ap.add_argument("--copy-in", action="store_true",
                     help="updateFrame copies the device-resident source frame into the ring (default: zero-copy reference)")
     ap.add_argument("--profile-every", type=int, default=8,
@@ -209,6 +211,8 @@ def main():
         flags |= capi.HF_FLAG_PRIORITY_STREAMS
     if a.dual_stream_contexts:
         flags |= capi.HF_FLAG_DUAL_STREAM
+    if a.warp_turnstile:
+        flags |= capi.HF_FLAG_WARP_TURNSTILE
     cls = OpticalFlowCalcHDR if hdr else OpticalFlowCalcSDR
     calcs, outbufs, plans = [], [], []
     total_steps = a.warmup + a.steps

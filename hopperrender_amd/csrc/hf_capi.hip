@@ -53,6 +53,10 @@ hipStream_t shared_warp_stream(int device) {
     return s;
 }
 
+// HF_FLAG_WARP_TURNSTILE: the event behind the most recently issued warp launch of any such context, per device
+std::mutex g_turnstile_mutex;
+std::map<int, hipEvent_t> g_turnstile_last;
+
 }  // namespace
 
 struct hf_ctx {
@@ -64,6 +68,7 @@ struct hf_ctx {
     hipStream_t warp_stream = nullptr;                 // == stream unless HF_FLAG_SHARED_WARP_STREAM / HF_FLAG_PRIORITY_STREAMS
     hipStream_t own_warp_stream = nullptr;             // HF_FLAG_PRIORITY_STREAMS: this context's low-priority warp stream
     hipEvent_t ev_chain_done = nullptr, ev_warps_done = nullptr;
+    hipEvent_t ev_turn = nullptr;                      // HF_FLAG_WARP_TURNSTILE: recorded behind this context's warp launches
     hipEvent_t ev_flow[2] = {nullptr, nullptr};        // recorded behind the chain that wrote blurred[i] (swapped with it)
     bool ev_flow_valid[2] = {false, false};
     bool dual() const { return (cfg.flags & HF_FLAG_DUAL_STREAM) != 0; }
@@ -369,6 +374,24 @@ int leave_warp_stream(hf_ctx* c) {
     return HF_OK;
 }
 
+// HF_FLAG_WARP_TURNSTILE: wait for the previously issued warp launch (of any context on this device) ...
+int turnstile_enter(hf_ctx* c) {
+    if (!(c->cfg.flags & HF_FLAG_WARP_TURNSTILE)) return HF_OK;
+    std::lock_guard<std::mutex> lock(g_turnstile_mutex);
+    auto it = g_turnstile_last.find(c->device);
+    if (it != g_turnstile_last.end() && it->second && it->second != c->ev_turn)   // our own last launch is ordered by the stream
+        HF_HIP(c, hipStreamWaitEvent(c->warp_stream, it->second, 0));
+    return HF_OK;
+}
+// ... and publish this context's launches as the ones to wait for
+int turnstile_leave(hf_ctx* c) {
+    if (!(c->cfg.flags & HF_FLAG_WARP_TURNSTILE)) return HF_OK;
+    std::lock_guard<std::mutex> lock(g_turnstile_mutex);
+    HF_HIP(c, hipEventRecord(c->ev_turn, c->warp_stream));
+    g_turnstile_last[c->device] = c->ev_turn;
+    return HF_OK;
+}
+
 int sync_ctx(hf_ctx* c) {
     if (int rc = leave_warp_stream(c)) return rc;
     HF_HIP(c, hipStreamSynchronize(c->stream));
@@ -557,6 +580,7 @@ int hf_create(const hf_config* cfg, hf_ctx** out_ctx) {
     }
     HF_TRY(hipEventCreateWithFlags(&c->ev_chain_done, hipEventDisableTiming));
     HF_TRY(hipEventCreateWithFlags(&c->ev_warps_done, hipEventDisableTiming));
+    HF_TRY(hipEventCreateWithFlags(&c->ev_turn, hipEventDisableTiming));
     for (int i = 0; i < 3; i++) {
         HF_TRY(hipMalloc(&c->ring_store[i], c->in_bytes));
         c->ring[i] = c->ring_store[i];
@@ -628,6 +652,12 @@ void hf_destroy(hf_ctx* c) {
     for (hipEvent_t e : c->ev_flow) if (e) hipEventDestroy(e);
     if (c->ev_chain_done) hipEventDestroy(c->ev_chain_done);
     if (c->ev_warps_done) hipEventDestroy(c->ev_warps_done);
+    if (c->ev_turn) {
+        std::lock_guard<std::mutex> lock(g_turnstile_mutex);
+        auto it = g_turnstile_last.find(c->device);
+        if (it != g_turnstile_last.end() && it->second == c->ev_turn) it->second = nullptr;   // the stream was drained above
+        hipEventDestroy(c->ev_turn);
+    }
     hipEvent_t evs[] = {c->ev_upload, c->ev_flow_end, c->ev_warp_start, c->ev_warp_end, c->ev_user0, c->ev_user1};
     for (hipEvent_t e : evs) if (e) hipEventDestroy(e);
     if (c->own_warp_stream) hipStreamDestroy(c->own_warp_stream);
@@ -911,6 +941,7 @@ int hf_warp_frames(hf_ctx* c, float t, int mode) {
     if (!c->warp_started) { HF_HIP(c, hipEventRecord(c->ev_warp_start, c->stream)); c->warp_started = true; }
     if (int rc = enter_warp_stream(c)) return rc;
     if (int rc = guard_output_slot(c, c->warp_stream)) return rc;
+    if (!c->in_period) if (int rc = turnstile_enter(c)) return rc;
     // frames N-2 / N-1 and the PREVIOUS flow (:154-156)
     // profiled launches carry start/stop events of the dispatch itself (hipExtLaunchKernel), i.e. the kernel's
     // execution time as rocprof reports it, not the time the launch spent queued behind other streams
@@ -919,6 +950,7 @@ int hf_warp_frames(hf_ctx* c, float t, int mode) {
                     c->p.black_level * scale, c->p.white_level * scale, c->warp_stream,
                     span >= 0 ? c->spans[span].b : nullptr, span >= 0 ? c->spans[span].e : nullptr);
     if (c->on_warp_stream && !c->in_period) HF_HIP(c, hipEventRecord(c->ev_warps_done, c->warp_stream));
+    if (!c->in_period) if (int rc = turnstile_leave(c)) return rc;
     if (int rc = note_launch(c, c->warp_stream)) return rc;
     HF_HIP(c, hipGetLastError());
     return HF_OK;
@@ -962,6 +994,7 @@ int hf_interpolate_period_ex(hf_ctx* c, const void* device_frame, int n_out, con
     if (fuse) {
         const float scale = c->g.hdr ? 256.0f : 1.0f;
         if (int rc = enter_warp_stream(c)) return rc;
+        if (int rc = turnstile_enter(c)) return rc;
         while (done < n_out) {
             const int n = n_out - done < hf::kMaxWarpOutputs ? n_out - done : hf::kMaxWarpOutputs;
             void* outs[hf::kMaxWarpOutputs];
@@ -979,6 +1012,7 @@ int hf_interpolate_period_ex(hf_ctx* c, const void* device_frame, int n_out, con
             HF_HIP(c, hipGetLastError());
             done += n;
         }
+        if (int rc = turnstile_leave(c)) return rc;
         if (done > 0) {
             if (c->on_warp_stream) HF_HIP(c, hipEventRecord(c->ev_warps_done, c->warp_stream));
             if (int rc = note_launch(c, c->warp_stream)) return rc;

@@ -26,6 +26,10 @@
 #include "hf_kernels.h"
 #include <cstdlib>
 
+#ifndef HF_PREP_NT_LOAD
+#define HF_PREP_NT_LOAD 0   // 1: non-temporal loads of the source frame in the phase-plane kernel
+#endif
+
 namespace hf {
 
 namespace {
@@ -125,8 +129,15 @@ __global__ __launch_bounds__(128) void prep_phase_fast_kernel(const E* __restric
     const bool luma = row < H;
     const E* __restrict__ src = (luma ? f + (size_t)row * S : f + (size_t)H * S + (size_t)(row - H) * S) + (size_t)t * NE;
     __attribute__((aligned(16))) E e[NE];
+    typedef unsigned nt_v4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-    for (int i = 0; i < NE * (int)sizeof(E) / 16; i++) ((uint4*)e)[i] = ((const uint4*)src)[i];
+    for (int i = 0; i < NE * (int)sizeof(E) / 16; i++) {
+#if HF_PREP_NT_LOAD
+        ((nt_v4*)e)[i] = __builtin_nontemporal_load((const nt_v4*)src + i);
+#else
+        ((uint4*)e)[i] = ((const uint4*)src)[i];
+#endif
+    }
     if (NE * sizeof(E) < 16) {                               // RS = 0..1 with 8-bit elements: 4 or 8 bytes per thread
 #pragma unroll
         for (int i = 0; i < NE; i++) e[i] = src[i];
