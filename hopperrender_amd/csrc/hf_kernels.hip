@@ -76,31 +76,34 @@ __global__ __launch_bounds__(256) void blur_flow_kernel(const BlurBatch batch, i
     }
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int T = 16 + 2 * r;                     // tile edge
-    int* rows = (int*)smem;                       // [T][16] horizontal sums
-    int16_t* tile = (int16_t*)(rows + T * 16);    // [T][T]
+    int* rows = (int*)smem;                       // [2][T][16] horizontal sums
+    int16_t* tile = (int16_t*)(rows + 2 * T * 16); // [2][T][T]
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * 16 - r, y0 = blockIdx.y * 16 - r;
     const int tx = tid & 15, ty = tid >> 4;
     const int gx = blockIdx.x * 16 + tx, gy = blockIdx.y * 16 + ty;
-    int res[2] = {0, 0};
-    for (int z = 0; z < 2; z++) {
-        const int16_t* __restrict__ src = z ? L.ty : L.tx;   // offsets are stored per window of the last level
-        if (z) __syncthreads();
-        for (int i = tid; i < T * T; i += 256) {
-            const int py = i / T, px = i - py * T;
-            tile[i] = src ? src[(mirror_flow(y0 + py, lh) >> L.log2w) * L.nwx + (mirror_flow(x0 + px, lw) >> L.log2w)] : (int16_t)0;
-        }
-        __syncthreads();
-        for (int i = tid; i < T * 16; i += 256) {     // taps -r .. r-1 (blurFlowKernelSDR.h:82-83)
-            const int row = i >> 4, col = i & 15;
-            const int16_t* p = tile + row * T + col;
-            int s = 0;
-            for (int k = 0; k < 2 * r; k++) s += p[k];
-            rows[i] = s;
-        }
-        __syncthreads();
+    // both planes go through every stage together: one round of global loads and two barriers per workgroup
+    for (int i = tid; i < T * T; i += 256) {      // offsets are stored per window of the last level
+        const int py = i / T, px = i - py * T;
+        const int w = (mirror_flow(y0 + py, lh) >> L.log2w) * L.nwx + (mirror_flow(x0 + px, lw) >> L.log2w);
+        tile[i] = L.tx ? L.tx[w] : (int16_t)0;
+        tile[T * T + i] = L.ty ? L.ty[w] : (int16_t)0;
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * T * 16; i += 256) {     // taps -r .. r-1 (blurFlowKernelSDR.h:82-83)
+        const int z = i >= T * 16, k16 = i - z * T * 16;
+        const int row = k16 >> 4, col = k16 & 15;
+        const int16_t* p = tile + z * T * T + row * T + col;
         int s = 0;
-        for (int k = 0; k < 2 * r; k++) s += rows[(ty + k) * 16 + tx];
+        for (int k = 0; k < 2 * r; k++) s += p[k];
+        rows[i] = s;
+    }
+    __syncthreads();
+    int res[2];
+#pragma unroll
+    for (int z = 0; z < 2; z++) {
+        int s = 0;
+        for (int k = 0; k < 2 * r; k++) s += rows[z * T * 16 + (ty + k) * 16 + tx];
         res[z] = (int)(int16_t)(s / (4 * r * r));      // C truncation, :89-90
     }
     if (gx < lw && gy < lh) {
@@ -705,7 +708,11 @@ __global__ void rcp_probe_kernel(const float* in, float* out, int n) {
 void launch_blur_flow(const Geom& g, const BlurBatch& b, int radius, int zero_count, hipStream_t stream) {
     const dim3 grd((g.lw + 15) / 16, (g.lh + 15) / 16, b.n);
     const int T = 16 + 2 * radius;
-    const size_t smem = (size_t)T * 16 * sizeof(int) + (size_t)T * T * sizeof(int16_t);
+    const size_t smem = 2 * ((size_t)T * 16 * sizeof(int) + (size_t)T * T * sizeof(int16_t));
+    if (smem > 48 * 1024) {   // large radii (up to 64: 101 KB of the CU's 160 KB LDS) need the opt-in
+        static bool raised = false;
+        if (!raised) raised = hipFuncSetAttribute((const void*)blur_flow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess;
+    }
     blur_flow_kernel<<<grd, 256, smem, stream>>>(b, g.lw, g.lh, radius, zero_count);
 }
 
