@@ -65,6 +65,8 @@ def parse_args():
     ap.add_argument("--no-fused-warp", action="store_true", help="one warp launch per output frame instead of one per source period")
     ap.add_argument("--shared-warp-stream", action="store_true",
                     help="issue the warp kernels of all pair streams on one shared stream per GPU (measured slower: 26.5k vs 33k frames/s)")
+    ap.add_argument("--timing-events", action="store_true",
+                    help="keep the reference's per-call timing events (m_ofcCalcTime, m_warpCalcTime); default off in the bench")
     ap.add_argument("--warp-turnstile", action="store_true",
                     help="HF_FLAG_WARP_TURNSTILE: the warp launches of all pair streams run one at a time")
     ap.add_argument("--copy-in", action="store_true",
@@ -203,6 +205,8 @@ def main():
             c.updateFrameDeviceRef(ptr)
 
     flags = capi.HF_FLAG_ASYNC | (0 if a.no_profile else capi.HF_FLAG_PROFILE)
+    if not a.timing_events:
+        flags |= capi.HF_FLAG_NO_TIMING   # the m_ofcCalcTime / m_warpCalcTime events are barrier packets between the kernels
     if a.no_fused_warp:
         flags |= capi.HF_FLAG_NO_FUSED_WARP
     if a.shared_warp_stream:

@@ -139,6 +139,7 @@ struct hf_ctx {
     bool profiling() const { return (cfg.flags & HF_FLAG_PROFILE) != 0; }
 
     bool async() const { return (cfg.flags & HF_FLAG_ASYNC) != 0; }
+    bool timing() const { return (cfg.flags & HF_FLAG_NO_TIMING) == 0; }   // record the reference's timing events
 };
 
 namespace {
@@ -454,8 +455,10 @@ int note_launch(hf_ctx* c, hipStream_t launch_stream) {   // remembers "the fram
 int update_common(hf_ctx* c, const void* src, hipMemcpyKind kind, bool by_reference = false) {
     if (int rc = set_device(c)) return rc;
     if (int rc = leave_warp_stream(c)) return rc;
-    HF_HIP(c, hipEventRecord(c->ev_upload, c->stream));  // m_ofcStartedEvent (:20)
-    c->upload_recorded = true;
+    if (c->timing()) {
+        HF_HIP(c, hipEventRecord(c->ev_upload, c->stream));  // m_ofcStartedEvent (:20)
+        c->upload_recorded = true;
+    }
     if (by_reference) {
         c->ring[0] = const_cast<void*>(src);
     } else {
@@ -689,8 +692,10 @@ int hf_update_frame_async(hf_ctx* c, const void* pinned_host_frame) {
     HF_HIP(c, hipMemcpyAsync(c->ring_store[0], pinned_host_frame, c->in_bytes, hipMemcpyHostToDevice, c->io_in));
     HF_HIP(c, hipEventRecord(c->ev_h2d, c->io_in));
     if (int rc = leave_warp_stream(c)) return rc;
-    HF_HIP(c, hipEventRecord(c->ev_upload, c->stream));
-    c->upload_recorded = true;
+    if (c->timing()) {
+        HF_HIP(c, hipEventRecord(c->ev_upload, c->stream));
+        c->upload_recorded = true;
+    }
     HF_HIP(c, hipStreamWaitEvent(c->stream, c->ev_h2d, 0));
     c->ring[0] = c->ring_store[0];
     hf::launch_prep_frame(c->g, c->pl, c->ring[0], c->py[0], c->puv[0], c->stream);
@@ -742,9 +747,11 @@ static int after_flow_enqueued(hf_ctx* c, hipStream_t s) {
     c->initial_window = initial_window(c->g.lw, c->g.lh);
     c->last_iterations = iters;
     c->last_level = iters ? c->levels[iters - 1] : hf::FlowLevel{};
-    HF_HIP(c, hipEventRecord(c->ev_flow_end, s));
+    if (c->timing()) {
+        HF_HIP(c, hipEventRecord(c->ev_flow_end, s));
+        c->flow_timing_pending = true;
+    }
     c->delta_pending = c->last_iterations > 0;
-    c->flow_timing_pending = true;
     if (c->dual()) {   // tag the flow buffer just written, the tag travels with the buffer through the swap below
         HF_HIP(c, hipEventRecord(c->ev_flow[0], s));
         c->ev_flow_valid[0] = true;
@@ -938,7 +945,7 @@ int hf_warp_frames(hf_ctx* c, float t, int mode) {
     if (mode < 0 || mode > 6) return fail(c, HF_ERR_INVALID_ARGUMENT, "warpFrames: frame output mode %d outside [0, 6]", mode);
     if (int rc = set_device(c)) return rc;
     const float scale = c->g.hdr ? 256.0f : 1.0f;  // opticalFlowCalcHDR.cpp:151-152
-    if (!c->warp_started) { HF_HIP(c, hipEventRecord(c->ev_warp_start, c->stream)); c->warp_started = true; }
+    if (!c->warp_started && c->timing()) { HF_HIP(c, hipEventRecord(c->ev_warp_start, c->stream)); c->warp_started = true; }
     if (int rc = enter_warp_stream(c)) return rc;
     if (int rc = guard_output_slot(c, c->warp_stream)) return rc;
     if (!c->in_period) if (int rc = turnstile_enter(c)) return rc;
@@ -962,7 +969,7 @@ int hf_copy_frame(hf_ctx* c) {
     const float scale = c->g.hdr ? 256.0f : 1.0f;  // opticalFlowCalcHDR.cpp:173-174
     const int idx = c->p.frame_count >= 3 ? 0 : c->p.frame_count >= 2 ? 1 : 2;  // opticalFlowCalcSDR.cpp:173
     if (int rc = leave_warp_stream(c)) return rc;
-    if (!c->warp_started) { HF_HIP(c, hipEventRecord(c->ev_warp_start, c->stream)); c->warp_started = true; }
+    if (!c->warp_started && c->timing()) { HF_HIP(c, hipEventRecord(c->ev_warp_start, c->stream)); c->warp_started = true; }
     if (int rc = guard_output_slot(c, c->stream)) return rc;
     const int span = span_begin(c, 1);
     hf::launch_copy(c->g, c->ring[idx], c->out_target, c->p.black_level * scale, c->p.white_level * scale, c->stream);
@@ -999,7 +1006,7 @@ int hf_interpolate_period_ex(hf_ctx* c, const void* device_frame, int n_out, con
             const int n = n_out - done < hf::kMaxWarpOutputs ? n_out - done : hf::kMaxWarpOutputs;
             void* outs[hf::kMaxWarpOutputs];
             for (int i = 0; i < n; i++) outs[i] = device_out[done + i] ? device_out[done + i] : c->out_frame;
-            if (!c->warp_started) { HF_HIP(c, hipEventRecord(c->ev_warp_start, c->stream)); c->warp_started = true; }
+            if (!c->warp_started && c->timing()) { HF_HIP(c, hipEventRecord(c->ev_warp_start, c->stream)); c->warp_started = true; }
             const int span = span_open(c, 0);
             const bool ok = hf::launch_warp_period(c->g, c->ring[0], c->ring[1], c->blurred[0], c->blurred_xy[0], n, outs, t + done, mode,
                                                    c->p.black_level * scale, c->p.white_level * scale, c->warp_stream,
@@ -1035,7 +1042,7 @@ static int download_common(hf_ctx* c, void* dst, hipMemcpyKind kind) {
     if (int rc = set_device(c)) return rc;
     if (int rc = leave_warp_stream(c)) return rc;
     if (c->out_target != dst) HF_HIP(c, hipMemcpyAsync(dst, c->out_target, c->out_bytes, kind, c->stream));
-    HF_HIP(c, hipEventRecord(c->ev_warp_end, c->stream));
+    if (c->timing()) HF_HIP(c, hipEventRecord(c->ev_warp_end, c->stream));
     if (kind == hipMemcpyDeviceToHost || !c->async()) {
         if (int rc = sync_ctx(c)) return rc;
         float ms = 0.f;

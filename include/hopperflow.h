@@ -65,6 +65,9 @@ typedef enum hf_output_mode {
                                     calculateOpticalFlow produces the next flow from N-1/N into the other buffer, so the two
                                     overlap inside one context; events keep every other ordering intact */
 #define HF_FLAG_NO_FUSED_WARP 0x80 /* hf_interpolate_period: one warp launch per output frame (debug / A-B timing) */
+#define HF_FLAG_NO_TIMING 0x200 /* do not record the events behind m_ofcCalcTime / m_warpCalcTime (hf_stats times stay 0).
+                                   Every timing event is a barrier packet on the stream: measured 5-6 us each between
+                                   back-to-back kernels, ~15 us per source period in a throughput pipeline */
 #define HF_FLAG_WARP_TURNSTILE 0x100 /* the warp launches of all such contexts on a device run one at a time (each waits
                                         for the previously issued one): two bandwidth-bound warps gain nothing from
                                         overlapping each other, the other streams' flow chains fill in instead */

@@ -1,6 +1,7 @@
 #!/bin/bash
-for sb in "8 2" "8 4" "12 3" "16 4" "4 1" "6 2" "12 2" "16 2" "8 1"; do
+for sb in "8 2" "8 8" "16 8" "8 4" "4 1" "16 4" "12 3"; do
   set -- $sb
   python bench.py --streams $1 --batch $2 --steps 100 --warmup 10 --no-profile --no-cpu-baseline --no-reference 2>&1 | tail -1 | \
     python -c "import json,sys; j=json.loads(sys.stdin.read()); print('streams=%2d batch=%d  us/period=%7.1f  frames/s=%8.0f' % ($1, $2, 1e3*j['ms_per_step']/$1, j['value']))"
 done
+python bench.py --streams 8 --batch 2 --timing-events --steps 100 --warmup 10 --no-profile --no-cpu-baseline --no-reference 2>&1 | tail -1 | python -c "import json,sys; j=json.loads(sys.stdin.read()); print('with timing events (8,2): frames/s', j['value'])"
