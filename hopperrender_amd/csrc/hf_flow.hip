@@ -26,6 +26,11 @@
 #include "hf_kernels.h"
 #include <cstdlib>
 
+#ifndef HF_FLOW_ALIGNED_LOADS
+#define HF_FLOW_ALIGNED_LOADS 0   // 1: strips through dword-aligned loads + v_alignbit.  Fewer addresser cycles but 2-3 loads per
+                                  // strip instead of 1: chain alone 98 -> 111 us, batch of 8 unchanged (35.2 us per pair),
+                                  // default bench +1 % (noise level) -- left off
+#endif
 #ifndef HF_PREP_NT_LOAD
 #define HF_PREP_NT_LOAD 0   // 1: non-temporal loads of the source frame in the phase-plane kernel
 #endif
@@ -244,6 +249,25 @@ __device__ __forceinline__ T load_unaligned(const void* p) {
     return v;
 }
 
+// A strip through DWORD-ALIGNED loads + funnel shift.  tools/ubench/gather_rate.hip, clocks per wave instruction in the
+// texture addresser: dword 6.1 aligned / 17.3 not; dwordx2 17.3 at a 4-byte boundary / 33.4 not; ushort 6.8 / 17.4.
+// A strip starts at an arbitrary byte (luma) or 2-byte (chroma) offset, so the plain loads were almost always the
+// slow kind.  The rows of the phase planes are padded (lwp >= lw + 2 mx + 8), so the extra dword stays inside the row.
+__device__ __forceinline__ uint32_t load_bytes4(const uint8_t* __restrict__ base, unsigned byte_off) {
+    const uint32_t* __restrict__ p = (const uint32_t*)(base + (byte_off & ~3u));
+    return __builtin_amdgcn_alignbit(p[1], p[0], (byte_off & 3u) * 8u);
+}
+__device__ __forceinline__ uint64_t load_bytes8(const uint8_t* __restrict__ base, unsigned byte_off) {
+    const uint32_t* __restrict__ p = (const uint32_t*)(base + (byte_off & ~3u));
+    const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+    const unsigned sh = (byte_off & 3u) * 8u;
+    return (uint64_t)__builtin_amdgcn_alignbit(d1, d0, sh) | ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, sh) << 32);
+}
+template <typename T> __device__ __forceinline__ T load_strip_bytes(const void* base, unsigned byte_off);
+template <> __device__ __forceinline__ uint16_t load_strip_bytes<uint16_t>(const void* b, unsigned o) { return (uint16_t)load_bytes4((const uint8_t*)b, o); }
+template <> __device__ __forceinline__ uint32_t load_strip_bytes<uint32_t>(const void* b, unsigned o) { return load_bytes4((const uint8_t*)b, o); }
+template <> __device__ __forceinline__ uint64_t load_strip_bytes<uint64_t>(const void* b, unsigned o) { return load_bytes8((const uint8_t*)b, o); }
+
 template <int PX>
 struct Strip {
     typename StripTypes<PX>::Y y2;    // frame-N luma bytes of the strip (masked)
@@ -324,8 +348,13 @@ __device__ __forceinline__ void strip_sads(uint32_t* sad, const Geom& g, const F
                 off_y = ph * pl.lwp + j + fix_y;
                 off_uv = (ph >> 1) * pl.lwp + j + fix_uv;
             }
+#if HF_FLOW_ALIGNED_LOADS
+            y1[cz] = load_strip_bytes<TY>(a.py1, (unsigned)off_y);
+            uv1[cz] = load_strip_bytes<TUV>(a.puv1, (unsigned)off_uv * 2u);
+#else
             y1[cz] = load_unaligned<TY>(a.py1 + (unsigned)off_y);
             uv1[cz] = load_unaligned<TUV>(a.puv1 + (unsigned)off_uv);
+#endif
         }
     }
 #pragma unroll

@@ -740,13 +740,12 @@ static bool launch_warp_fast(const Geom& g, const WarpArgs& a, hipStream_t strea
     const int wpr = (g.W + 64 * VEC - 1) / (64 * VEC);
     const int n_blocks = (wpr * (y_groups + uv_groups) + HF_WARP_WAVES - 1) / HF_WARP_WAVES;
     const dim3 fg(((n_blocks + 7) / 8) * 8);
-    static const unsigned warp_lds = getenv("HF_WARP_LDS") ? (unsigned)atoi(getenv("HF_WARP_LDS")) : 0u;   // experiment: caps workgroups per CU
 #define HF_WARP_FAST(G, D)                                                                   \
     do {                                                                                     \
         /* ev0/ev1 (may be null): timestamps of the dispatch itself, like rocprof's kernel trace */ \
-        if (a.mode == 0) hipExtLaunchKernelGGL((warp_fast_kernel<E, G, 2, 0, VB, D>), fg, dim3(64 * HF_WARP_WAVES), warp_lds, stream, ev0, ev1, 0, g, a, y_groups);      \
-        else if (a.mode == 1) hipExtLaunchKernelGGL((warp_fast_kernel<E, G, 2, 1, VB, D>), fg, dim3(64 * HF_WARP_WAVES), warp_lds, stream, ev0, ev1, 0, g, a, y_groups); \
-        else hipExtLaunchKernelGGL((warp_fast_kernel<E, G, 2, 2, VB, D>), fg, dim3(64 * HF_WARP_WAVES), warp_lds, stream, ev0, ev1, 0, g, a, y_groups);                  \
+        if (a.mode == 0) hipExtLaunchKernelGGL((warp_fast_kernel<E, G, 2, 0, VB, D>), fg, dim3(64 * HF_WARP_WAVES), 0, stream, ev0, ev1, 0, g, a, y_groups);      \
+        else if (a.mode == 1) hipExtLaunchKernelGGL((warp_fast_kernel<E, G, 2, 1, VB, D>), fg, dim3(64 * HF_WARP_WAVES), 0, stream, ev0, ev1, 0, g, a, y_groups); \
+        else hipExtLaunchKernelGGL((warp_fast_kernel<E, G, 2, 2, VB, D>), fg, dim3(64 * HF_WARP_WAVES), 0, stream, ev0, ev1, 0, g, a, y_groups);                  \
     } while (0)
 #define HF_WARP_GROUP(D)                                  \
     do {                                                  \
