@@ -233,7 +233,7 @@ int enqueue_flow_chain(hf_ctx* const* cs, int n, hipStream_t s) {
             hf::FlowStep& f = b.s[i];
             const hf::PendingArgmin& p = pending[i];
             f.cur = p.lvl; f.prev = p.lvl_prev; f.axis = p.axis; f.capture_delta = p.capture_delta;
-            f.sums = const_cast<uint32_t*>(p.sums); f.use_neighbors = 0; f.pend = hf::PendingArgmin{};
+            f.sums = const_cast<uint32_t*>(p.sums); f.use_neighbors = p.use_neighbors; f.pend = hf::PendingArgmin{};
             pending[i] = hf::PendingArgmin{};
         }
         hf::launch_flow_big_argmin(g, b, s);
@@ -263,6 +263,7 @@ int enqueue_flow_chain(hf_ctx* const* cs, int n, hipStream_t s) {
                 for (int i = 0; i < n; i++) {
                     const hf::FlowStep& f = a.s[i];
                     pending[i].active = 1; pending[i].axis = axis; pending[i].capture_delta = f.capture_delta;
+                    pending[i].use_neighbors = f.use_neighbors;
                     pending[i].lvl = f.cur; pending[i].lvl_prev = f.prev; pending[i].sums = f.sums;
                 }
                 step_index++;

@@ -44,6 +44,7 @@ struct PendingArgmin {
     int active;
     int axis;                // axis of the pending step
     int capture_delta;       // pending step is the first of the chain: emit m_totalFrameDelta
+    int use_neighbors;       // the pending step has a neighbour term (level >= 4): only the explicit argmin launch handles it
     FlowLevel lvl;           // level of the pending step (its table receives the result)
     FlowLevel lvl_prev;      // level before it (offset the candidates were relative to); tx == nullptr: zero
     const uint32_t* sums;    // [n_windows][16] raw SAD sums of the pending step
