@@ -344,3 +344,28 @@ def test_async_host_io_pipeline_matches_blocking(native_lib):
         c.close()
         for p in pin_in + pin_out:
             p.free()
+
+
+@pytest.mark.parametrize("hdr,H,W,max_res", [(0, 568, 1388, 1000), (1, 300, 1100, 600)])
+def test_wide_grid_large_windows_with_neighbour_term(native_lib, hdr, H, W, max_res):
+    """Grids wider than 512 (maxCalcRes above the default 270): the levels that carry the neighbour bias
+    (iteration >= 4, calcDeltaSumsKernelSDR.h:3,112) still have windows > 32, which take the partial-sum + explicit
+    argmin path.  Every iteration count, so that each level is the last one once."""
+    from hopperrender_amd import synth
+    from hopperrender_amd.calc import OpticalFlowCalcHDR, OpticalFlowCalcSDR
+    from oracle import oracle
+    sc = synth.Scene(H, W, bool(hdr), seed=4242)
+    f = [sc.frame(k) for k in range(3)]
+    g = oracle.make_geom(hdr, H, W, 0, 0, max_res)
+    assert g.lw > 512
+    for it in (4, 5, 6, 7, 0):
+        c = (OpticalFlowCalcHDR if hdr else OpticalFlowCalcSDR)(H, W, 0, 0, 3, 4, 0.0, 255.0, max_res, iterations=it, search_radius=12)
+        for x in f:
+            c.updateFrame(x)
+        c.calculateOpticalFlow()
+        off_o, blur_o, tot_o, oob = oracle.calculate_optical_flow(f[1], f[2], g, 12, it, 3, 4, 4)
+        assert oob == 0
+        assert (c.readOffsets() == off_o).all(), it
+        assert (c.readBlurredFlow(1) == blur_o).all(), it
+        assert c.m_totalFrameDelta == tot_o
+        c.close()

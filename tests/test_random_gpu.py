@@ -16,8 +16,8 @@ def _case(seed):
     W = int(rng.integers(16, 240) if not big else rng.integers(300, 700)) * 2
     if seed % 3 == 0:                      # exercise the 16-byte fast paths too
         W = (W + 15) // 16 * 16
-    si = W + int(rng.choice([0, 0, 2, 6, 16, 34]))
-    so = W + int(rng.choice([0, 0, 2, 8, 16, 30]))
+    si = W + int(rng.choice([0, 0, 2, 6, 16, 34, 1, 7]))      # odd pitches: no vector path applies
+    so = W + int(rng.choice([0, 0, 2, 8, 16, 30, 3, 5]))
     max_res = int(rng.choice([270, 270, 64, 48, 1000]))        # forces rs = 0 .. 2 at these sizes
     if big and seed % 2 == 0:
         max_res = 1000                     # grids wider than 512: windows > 32 at the levels that have the neighbour term
