@@ -112,3 +112,45 @@ def test_batch_rejects_incompatible_members(native_lib):
     bt.close()
     for x in (a, b, c, sync_ctx):
         x.close()
+
+
+def test_batch_members_out_of_step_and_parameter_churn(native_lib):
+    """Members whose rings / flow ping-pong are in different phases (one joined a frame later), and more
+    (R, delta, neighbour) combinations than the graph caches hold (96): every result still equals the single-context one."""
+    from hopperrender_amd import synth
+    from hopperrender_amd.calc import FlowBatch
+    hdr, H, W, n = 0, 180, 320, 3
+    scenes = [synth.Scene(H, W, False, 900 + i) for i in range(n)]
+    frames = [[sc.frame(k) for k in range(8)] for sc in scenes]
+    singles = [calc_for(hdr, H, W, search_radius=8) for _ in range(n)]
+    members = [calc_for(hdr, H, W, search_radius=8) for _ in range(n)]
+    for i in range(n):
+        for k in range(2 + i):                 # member i is i frames (and i flow calculations) ahead
+            for c in (singles[i], members[i]):
+                c.updateFrame(frames[i][k])
+                if k >= 2:
+                    c.calculateOpticalFlow()
+    batch = FlowBatch(members)
+    rng = np.random.default_rng(3)
+    combos = [(int(rng.integers(2, 17)), int(rng.integers(0, 11)), int(rng.integers(0, 11))) for _ in range(110)]
+    for j, (R, delta, nb) in enumerate(combos):
+        new_frame = j % 4 == 0
+        for i in range(n):
+            for c in (singles[i], members[i]):
+                c.m_opticalFlowSearchRadius = R
+                c.m_deltaScalar = delta
+                c.m_neighborBiasScalar = nb
+                if new_frame:
+                    c.updateFrame(frames[i][(2 + i + j // 4) % 8])
+            singles[i].calculateOpticalFlow()
+        batch.calculateOpticalFlow()
+        if j % 10 == 9 or j == len(combos) - 1:
+            for i in range(n):
+                singles[i].sync(); members[i].sync()
+                assert members[i].m_totalFrameDelta == singles[i].m_totalFrameDelta, (j, i)
+                assert (members[i].readOffsets() == singles[i].readOffsets()).all(), (j, i)
+                assert (members[i].readBlurredFlow(1) == singles[i].readBlurredFlow(1)).all(), (j, i)
+                assert (members[i].readBlurredFlow(0) == singles[i].readBlurredFlow(0)).all(), (j, i)
+    batch.close()
+    for c in singles + members:
+        c.close()

@@ -42,6 +42,8 @@ def test_random_configuration_matches_oracle(native_lib, seed):
     hdr, H, W = k["hdr"], k["H"], k["W"]
     sc = synth.Scene(H, W, bool(hdr), seed=300 + seed, in_stride=k["si"], max_rect_speed=int(rng.integers(2, 40)))
     f = [sc.frame(i) for i in range(4)]
+    if seed % 5 == 4:     # white noise over the full code range (P010 low bits set, 8-bit 0..255): no structure, worst case for wrap-around
+        f = [synth.random_frame(H, W, bool(hdr), seed=7000 + 10 * seed + i, in_stride=k["si"]) for i in range(4)]
     g = oracle.make_geom(hdr, H, W, k["si"], k["so"], k["max_res"])
     cls = OpticalFlowCalcHDR if hdr else OpticalFlowCalcSDR
     c = cls(H, W, k["si"], k["so"], k["delta"], k["nb"], k["black"], k["white"], k["max_res"], iterations=k["iters"],
