@@ -7,14 +7,16 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("hdr,H,W,si,so,R,delta,nb,seed", [
-    (0, 270, 480, 0, 0, 16, 8, 6, 501),
-    (1, 270, 480, 512, 496, 12, 8, 6, 502),
-    (0, 1080, 1920, 0, 0, 16, 8, 6, 503),
-    (1, 1080, 1920, 0, 0, 5, 6, 10, 504),
-    (1, 2160, 3840, 0, 0, 16, 8, 6, 505),
+@pytest.mark.parametrize("hdr,H,W,si,so,R,delta,nb,seed,max_res", [
+    (0, 270, 480, 0, 0, 16, 8, 6, 501, 270),
+    (1, 270, 480, 512, 496, 12, 8, 6, 502, 270),
+    (0, 1080, 1920, 0, 0, 16, 8, 6, 503, 270),
+    (1, 1080, 1920, 0, 0, 5, 6, 10, 504, 270),
+    (1, 2160, 3840, 0, 0, 16, 8, 6, 505, 270),
+    (0, 568, 1388, 0, 0, 12, 3, 4, 506, 1000),      # maxCalcRes above the default: 1388-wide grid, windows > 32 at neighbour-term levels
+    (1, 540, 960, 0, 0, 9, 8, 6, 507, 540),         # rs = 0 at qHD
 ])
-def test_hip_matches_live_reference(native_lib, hdr, H, W, si, so, R, delta, nb, seed):
+def test_hip_matches_live_reference(native_lib, hdr, H, W, si, so, R, delta, nb, seed, max_res):
     from hopperrender_amd import synth
     from hopperrender_amd.calc import OpticalFlowCalcHDR, OpticalFlowCalcSDR
     from oracle import oracle
@@ -23,7 +25,7 @@ def test_hip_matches_live_reference(native_lib, hdr, H, W, si, so, R, delta, nb,
     sc = synth.Scene(H, W, bool(hdr), seed, in_stride=si)
     f = [sc.frame(k) for k in range(4)]
     tvals = [0.0, 0.1998, 0.5994, 0.999]
-    s = oracle.RefSession(hdr, H, W, si, so, delta, nb, 0.0, 255.0, 270)
+    s = oracle.RefSession(hdr, H, W, si, so, delta, nb, 0.0, 255.0, max_res)
     s.radius(R)
     for x in f[:3]:
         s.update(x)
@@ -35,7 +37,7 @@ def test_hip_matches_live_reference(native_lib, hdr, H, W, si, so, R, delta, nb,
     s.copy(); s.download("copy")
     js, ref = s.run()
 
-    c = (OpticalFlowCalcHDR if hdr else OpticalFlowCalcSDR)(H, W, si, so, delta, nb, 0.0, 255.0, 270)
+    c = (OpticalFlowCalcHDR if hdr else OpticalFlowCalcSDR)(H, W, si, so, delta, nb, 0.0, 255.0, max_res)
     c.m_opticalFlowSearchRadius = R
     for x in f[:3]:
         c.updateFrame(x)
