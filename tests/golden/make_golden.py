@@ -61,6 +61,8 @@ CASES = [
     dict(name="sdr_scenecut", hdr=0, H=180, W=320, si=0, so=0, seed=42, params=[(8, 8, 6)], content="cut"),
     dict(name="sdr_1080p", hdr=0, H=1080, W=1920, si=0, so=0, seed=1234, params=[(5, 8, 6), (16, 8, 6)], big=True),
     dict(name="hdr_2160p", hdr=1, H=2160, W=3840, si=0, so=0, seed=1234, params=[(16, 8, 6), (16, 8, 10)], big=True),
+    # maxCalcRes above the default: no down-scaling, a 1040-wide grid whose levels with the neighbour term still have windows > 32
+    dict(name="sdr_widegrid_rs0", hdr=0, H=200, W=1040, si=0, so=0, seed=51, params=[(12, 3, 4), (16, 8, 6)], big=True, max_res=1000),
 ]
 
 
@@ -84,7 +86,7 @@ def run_case(case, outdir, modes_small=(0, 1, 2, 3, 4, 5, 6)):
     arrays = {}
     for (R, delta, nb) in case["params"]:
         key = f"R{R}_d{delta}_n{nb}"
-        s = oracle.RefSession(case["hdr"], case["H"], case["W"], case["si"], case["so"], delta, nb, 0.0, 255.0, 270)
+        s = oracle.RefSession(case["hdr"], case["H"], case["W"], case["si"], case["so"], delta, nb, 0.0, 255.0, case.get("max_res", 270))
         g = s.g
         s.radius(R)
         for f in frames[:3]:

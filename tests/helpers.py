@@ -55,7 +55,7 @@ class Golden:
 
 
 ALL_GOLDEN = ["sdr_180p", "hdr_180p", "sdr_360p", "hdr_360p", "sdr_ragged_strided", "hdr_ragged_strided",
-              "sdr_722p_rs2", "sdr_identical", "sdr_scenecut", "sdr_1080p", "hdr_2160p"]
+              "sdr_722p_rs2", "sdr_identical", "sdr_scenecut", "sdr_1080p", "hdr_2160p", "sdr_widegrid_rs0"]
 
 
 def parse_frame_name(name):

@@ -18,7 +18,7 @@ def test_flow_matches_reference(name):
     g = Golden(name)
     frames = g.frames()
     c = g.case
-    geom = oracle.make_geom(c["hdr"], c["H"], c["W"], c["si"], c["so"])
+    geom = oracle.make_geom(c["hdr"], c["H"], c["W"], c["si"], c["so"], c.get("max_res", 270))
     keys = g.keys if name in SMALL else g.keys[-1:]          # full-size cases: one parameter set (CPU time)
     for key in keys:
         R, delta, nb = g.params(key)
@@ -39,7 +39,7 @@ def test_warp_and_copy_match_reference(name):
     g = Golden(name)
     frames = g.frames()
     c = g.case
-    geom = oracle.make_geom(c["hdr"], c["H"], c["W"], c["si"], c["so"])
+    geom = oracle.make_geom(c["hdr"], c["H"], c["W"], c["si"], c["so"], c.get("max_res", 270))
     key = g.keys[-1]
     flow = g.arr(key, "blur_a")
     for fname in g.frame_names(key):

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 def make_calc(case, R, delta, nb, **kw):
     from hopperrender_amd.calc import OpticalFlowCalcHDR, OpticalFlowCalcSDR
     cls = OpticalFlowCalcHDR if case["hdr"] else OpticalFlowCalcSDR
-    c = cls(case["H"], case["W"], case["si"], case["so"], delta, nb, 0.0, 255.0, 270, **kw)
+    c = cls(case["H"], case["W"], case["si"], case["so"], delta, nb, 0.0, 255.0, case.get("max_res", 270), **kw)
     c.m_opticalFlowSearchRadius = R
     return c
 
