@@ -1146,8 +1146,8 @@ int hf_read_offsets(hf_ctx* c, int16_t* host_out) {
     if (int rc = set_device(c)) return rc;
     if (int rc = sync_ctx(c)) return rc;
     hf::launch_expand_offsets(c->g, c->last_level, c->off_view, c->stream);
+    HF_HIP(c, hipMemcpyAsync(host_out, c->off_view, 2 * c->plane_elems * sizeof(int16_t), hipMemcpyDeviceToHost, c->stream));
     HF_HIP(c, hipStreamSynchronize(c->stream));
-    HF_HIP(c, hipMemcpy(host_out, c->off_view, 2 * c->plane_elems * sizeof(int16_t), hipMemcpyDeviceToHost));
     return HF_OK;
 }
 
@@ -1156,7 +1156,8 @@ int hf_read_blurred_flow(hf_ctx* c, int idx, int16_t* host_out) {
     if (!host_out || idx < 0 || idx > 1) return fail(c, HF_ERR_INVALID_ARGUMENT, "hf_read_blurred_flow: bad argument");
     if (int rc = set_device(c)) return rc;
     if (int rc = sync_ctx(c)) return rc;
-    HF_HIP(c, hipMemcpy(host_out, c->blurred[idx], 2 * c->plane_elems * sizeof(int16_t), hipMemcpyDeviceToHost));
+    HF_HIP(c, hipMemcpyAsync(host_out, c->blurred[idx], 2 * c->plane_elems * sizeof(int16_t), hipMemcpyDeviceToHost, c->stream));
+    HF_HIP(c, hipStreamSynchronize(c->stream));
     return HF_OK;
 }
 
@@ -1165,7 +1166,7 @@ int hf_write_blurred_flow(hf_ctx* c, int idx, const int16_t* host_in) {
     if (!host_in || idx < 0 || idx > 1) return fail(c, HF_ERR_INVALID_ARGUMENT, "hf_write_blurred_flow: bad argument");
     if (int rc = set_device(c)) return rc;
     if (int rc = sync_ctx(c)) return rc;
-    HF_HIP(c, hipMemcpy(c->blurred[idx], host_in, 2 * c->plane_elems * sizeof(int16_t), hipMemcpyHostToDevice));
+    HF_HIP(c, hipMemcpyAsync(c->blurred[idx], host_in, 2 * c->plane_elems * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
     hf::launch_pack_flow(c->g, c->blurred[idx], c->blurred_xy[idx], c->stream);
     HF_HIP(c, hipStreamSynchronize(c->stream));
     return HF_OK;
@@ -1195,10 +1196,10 @@ int hf_device_rcp(hf_ctx* c, const float* host_in, float* host_out, int n) {
     if (!host_in || !host_out || n < 1 || n > 32) return fail(c, HF_ERR_INVALID_ARGUMENT, "hf_device_rcp: bad argument");
     if (int rc = set_device(c)) return rc;
     if (int rc = sync_ctx(c)) return rc;
-    HF_HIP(c, hipMemcpy(c->d_probe, host_in, n * sizeof(float), hipMemcpyHostToDevice));
+    HF_HIP(c, hipMemcpyAsync(c->d_probe, host_in, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
     hf::launch_rcp_probe(c->d_probe, c->d_probe + 32, n, c->stream);
+    HF_HIP(c, hipMemcpyAsync(host_out, c->d_probe + 32, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HF_HIP(c, hipStreamSynchronize(c->stream));
-    HF_HIP(c, hipMemcpy(host_out, c->d_probe + 32, n * sizeof(float), hipMemcpyDeviceToHost));
     return HF_OK;
 }
 
@@ -1224,14 +1225,18 @@ int hf_host_malloc_pinned(size_t bytes, void** out) {
 
 int hf_host_free_pinned(void* p) { return hipHostFree(p) == hipSuccess ? HF_OK : HF_ERR_HIP; }
 
-int hf_memcpy_h2d(int device_index, void* d, const void* h, size_t bytes) {
+// The library never touches the legacy (null) stream: a synchronous hipMemcpy there while ANOTHER thread captures a
+// hipGraph on its own stream invalidates that capture (HIP error 906, seen as a rare failure of the threads test).
+static int util_copy(int device_index, void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
     if (hipSetDevice(device_index) != hipSuccess) return HF_ERR_NO_DEVICE;
-    return hipMemcpy(d, h, bytes, hipMemcpyHostToDevice) == hipSuccess ? HF_OK : HF_ERR_HIP;
+    hipStream_t s = shared_warp_stream(device_index);   // per-device non-blocking utility stream (shared with HF_FLAG_SHARED_WARP_STREAM)
+    if (!s) return HF_ERR_HIP;
+    if (hipMemcpyAsync(dst, src, bytes, kind, s) != hipSuccess) return HF_ERR_HIP;
+    return hipStreamSynchronize(s) == hipSuccess ? HF_OK : HF_ERR_HIP;
 }
 
-int hf_memcpy_d2h(int device_index, void* h, const void* d, size_t bytes) {
-    if (hipSetDevice(device_index) != hipSuccess) return HF_ERR_NO_DEVICE;
-    return hipMemcpy(h, d, bytes, hipMemcpyDeviceToHost) == hipSuccess ? HF_OK : HF_ERR_HIP;
-}
+int hf_memcpy_h2d(int device_index, void* d, const void* h, size_t bytes) { return util_copy(device_index, d, h, bytes, hipMemcpyHostToDevice); }
+
+int hf_memcpy_d2h(int device_index, void* h, const void* d, size_t bytes) { return util_copy(device_index, h, d, bytes, hipMemcpyDeviceToHost); }
 
 }  // extern "C"

@@ -369,3 +369,15 @@ def test_wide_grid_large_windows_with_neighbour_term(native_lib, hdr, H, W, max_
         assert (c.readBlurredFlow(1) == blur_o).all(), it
         assert c.m_totalFrameDelta == tot_o
         c.close()
+
+
+def test_threads_capture_and_readback_stress(native_lib):
+    """Several host threads creating contexts, capturing their flow graphs and reading results back at the same time.
+    The library must stay off the legacy (null) stream: a synchronous hipMemcpy there while another thread captures
+    invalidates that capture (HIP error 906).  tools/stress_threads.py, 6 rounds."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_threads.py"), "6"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-600:] + r.stderr[-600:]
