@@ -142,3 +142,35 @@ def test_cli_y4m_matches_raw(native_lib, tmp_path, hdr):
     for a, b in zip(got, raw):
         # Y4M keeps the 10-bit code only: P010's low 6 bits (levels stretch residue) are cut on write
         assert (a == ((b >> 6) << 6 if hdr else b)).all()
+
+
+@pytest.mark.parametrize("hdr", [0, 1])
+def test_long_run_last_period_matches_oracle(native_lib, hdr):
+    """60 source periods through hf_interpolate_period (graph replay, ring / ping-pong phases cycling, fused warps into
+    caller buffers): the outputs of the LAST period still equal the oracle's, which only needs the last three frames."""
+    from hopperrender_amd import capi, synth
+    from hopperrender_amd.calc import DeviceBuffer
+    from hopperrender_amd.protocol import SOURCE_24, BlendSchedule
+    from oracle import oracle
+    H, W, n = 180, 320, 60
+    sc = synth.Scene(H, W, bool(hdr), 61)
+    frames = [sc.frame(k % 9) for k in range(n)]
+    dev = []
+    for f in frames[:9]:
+        b = DeviceBuffer(f.nbytes); b.upload(f); dev.append(b)
+    c = calc_for(hdr, H, W, search_radius=11, flags=capi.HF_FLAG_ASYNC | capi.HF_FLAG_NO_TIMING)
+    plan = BlendSchedule(SOURCE_24, 83333).plan(n)
+    outs = [DeviceBuffer(c.output_frame_bytes) for _ in range(6)]
+    for k in range(n):
+        c.interpolatePeriod(dev[k % 9].ptr, plan[k], [o.ptr for o in outs], 2)
+    c.sync()
+    g = oracle.make_geom(hdr, H, W)
+    f0, f1, f2 = frames[n - 3], frames[n - 2], frames[n - 1]
+    _, blur_prev, _, _ = oracle.calculate_optical_flow(f0, f1, g, 11)       # flow the last period's warps use
+    off, blur, tot, _ = oracle.calculate_optical_flow(f1, f2, g, 11)
+    assert (c.readOffsets() == off).all() and (c.readBlurredFlow(1) == blur).all() and c.m_totalFrameDelta == tot
+    assert (c.readBlurredFlow(0) == blur_prev).all()
+    dt = np.uint16 if hdr else np.uint8
+    for t, o in zip(plan[n - 1], outs):
+        assert (o.download(dt, H * W * 3 // 2) == oracle.warp_frames(f0, f1, blur_prev, g, t, 2)).all(), t
+    c.close()
