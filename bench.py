@@ -165,12 +165,15 @@ def main():
     backend = os.environ.get("HF_BENCH_BACKEND", "nccl")
     dev_index = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(dev_index)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
-        else:
-            dist.init_process_group(backend)
+    def init_dist():
+        # Called AFTER the pair streams exist: HIP deals streams to its few hardware queues in creation order, and the
+        # communicator's own streams must not push two pair streams onto one queue (DESIGN.md "Hardware queues").
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+            else:
+                dist.init_process_group(backend)
     n_gpus = world
     if a.gpus != n_gpus and rank == 0 and world > 1:
         print(f"warning: --gpus {a.gpus} but WORLD_SIZE {world}", file=sys.stderr)
@@ -285,6 +288,7 @@ def main():
             c.sync()
         torch.cuda.synchronize()
 
+    init_dist()
     for i in range(a.warmup):
         run_step(i)
     sync_all()

@@ -21,6 +21,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <shared_mutex>
 #include <new>
 #include <string>
 #include <tuple>
@@ -54,6 +55,7 @@ hipStream_t shared_warp_stream(int device) {
 }
 
 // HF_FLAG_WARP_TURNSTILE: the event behind the most recently issued warp launch of any such context, per device
+std::shared_mutex g_capture_mutex;   // shared: a stream capture is in progress; exclusive: a legacy-stream copy (util_copy)
 std::mutex g_turnstile_mutex;
 std::map<int, hipEvent_t> g_turnstile_last;
 
@@ -786,9 +788,11 @@ int hf_calculate_optical_flow(hf_ctx* c) {
         auto it = c->graphs.find(key);
         if (it == c->graphs.end()) {
             hipGraph_t graph = nullptr;
+            std::shared_lock<std::shared_mutex> capture_lock(g_capture_mutex);
             HF_HIP(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
             const int rc = enqueue_flow_chain(c);
             const hipError_t e = hipStreamEndCapture(c->stream, &graph);
+            capture_lock.unlock();
             if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
             HF_HIP(c, e);
             hipGraphExec_t exec = nullptr;
@@ -915,9 +919,11 @@ int hf_batch_calculate_optical_flow(hf_batch* b) {
     auto it = b->graphs.find(key);
     if (it == b->graphs.end()) {
         hipGraph_t graph = nullptr;
+        std::shared_lock<std::shared_mutex> capture_lock(g_capture_mutex);
         if (hipStreamBeginCapture(b->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return batch_fail(b, HF_ERR_HIP, "hipStreamBeginCapture failed");
         const int rc = enqueue_flow_chain(b->members.data(), n, b->stream);
         const hipError_t e = hipStreamEndCapture(b->stream, &graph);
+        capture_lock.unlock();
         if (rc || e != hipSuccess) { if (graph) hipGraphDestroy(graph); return batch_fail(b, rc ? rc : HF_ERR_HIP, rc ? l->err : "hipStreamEndCapture failed"); }
         hipGraphExec_t exec = nullptr;
         const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
@@ -1225,14 +1231,15 @@ int hf_host_malloc_pinned(size_t bytes, void** out) {
 
 int hf_host_free_pinned(void* p) { return hipHostFree(p) == hipSuccess ? HF_OK : HF_ERR_HIP; }
 
-// The library never touches the legacy (null) stream: a synchronous hipMemcpy there while ANOTHER thread captures a
-// hipGraph on its own stream invalidates that capture (HIP error 906, seen as a rare failure of the threads test).
+// hf_memcpy_* have no context, hence no stream of their own, and an extra stream would occupy one of the few hardware
+// queues the pair streams need (DESIGN.md "Hardware queues": 50 k -> 42 k frames/s with one more stream alive, 35 k
+// with short-lived ones).  They use the legacy stream -- but never while a thread of this process captures a graph: a
+// synchronous hipMemcpy there invalidates the capture (HIP error 906, a rare failure of the threads test; 130 errors
+// under tools/stress_threads.py).  Captures hold g_capture_mutex shared, these copies exclusively.
 static int util_copy(int device_index, void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
     if (hipSetDevice(device_index) != hipSuccess) return HF_ERR_NO_DEVICE;
-    hipStream_t s = shared_warp_stream(device_index);   // per-device non-blocking utility stream (shared with HF_FLAG_SHARED_WARP_STREAM)
-    if (!s) return HF_ERR_HIP;
-    if (hipMemcpyAsync(dst, src, bytes, kind, s) != hipSuccess) return HF_ERR_HIP;
-    return hipStreamSynchronize(s) == hipSuccess ? HF_OK : HF_ERR_HIP;
+    std::unique_lock<std::shared_mutex> lock(g_capture_mutex);
+    return hipMemcpy(dst, src, bytes, kind) == hipSuccess ? HF_OK : HF_ERR_HIP;
 }
 
 int hf_memcpy_h2d(int device_index, void* d, const void* h, size_t bytes) { return util_copy(device_index, d, h, bytes, hipMemcpyHostToDevice); }
