@@ -176,9 +176,14 @@ def test_batched_async_contexts_match_blocking_path(native_lib):
                     outs.append(c.downloadFrame().copy())
         want.append(outs)
         c.close()
-    run_batched(frames, want, ts, capi.HF_FLAG_ASYNC | capi.HF_FLAG_SHARED_WARP_STREAM)
-    run_batched(frames, want, ts, capi.HF_FLAG_ASYNC | capi.HF_FLAG_DUAL_STREAM)
-    run_batched(frames, want, ts, capi.HF_FLAG_ASYNC | capi.HF_FLAG_NO_FUSED_WARP)
+    A = capi.HF_FLAG_ASYNC
+    for extra in (capi.HF_FLAG_SHARED_WARP_STREAM, capi.HF_FLAG_DUAL_STREAM, capi.HF_FLAG_NO_FUSED_WARP,
+                  capi.HF_FLAG_PRIORITY_STREAMS, capi.HF_FLAG_WARP_TURNSTILE, capi.HF_FLAG_NO_TIMING,
+                  capi.HF_FLAG_NO_GRAPH, capi.HF_FLAG_NO_LAZY_ARGMIN, capi.HF_FLAG_PROFILE,
+                  capi.HF_FLAG_DUAL_STREAM | capi.HF_FLAG_WARP_TURNSTILE | capi.HF_FLAG_NO_TIMING,
+                  capi.HF_FLAG_NO_GRAPH | capi.HF_FLAG_NO_LAZY_ARGMIN | capi.HF_FLAG_NO_FUSED_WARP,
+                  capi.HF_FLAG_SHARED_WARP_STREAM | capi.HF_FLAG_PROFILE | capi.HF_FLAG_NO_TIMING):
+        run_batched(frames, want, ts, A | extra)
 
 
 def run_batched(frames, want, ts, flags):
