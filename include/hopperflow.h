@@ -56,7 +56,8 @@ typedef enum hf_output_mode {
 #define HF_FLAG_NO_LAZY_ARGMIN 0x8 /* large windows: take every argmin in a launch of its own (debug / A-B timing) */
 #define HF_FLAG_SHARED_WARP_STREAM 0x10 /* batch hosts: warp kernels of all contexts of a device are issued on one shared
                                            stream (they are bandwidth-bound: back-to-back beats side by side), the
-                                           latency-bound flow chains of the other contexts overlap them */
+                                           latency-bound flow chains of the other contexts overlap them.  Measured slower
+                                           than one stream per context on MI355X, like the next three */
 #define HF_FLAG_PRIORITY_STREAMS 0x20 /* batch hosts: the context's flow chain runs on a high-priority stream, its warp
                                          kernels on a low-priority one (tied by events), so the short latency-bound
                                          chain kernels are not starved by other contexts' bandwidth-bound warps */
@@ -70,7 +71,8 @@ typedef enum hf_output_mode {
                                    back-to-back kernels, ~15 us per source period in a throughput pipeline */
 #define HF_FLAG_WARP_TURNSTILE 0x100 /* the warp launches of all such contexts on a device run one at a time (each waits
                                         for the previously issued one): two bandwidth-bound warps gain nothing from
-                                        overlapping each other, the other streams' flow chains fill in instead */
+                                        overlapping each other, the other streams' flow chains fill in instead.
+                                        Measured: shorter launches (105 vs 160 us) but 41.7 k instead of 45.8 k frames/s */
 #define HF_FLAG_PROFILE 0x4  /* bracket every warp/copy launch and every flow chain with HIP events on ctx's
                                 stream; totals are read with hf_get_profile() (bench.py's live roofline figure) */
 
