@@ -303,6 +303,7 @@ def main():
     frames_out = 0
     for i in range(a.warmup, a.warmup + a.steps):
         frames_out += run_step(i)
+    host_enqueue_s = time.perf_counter() - t0     # the host is done issuing; the GPU may still be busy
     sync_all()
     if world > 1:
         dist.barrier()
@@ -381,6 +382,7 @@ def main():
             "unit": "frames/s",
             "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(1e3 * elapsed_max / a.steps, 4),
+            "host_enqueue_ms_per_step": round(1e3 * host_enqueue_s / a.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u16" if hdr else "u8", "data": "synthetic",
             "config": {"workload": a.workload, "description": desc, "search_radius": a.radius,
