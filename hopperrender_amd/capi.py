@@ -18,6 +18,7 @@ HF_FLAG_DUAL_STREAM = 0x40
 HF_FLAG_NO_FUSED_WARP = 0x80
 HF_FLAG_WARP_TURNSTILE = 0x100
 HF_FLAG_NO_TIMING = 0x200
+HF_FLAG_DEFER_PREP = 0x400
 
 (HF_OK, HF_ERR_INVALID_ARGUMENT, HF_ERR_NO_DEVICE, HF_ERR_OUT_OF_MEMORY, HF_ERR_HIP, HF_ERR_STATE) = (0, -1, -2, -3, -4, -5)
 

@@ -468,7 +468,15 @@ int update_common(hf_ctx* c, const void* src, hipMemcpyKind kind, bool by_refere
         c->ring[0] = c->ring_store[0];
         HF_HIP(c, hipMemcpyAsync(c->ring[0], src, c->in_bytes, kind, c->stream));
     }
-    hf::launch_prep_frame(c->g, c->pl, c->ring[0], c->py[0], c->puv[0], c->stream);
+    if ((c->cfg.flags & HF_FLAG_DEFER_PREP) && !c->io_in) {
+        // The chain reads ALL phases of frame N-1 but only the grid samples (phase 0) of frame N.  So: only those for
+        // the new frame now, and the full planes of the frame that becomes N-1 right here, just before the chain that
+        // gathers from them -- they are still in L2 / the Infinity Cache then, instead of a whole period old.
+        hf::launch_prep_phase0(c->g, c->pl, c->ring[0], c->py[0], c->puv[0], c->stream);
+        hf::launch_prep_frame(c->g, c->pl, c->ring[2], c->py[2], c->puv[2], c->stream);
+    } else {
+        hf::launch_prep_frame(c->g, c->pl, c->ring[0], c->py[0], c->puv[0], c->stream);
+    }
     HF_HIP(c, hipGetLastError());
     if (c->io_in) HF_HIP(c, hipEventRecord(c->ev_slot_prep[0], c->stream));
     rotate_after_upload(c);

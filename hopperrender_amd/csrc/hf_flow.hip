@@ -183,6 +183,19 @@ __global__ __launch_bounds__(128) void prep_phase_fast_kernel(const E* __restric
     }
 }
 
+// Only what the refinement chain reads of frame N (its "frame 2" operand): the grid samples = phase 0 of the rows
+// y = cy << rs (calcDeltaSumsKernelSDR.h:98-100).  One thread per grid point; 1/64 of the luma plane at rs = 3.
+template <typename E>
+__global__ __launch_bounds__(256) void prep_phase0_kernel(const E* __restrict__ f, uint8_t* __restrict__ py, uint16_t* __restrict__ puv,
+                                                          int H, int W, int S, int lw, int lh, int rs, PhaseLayout pl) {
+    const int cx = blockIdx.x * 64 + (threadIdx.x & 63), cy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (cx >= lw || cy >= lh) return;
+    const int sx = min(cx << rs, W - 1), sy = min(cy << rs, H - 1);      // (the grid is ceil(W / 2^rs): its last column / row may start outside)
+    py[(size_t)sy * pl.nph * pl.lwp + pl.mx + cx] = (uint8_t)top8<E>(f[(size_t)sy * S + sx]);
+    const E* uv = f + (size_t)H * S + (size_t)(sy >> 1) * S + (sx & ~1);
+    puv[(size_t)(sy >> 1) * pl.nph2 * pl.lwp + pl.mx + cx] = (uint16_t)(top8<E>(uv[0]) | (top8<E>(uv[1]) << 8));
+}
+
 // ------------------------------------------------------------------------------------------
 // per-window constants
 // ------------------------------------------------------------------------------------------
@@ -728,6 +741,12 @@ void launch_prep_frame(const Geom& g, const PhaseLayout& pl, const void* frame, 
     const size_t smem = (size_t)((g.W + 15) / 16) * 16 + 16;
     if (g.hdr) prep_phase_kernel<uint16_t><<<rows, 256, smem, stream>>>((const uint16_t*)frame, py, puv, g.H, g.W, g.in_stride, pl);
     else prep_phase_kernel<uint8_t><<<rows, 256, smem, stream>>>((const uint8_t*)frame, py, puv, g.H, g.W, g.in_stride, pl);
+}
+
+void launch_prep_phase0(const Geom& g, const PhaseLayout& pl, const void* frame, uint8_t* py, uint16_t* puv, hipStream_t stream) {
+    const dim3 grd((g.lw + 63) / 64, (g.lh + 3) / 4);
+    if (g.hdr) prep_phase0_kernel<uint16_t><<<grd, 256, 0, stream>>>((const uint16_t*)frame, py, puv, g.H, g.W, g.in_stride, g.lw, g.lh, g.rs, pl);
+    else prep_phase0_kernel<uint8_t><<<grd, 256, 0, stream>>>((const uint8_t*)frame, py, puv, g.H, g.W, g.in_stride, g.lw, g.lh, g.rs, pl);
 }
 
 void launch_flow_level_small(const Geom& g, const FlowBatch& b, hipStream_t stream) {

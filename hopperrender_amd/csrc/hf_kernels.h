@@ -93,6 +93,8 @@ struct BlurBatch {
 
 // Re-lay a freshly uploaded frame as phase planes (once per frame).
 void launch_prep_frame(const Geom& g, const PhaseLayout& pl, const void* frame, uint8_t* py, uint16_t* puv, hipStream_t stream);
+// Only the entries the chain reads of its NEWER frame (phase 0 of the rows cy << rs); the full planes can follow later.
+void launch_prep_phase0(const Geom& g, const PhaseLayout& pl, const void* frame, uint8_t* py, uint16_t* puv, hipStream_t stream);
 // Windows <= 32: X and Y step of one level in a single launch.
 void launch_flow_level_small(const Geom& g, const FlowBatch& b, hipStream_t stream);
 // Windows > 32, one axis: partial SAD sums (atomics), then argmin + table update.

@@ -69,6 +69,10 @@ typedef enum hf_output_mode {
 #define HF_FLAG_NO_TIMING 0x200 /* do not record the events behind m_ofcCalcTime / m_warpCalcTime (hf_stats times stay 0).
                                    Every timing event is a barrier packet on the stream: measured 5-6 us each between
                                    back-to-back kernels, ~15 us per source period in a throughput pipeline */
+#define HF_FLAG_DEFER_PREP 0x400 /* updateFrame builds only the grid samples of the new frame and the full phase planes of the
+                                    PREVIOUS one (the frame the next flow calculation gathers from), so they are still cached.
+                                    Measured: no effect on throughput (51.6 k either way) -- the chain is not held back by
+                                    cold phase planes */
 #define HF_FLAG_WARP_TURNSTILE 0x100 /* the warp launches of all such contexts on a device run one at a time (each waits
                                         for the previously issued one): two bandwidth-bound warps gain nothing from
                                         overlapping each other, the other streams' flow chains fill in instead.

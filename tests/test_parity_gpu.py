@@ -179,7 +179,8 @@ def test_batched_async_contexts_match_blocking_path(native_lib):
     A = capi.HF_FLAG_ASYNC
     for extra in (capi.HF_FLAG_SHARED_WARP_STREAM, capi.HF_FLAG_DUAL_STREAM, capi.HF_FLAG_NO_FUSED_WARP,
                   capi.HF_FLAG_PRIORITY_STREAMS, capi.HF_FLAG_WARP_TURNSTILE, capi.HF_FLAG_NO_TIMING,
-                  capi.HF_FLAG_NO_GRAPH, capi.HF_FLAG_NO_LAZY_ARGMIN, capi.HF_FLAG_PROFILE,
+                  capi.HF_FLAG_NO_GRAPH, capi.HF_FLAG_NO_LAZY_ARGMIN, capi.HF_FLAG_PROFILE, capi.HF_FLAG_DEFER_PREP,
+                  capi.HF_FLAG_DEFER_PREP | capi.HF_FLAG_DUAL_STREAM | capi.HF_FLAG_NO_TIMING,
                   capi.HF_FLAG_DUAL_STREAM | capi.HF_FLAG_WARP_TURNSTILE | capi.HF_FLAG_NO_TIMING,
                   capi.HF_FLAG_NO_GRAPH | capi.HF_FLAG_NO_LAZY_ARGMIN | capi.HF_FLAG_NO_FUSED_WARP,
                   capi.HF_FLAG_SHARED_WARP_STREAM | capi.HF_FLAG_PROFILE | capi.HF_FLAG_NO_TIMING):

@@ -47,7 +47,7 @@ def test_random_configuration_matches_oracle(native_lib, seed):
     g = oracle.make_geom(hdr, H, W, k["si"], k["so"], k["max_res"])
     cls = OpticalFlowCalcHDR if hdr else OpticalFlowCalcSDR
     c = cls(H, W, k["si"], k["so"], k["delta"], k["nb"], k["black"], k["white"], k["max_res"], iterations=k["iters"],
-            blur_radius=k["blur"], search_radius=k["R"], flags=capi.HF_FLAG_ASYNC if seed % 2 else 0)
+            blur_radius=k["blur"], search_radius=k["R"], flags=(capi.HF_FLAG_ASYNC if seed % 2 else 0) | (capi.HF_FLAG_DEFER_PREP if seed % 3 == 1 else 0))
     for x in f[:3]:
         c.updateFrame(x)
     c.calculateOpticalFlow()
