@@ -736,6 +736,8 @@ static bool launch_warp_fast(const Geom& g, const WarpArgs& a, hipStream_t strea
                       g.W >= 2 * VEC && group * (int)sizeof(E) >= 4 && VEC % group == 0 && VEC / group <= 4;
     if (!fast) return false;
     const int rows = 2;  // rows per thread (divides the 2^rs rows of a flow cell); measured on MI355X, 2160p HDR blend: 1 row 25.9 us, 2 rows 24.3 us, 4 rows 30.2 us
+                         // (re-measured with the final kernel, fused period HBM-cold: 2 rows 51.1 us, 4 rows 59.3 us -- halving the
+                         // per-element scalar work does not pay for halving the number of waves)
     const int y_groups = (g.H + rows - 1) / rows, uv_groups = ((g.H >> 1) + rows - 1) / rows;
     const int wpr = (g.W + 64 * VEC - 1) / (64 * VEC);
     const int n_blocks = (wpr * (y_groups + uv_groups) + HF_WARP_WAVES - 1) / HF_WARP_WAVES;
