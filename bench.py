@@ -399,14 +399,14 @@ def main():
             "ms_per_flow_calc_isolated": round(isolated["flow_chain_us"] / 1e3, 4) if isolated else None,
             "roofline": roof,
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:   # reported baselines: rank 0 at N = 1 only
             try:
                 out["cpu_baseline"] = cpu_baseline(hdr, H, W, target, a.radius, a.neighbor, host_frames, a.cpu_sample_pairs)
                 out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
                 out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(hdr, H, W, target, a.radius, a.neighbor, host_frames)
             except Exception as e:  # the checker must never take the measurement down
                 out["cpu_baseline"] = {"error": repr(e)}
-        if not a.no_reference:
+        if not a.no_reference and world == 1:
             try:
                 r = reference_opencl(hdr, H, W, target, a.radius, a.neighbor, host_frames)
                 if r:
