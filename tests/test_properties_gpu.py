@@ -174,3 +174,71 @@ def test_long_run_last_period_matches_oracle(native_lib, hdr):
     for t, o in zip(plan[n - 1], outs):
         assert (o.download(dt, H * W * 3 // 2) == oracle.warp_frames(f0, f1, blur_prev, g, t, 2)).all(), t
     c.close()
+
+
+def test_period_with_many_outputs_and_edge_scalars(native_lib):
+    """hf_interpolate_period with more outputs than one fused launch takes (6), t = 0 and t = 1 exactly, duplicates,
+    and an empty period; every output equals the single-launch warpFrames result."""
+    from hopperrender_amd import capi, synth
+    from hopperrender_amd.calc import DeviceBuffer
+    H, W, hdr = 180, 320, 1
+    sc = synth.Scene(H, W, True, 73)
+    f = [sc.frame(k) for k in range(4)]
+    dev = [DeviceBuffer(x.nbytes) for x in f]
+    for d, x in zip(dev, f):
+        d.upload(x)
+    c = calc_for(hdr, H, W, search_radius=9, flags=capi.HF_FLAG_ASYNC)
+    for d in dev[:3]:
+        c.updateFrameDeviceRef(d.ptr)
+    c.calculateOpticalFlow()
+    ts = [0.0, 1.0, 0.5, 0.5, 0.125, 0.999, 0.001, 0.25, 0.75, 1.0, 0.0, 0.3996, 0.7992]      # 13 outputs: 6 + 6 + 1
+    outs = [DeviceBuffer(c.output_frame_bytes) for _ in ts]
+    c.interpolatePeriod(dev[3].ptr, ts, [o.ptr for o in outs], 2)
+    c.interpolatePeriod(0, [], [], 2)             # no new frame, no outputs: just another flow calculation
+    c.sync()
+    ref = calc_for(hdr, H, W, search_radius=9)
+    for x in f:
+        ref.updateFrame(x)
+        if x is f[2] or x is f[3]:
+            ref.calculateOpticalFlow()
+    for t, o in zip(ts, outs):
+        ref.warpFrames(t, 2)
+        assert (o.download(np.uint16, H * W * 3 // 2) == ref.downloadFrame()).all(), t
+    c.close(); ref.close()
+
+
+@pytest.mark.parametrize("hdr", [0, 1])
+def test_misaligned_device_pointers_take_the_generic_paths(native_lib, hdr):
+    """Source frames and output buffers that are only element-aligned (not 4 / 16 bytes): none of the vector paths may be
+    selected, the results stay identical."""
+    from hopperrender_amd import capi, synth
+    from hopperrender_amd.calc import DeviceBuffer
+    H, W = 180, 320
+    el = 2 if hdr else 1
+    sc = synth.Scene(H, W, bool(hdr), 91)
+    f = [sc.frame(k) for k in range(4)]
+    off = el                                     # one element off every alignment
+    dev = [DeviceBuffer(x.nbytes + 64) for x in f]
+    lib = capi.load()
+    for d, x in zip(dev, f):
+        assert lib.hf_memcpy_h2d(0, d.ptr + off, x.ctypes.data, x.nbytes) == 0
+    c = calc_for(hdr, H, W, search_radius=9, flags=capi.HF_FLAG_ASYNC)
+    ref = calc_for(hdr, H, W, search_radius=9)
+    for d, x in zip(dev[:3], f[:3]):
+        c.updateFrameDeviceRef(d.ptr + off)
+        ref.updateFrame(x)
+    c.calculateOpticalFlow(); ref.calculateOpticalFlow()
+    ts = [0.0, 0.3996, 0.7992, 1.0]
+    outs = [DeviceBuffer(c.output_frame_bytes + 64) for _ in ts]
+    c.interpolatePeriod(dev[3].ptr + off, ts, [o.ptr + off for o in outs], 2)
+    c.sync()
+    ref.updateFrame(f[3]); ref.calculateOpticalFlow()
+    assert (c.readOffsets() == ref.readOffsets()).all() and (c.readBlurredFlow(1) == ref.readBlurredFlow(1)).all()
+    dt = np.uint16 if hdr else np.uint8
+    n = H * W * 3 // 2
+    for t, o in zip(ts, outs):
+        ref.warpFrames(t, 2)
+        got = np.empty(n, dtype=dt)
+        assert lib.hf_memcpy_d2h(0, got.ctypes.data, o.ptr + off, got.nbytes) == 0
+        assert (got == ref.downloadFrame()).all(), t
+    c.close(); ref.close()
