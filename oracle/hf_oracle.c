@@ -75,7 +75,10 @@ static inline void store_el(void* f, int hdr, long idx, unsigned v) {
     if (hdr) ((uint16_t*)f)[idx] = (uint16_t)v; else ((uint8_t*)f)[idx] = (uint8_t)v;
 }
 static inline unsigned absdiff_u(unsigned a, unsigned b) { return a > b ? a - b : b - a; }
-static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+/* OpenCL clamp(x, lo, hi) = min(max(x, lo), hi); the order matters only when lo > hi (mirrorCoordinate on a plane of
+ * 2 rows, i.e. 4-row frames: clamp(r, 1, 0)), where the reference as run on the MI355X returns hi -- checked live
+ * with tools/debug_tiny_ref.py */
+static inline int clampi(int v, int lo, int hi) { const int m = v < lo ? lo : v; return m > hi ? hi : m; }
 
 /* ---- calcDeltaSums -------------------------------------------------------------------- */
 

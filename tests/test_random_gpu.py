@@ -86,3 +86,33 @@ def test_random_configuration_matches_oracle(native_lib, seed):
     c.copyFrame()
     assert (c.downloadFrame() == oracle.copy_frame(f[1], g, k["black"], k["white"])).all(), k
     c.close()
+
+
+@pytest.mark.parametrize("hdr,H,W", [(0, 4, 4), (1, 4, 4), (0, 6, 10), (1, 8, 6), (0, 4, 64), (1, 64, 4), (0, 10, 34), (1, 16, 16), (0, 2 * 135, 2 * 3), (1, 12, 130)])
+def test_tiny_frames_match_oracle(native_lib, hdr, H, W):
+    """The smallest frames the C ABI accepts (even sizes >= 4): degenerate pyramids (1-3 levels), grids narrower than one
+    strip / one tile, all output modes."""
+    from hopperrender_amd import synth
+    from hopperrender_amd.calc import OpticalFlowCalcHDR, OpticalFlowCalcSDR
+    from oracle import oracle
+    f = [synth.random_frame(H, W, bool(hdr), seed=900 + 7 * i + H + W) for i in range(4)]
+    g = oracle.make_geom(hdr, H, W)
+    for R in (2, 5, 16):
+        c = (OpticalFlowCalcHDR if hdr else OpticalFlowCalcSDR)(H, W, search_radius=R)
+        for x in f[:3]:
+            c.updateFrame(x)
+        c.calculateOpticalFlow()
+        off, blur, tot, oob = oracle.calculate_optical_flow(f[1], f[2], g, R)
+        if oob == 0:
+            assert (c.readOffsets() == off).all(), (R, "offsets")
+            assert c.m_totalFrameDelta == tot
+        assert (c.readBlurredFlow(1) == oracle.blur_flow(c.readOffsets(), g, 4)).all(), (R, "blur")
+        c.updateFrame(f[3]); c.calculateOpticalFlow()
+        flow = c.readBlurredFlow(0)
+        for mode in (0, 1, 2, 4, 5, 6):
+            for t in (0.0, 0.43, 1.0):
+                c.warpFrames(t, mode)
+                assert (c.downloadFrame() == oracle.warp_frames(f[1], f[2], flow, g, t, mode)).all(), (R, mode, t)
+        c.copyFrame()
+        assert (c.downloadFrame() == oracle.copy_frame(f[1], g)).all()
+        c.close()

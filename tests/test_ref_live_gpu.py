@@ -54,3 +54,38 @@ def test_hip_matches_live_reference(native_lib, hdr, H, W, si, so, R, delta, nb,
     c.copyFrame()
     assert (c.downloadFrame() == ref["copy"]).all()
     c.close()
+
+
+@pytest.mark.parametrize("hdr,H,W", [(0, 4, 4), (1, 4, 4), (0, 6, 10)])
+def test_tiny_frames_match_live_reference(native_lib, hdr, H, W):
+    """4-row frames: the chroma plane has 2 rows and mirrorCoordinate's clamp(r, 1, dim - 2) has min > max -- OpenCL's
+    min(max()) order decides.  HIP path and oracle against the reference itself."""
+    from hopperrender_amd import synth
+    from hopperrender_amd.calc import OpticalFlowCalcHDR, OpticalFlowCalcSDR
+    from oracle import oracle
+    if not oracle.ref_available():
+        pytest.skip("oracle/_ref (the compiled reference) or an OpenCL GPU is not available")
+    f = [synth.random_frame(H, W, bool(hdr), seed=900 + 7 * i + H + W) for i in range(4)]
+    s = oracle.RefSession(hdr, H, W, 0, 0, 8, 6, 0.0, 255.0, 270)
+    s.radius(5)
+    for x in f[:3]:
+        s.update(x)
+    s.calc(); s.update(f[3]); s.calc()
+    s.dump_blurred(0, "flow")
+    for m in (0, 1, 2):
+        s.warp(0.43, m); s.download(f"w{m}")
+    s.copy(); s.download("copy")
+    js, ref = s.run()
+    c = (OpticalFlowCalcHDR if hdr else OpticalFlowCalcSDR)(H, W, search_radius=5)
+    for x in f[:3]:
+        c.updateFrame(x)
+    c.calculateOpticalFlow(); c.updateFrame(f[3]); c.calculateOpticalFlow()
+    assert (c.readBlurredFlow(0) == ref["flow"]).all()
+    g = oracle.make_geom(hdr, H, W)
+    for m in (0, 1, 2):
+        c.warpFrames(0.43, m)
+        assert (c.downloadFrame() == ref[f"w{m}"]).all(), m
+        assert (oracle.warp_frames(f[1], f[2], ref["flow"], g, 0.43, m) == ref[f"w{m}"]).all(), ("oracle", m)
+    c.copyFrame()
+    assert (c.downloadFrame() == ref["copy"]).all()
+    c.close()
