@@ -89,3 +89,38 @@ def test_tiny_frames_match_live_reference(native_lib, hdr, H, W):
     c.copyFrame()
     assert (c.downloadFrame() == ref["copy"]).all()
     c.close()
+
+
+@pytest.mark.parametrize("hdr", [0, 1])
+def test_degenerate_levels_match_live_reference(native_lib, hdr):
+    """Levels a settings UI can produce but no sane user wants: white == black, white = 0, black > white, out-of-range
+    values (division by zero / negative scale inside apply_levels): blend and copy against the reference itself."""
+    from hopperrender_amd import synth
+    from hopperrender_amd.calc import OpticalFlowCalcHDR, OpticalFlowCalcSDR
+    from oracle import oracle
+    if not oracle.ref_available():
+        pytest.skip("oracle/_ref (the compiled reference) or an OpenCL GPU is not available")
+    H, W = 36, 64
+    sc = synth.Scene(H, W, bool(hdr), 5)
+    f = [sc.frame(k) for k in range(4)]
+    g = oracle.make_geom(hdr, H, W)
+    for bk, wh in [(16.0, 16.0), (0.0, 0.0), (200.0, 100.0), (-20.0, 300.0), (0.0, 1e-3), (255.0, 0.0)]:
+        s = oracle.RefSession(hdr, H, W, 0, 0, 8, 6, bk, wh, 270)
+        s.radius(8)
+        for x in f[:3]:
+            s.update(x)
+        s.calc(); s.update(f[3]); s.calc()
+        s.warp(0.4, 2); s.download("w2")
+        s.copy(); s.download("copy")
+        js, ref = s.run()
+        c = (OpticalFlowCalcHDR if hdr else OpticalFlowCalcSDR)(H, W, 0, 0, 8, 6, bk, wh, 270, search_radius=8)
+        for x in f[:3]:
+            c.updateFrame(x)
+        c.calculateOpticalFlow(); c.updateFrame(f[3]); c.calculateOpticalFlow()
+        c.warpFrames(0.4, 2)
+        assert (c.downloadFrame() == ref["w2"]).all(), (bk, wh)
+        assert (oracle.warp_frames(f[1], f[2], c.readBlurredFlow(0), g, 0.4, 2, bk, wh) == ref["w2"]).all(), ("oracle", bk, wh)
+        c.copyFrame()
+        assert (c.downloadFrame() == ref["copy"]).all(), (bk, wh)
+        assert (oracle.copy_frame(f[1], g, bk, wh) == ref["copy"]).all(), ("oracle", bk, wh)
+        c.close()
