@@ -124,3 +124,59 @@ def test_degenerate_levels_match_live_reference(native_lib, hdr):
         assert (c.downloadFrame() == ref["copy"]).all(), (bk, wh)
         assert (oracle.copy_frame(f[1], g, bk, wh) == ref["copy"]).all(), ("oracle", bk, wh)
         c.close()
+
+
+@pytest.mark.parametrize("seed", list(range(40)))
+def test_random_configurations_match_live_reference(native_lib, seed):
+    """The randomized sweep of test_random_gpu.py, but judged by the reference itself (oracle/_ref on this GPU) instead
+    of the oracle: geometry, pitches, resolution scalar, search radius 2..16, scalars, levels, all production modes.
+    The oracle is checked against the same outputs, so every seed pins it once more."""
+    from hopperrender_amd import synth
+    from hopperrender_amd.calc import OpticalFlowCalcHDR, OpticalFlowCalcSDR
+    from oracle import oracle
+    if not oracle.ref_available():
+        pytest.skip("oracle/_ref (the compiled reference) or an OpenCL GPU is not available")
+    rng = np.random.default_rng(9000 + seed)
+    hdr = int(rng.integers(0, 2))
+    H = int(rng.integers(8, 120)) * 2
+    W = int(rng.integers(16, 200)) * 2
+    si = W + int(rng.choice([0, 0, 2, 16, 6]))
+    so = W + int(rng.choice([0, 0, 2, 16, 10]))
+    max_res = int(rng.choice([270, 270, 64, 40, 1000]))
+    R = int(rng.integers(2, 17))
+    delta, nb = int(rng.integers(0, 11)), int(rng.integers(0, 11))
+    bk, wh = float(rng.choice([0.0, 16.0, 3.5])), float(rng.choice([255.0, 235.0, 200.25]))
+    sc = synth.Scene(H, W, bool(hdr), seed=700 + seed, in_stride=si, max_rect_speed=int(rng.integers(2, 30)))
+    f = [sc.frame(k) for k in range(4)]
+    ts = [0.0, float(np.float32(rng.random())), 0.999]
+    s = oracle.RefSession(hdr, H, W, si, so, delta, nb, bk, wh, max_res)
+    s.radius(R)
+    for x in f[:3]:
+        s.update(x)
+    s.calc(); s.stats(); s.dump_offsets("off"); s.dump_blurred(1, "blur")
+    s.update(f[3]); s.radius(R); s.calc(); s.stats()
+    for m in (0, 1, 2):
+        for t in ts:
+            s.warp(t, m); s.download(f"w{m}_{t}")
+    s.copy(); s.download("copy")
+    js, ref = s.run()
+    g = oracle.make_geom(hdr, H, W, si, so, max_res)
+    off_o, blur_o, tot_o, oob = oracle.calculate_optical_flow(f[1], f[2], g, R, 0, delta, nb, 4)
+    c = (OpticalFlowCalcHDR if hdr else OpticalFlowCalcSDR)(H, W, si, so, delta, nb, bk, wh, max_res, search_radius=R)
+    for x in f[:3]:
+        c.updateFrame(x)
+    c.calculateOpticalFlow()
+    cfg = dict(hdr=hdr, H=H, W=W, si=si, so=so, max_res=max_res, R=R, delta=delta, nb=nb, bk=bk, wh=wh)
+    if oob == 0:    # otherwise the reference reads outside its frame buffers (undefined)
+        assert c.m_totalFrameDelta == js[0]["total_frame_delta"] == tot_o, cfg
+        assert (c.readOffsets() == ref["off"]).all() and (off_o == ref["off"]).all(), cfg
+        assert (c.readBlurredFlow(1) == ref["blur"]).all() and (blur_o == ref["blur"]).all(), cfg
+        c.updateFrame(f[3]); c.calculateOpticalFlow()
+        for m in (0, 1, 2):
+            for t in ts:
+                c.warpFrames(t, m)
+                assert (c.downloadFrame() == ref[f"w{m}_{t}"]).all(), (cfg, m, t)
+                assert (oracle.warp_frames(f[1], f[2], ref["blur"], g, t, m, bk, wh) == ref[f"w{m}_{t}"]).all(), (cfg, "oracle", m, t)
+        c.copyFrame()
+        assert (c.downloadFrame() == ref["copy"]).all(), cfg
+    c.close()
