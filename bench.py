@@ -65,6 +65,7 @@ def parse_args():
     ap.add_argument("--no-fused-warp", action="store_true", help="one warp launch per output frame instead of one per source period")
     ap.add_argument("--shared-warp-stream", action="store_true",
                     help="issue the warp kernels of all pair streams on one shared stream per GPU (measured slower: 26.5k vs 33k frames/s)")
+    ap.add_argument("--no-lazy-argmin", action="store_true", help="HF_FLAG_NO_LAZY_ARGMIN: 6 more (tiny) launches per flow chain (A-B: cost of kernel boundaries)")
     ap.add_argument("--defer-prep", action="store_true", help="HF_FLAG_DEFER_PREP (full phase planes one period later, right before their use)")
     ap.add_argument("--timing-events", action="store_true",
                     help="keep the reference's per-call timing events (m_ofcCalcTime, m_warpCalcTime); default off in the bench")
@@ -223,6 +224,8 @@ def main():
         flags |= capi.HF_FLAG_WARP_TURNSTILE
     if a.defer_prep:
         flags |= capi.HF_FLAG_DEFER_PREP
+    if a.no_lazy_argmin:
+        flags |= capi.HF_FLAG_NO_LAZY_ARGMIN
     cls = OpticalFlowCalcHDR if hdr else OpticalFlowCalcSDR
     calcs, outbufs, plans = [], [], []
     total_steps = a.warmup + a.steps
