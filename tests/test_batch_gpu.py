@@ -154,3 +154,51 @@ def test_batch_members_out_of_step_and_parameter_churn(native_lib):
     batch.close()
     for c in singles + members:
         c.close()
+
+
+def test_c_batch_driver_example_matches_python_path(native_lib, tmp_path):
+    """examples/hf_batch_driver.c (plain C against include/hopperflow.h: contexts, hf_batch, device frames, fused
+    periods) prints one checksum per output frame; the same clips through single Python contexts give the same ones."""
+    import os
+    import subprocess
+    from hopperrender_amd.calc import OpticalFlowCalcSDR
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "hf_batch_driver"
+    lib = os.path.join(root, "hopperrender_amd", "lib")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "hf_batch_driver.c"), "-L", lib, "-lhopperflow",
+                           f"-Wl,-rpath,{lib}", "-o", str(exe)])
+    periods = 4
+    out = subprocess.run([str(exe), str(periods)], capture_output=True, text=True, timeout=300, check=True).stdout
+    got = {}
+    for line in out.strip().splitlines():
+        w = line.split()
+        got[(int(w[1]), int(w[3]), int(w[5]))] = (int(w[7]), w[9])
+    assert len(got) == periods * 2 * 3
+
+    H, W = 180, 320
+
+    def make_frame(clip, k):
+        y, x = np.mgrid[0:H, 0:W]
+        luma = (((x + 3 * k + 5 * clip) * 7 + (y + 2 * k) * 13 + (((x + 3 * k) >> 4) ^ ((y + 2 * k) >> 4)) * 29) & 0xFF).astype(np.uint8)
+        yc, xc = np.mgrid[0:H // 2, 0:W]
+        chroma = (128 + (((xc >> 1) + k + clip) * 3 + yc * 5) % 64 - 32).astype(np.uint8)
+        return np.concatenate([luma.reshape(-1), chroma.reshape(-1)])
+
+    def fnv1a(a):
+        h = 1469598103934665603
+        for b in a.tobytes():
+            h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return "%016x" % h
+
+    for clip in range(2):
+        c = OpticalFlowCalcSDR(H, W, search_radius=12)
+        for k in range(2):
+            c.updateFrame(make_frame(clip, k))
+        for p in range(periods):
+            c.updateFrame(make_frame(clip, p + 2))
+            c.calculateOpticalFlow()
+            for i, t in enumerate((0.0, 0.3996, 0.7992)):
+                c.warpFrames(t, 2)
+                assert got[(p, clip, i)] == (c.m_totalFrameDelta, fnv1a(c.downloadFrame())), (p, clip, i)
+        c.close()
