@@ -620,15 +620,15 @@ __global__ __launch_bounds__(SPLIT ? 64 : 256) void flow_level_small_kernel(cons
 // 32x32 tiles) at the price of more atomics on the same R addresses of each window.
 template <int WPB>
 __global__ __launch_bounds__(64 * WPB) void flow_big_partial_kernel(const Geom g, const FlowBatch batch) {
-    const TileId tile = decode_tile((g.lw + 31) / 32, (g.lh + 8 * WPB - 1) / (8 * WPB), 1, batch.n);
+    const TileId tile = decode_tile((g.lw + 63) / 64, (g.lh + 4 * WPB - 1) / (4 * WPB), 1, batch.n);
     if (!tile.valid) return;
     const FlowStep& a = batch.s[tile.pair];
-    using M = Map<32>;
     __shared__ uint32_t s_part[WPB][16];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    int lx, ly;
-    M::at(tid, lx, ly);
-    const int tx0 = tile.tx * 32, ty0 = tile.ty * (8 * WPB);   // 8 * WPB divides 32: the tile lies in one window
+    // wave = 64 grid pixels x 4 rows: the 16 lanes the texture addresser handles together read 64 contiguous bytes of ONE
+    // phase row (a 16-lane group that spans several rows costs one L1 tag lookup per row and 64-byte block)
+    const int lx = (tid & 15) * 4, ly = tid >> 4;
+    const int tx0 = tile.tx * 64, ty0 = tile.ty * (4 * WPB);   // 64 x 4 WPB divides every window > 32: the tile lies in one window
     const int cx0 = tx0 + lx, cy = ty0 + ly;
     const int wx = tx0 >> a.cur.log2w, wy = ty0 >> a.cur.log2w;
     int ox = 0, oy = 0;
@@ -777,8 +777,8 @@ void launch_flow_level_small(const Geom& g, const FlowBatch& b, hipStream_t stre
 void launch_flow_big_partial(const Geom& g, const FlowBatch& b, hipStream_t stream) {
     // measured on MI355X (2160p HDR chain): 4 waves per workgroup 108.2 us, 2: 109.0 us, 1: 111.9 us (more atomics)
     static const int wpb = getenv("HF_FLOW_BIG_WPB") ? atoi(getenv("HF_FLOW_BIG_WPB")) : 4;
-    const int th = 8 * (wpb == 1 || wpb == 2 ? wpb : 4);
-    const dim3 grd(xcd_grid((g.lw + 31) / 32, (g.lh + th - 1) / th, 1, b.n));
+    const int th = 4 * (wpb == 1 || wpb == 2 ? wpb : 4);
+    const dim3 grd(xcd_grid((g.lw + 63) / 64, (g.lh + th - 1) / th, 1, b.n));
     if (wpb == 1) flow_big_partial_kernel<1><<<grd, 64, 0, stream>>>(g, b);
     else if (wpb == 2) flow_big_partial_kernel<2><<<grd, 128, 0, stream>>>(g, b);
     else flow_big_partial_kernel<4><<<grd, 256, 0, stream>>>(g, b);
