@@ -88,8 +88,7 @@ struct hf_ctx {
     size_t in_bytes = 0, out_bytes = 0, plane_elems = 0;
     void* ring[3] = {nullptr, nullptr, nullptr};       // m_inputFrameArray, ring[2] = newest (may point at caller memory)
     void* ring_store[3] = {nullptr, nullptr, nullptr}; // the context's own frame buffers, rotating with the ring
-    uint8_t* py[3] = {nullptr, nullptr, nullptr};      // luma phase planes of each ring frame (hf_flow.hip)
-    uint16_t* puv[3] = {nullptr, nullptr, nullptr};    // chroma phase planes of each ring frame
+    uint32_t* pp[3] = {nullptr, nullptr, nullptr};     // phase plane of each ring frame (hf_flow.hip)
     hf::PhaseLayout pl{};
     void* out_frame = nullptr;                         // m_outputFrameArray
     void* out_target = nullptr;                        // where warp/copy write (out_frame or caller's)
@@ -216,8 +215,8 @@ int enqueue_flow_chain(hf_ctx* const* cs, int n, hipStream_t s) {
         m->initial_window = initial_window(g.lw, g.lh);
         m->last_iterations = iters;
         hf::FlowStep& f = a.s[i];
-        f.py1 = m->py[1]; f.puv1 = m->puv[1];                         // :79 frame N-1
-        f.py2 = m->py[2]; f.puv2 = m->puv[2];                         // :80 frame N
+        f.pp1 = m->pp[1];                                             // :79 frame N-1
+        f.pp2 = m->pp[2];                                             // :80 frame N
         f.pl = m->pl;
         f.total_delta = m->d_total_delta;
         f.R = c->p.search_radius;
@@ -413,11 +412,10 @@ int rotate_after_upload(hf_ctx* c) {
     c->ring_store[0] = c->ring_store[1]; c->ring_store[1] = c->ring_store[2]; c->ring_store[2] = fs;
     hipEvent_t es = c->ev_slot_prep[0];
     c->ev_slot_prep[0] = c->ev_slot_prep[1]; c->ev_slot_prep[1] = c->ev_slot_prep[2]; c->ev_slot_prep[2] = es;
-    uint8_t* y = c->py[0];
-    uint16_t* uv = c->puv[0];
-    c->ring[0] = c->ring[1]; c->py[0] = c->py[1]; c->puv[0] = c->puv[1];
-    c->ring[1] = c->ring[2]; c->py[1] = c->py[2]; c->puv[1] = c->puv[2];
-    c->ring[2] = f;          c->py[2] = y;        c->puv[2] = uv;
+    uint32_t* pp = c->pp[0];
+    c->ring[0] = c->ring[1]; c->pp[0] = c->pp[1];
+    c->ring[1] = c->ring[2]; c->pp[1] = c->pp[2];
+    c->ring[2] = f;          c->pp[2] = pp;
     c->ring_phase = (c->ring_phase + 1) % 3;
     c->p.frame_count++;
     return HF_OK;
@@ -468,15 +466,7 @@ int update_common(hf_ctx* c, const void* src, hipMemcpyKind kind, bool by_refere
         c->ring[0] = c->ring_store[0];
         HF_HIP(c, hipMemcpyAsync(c->ring[0], src, c->in_bytes, kind, c->stream));
     }
-    if ((c->cfg.flags & HF_FLAG_DEFER_PREP) && !c->io_in) {
-        // The chain reads ALL phases of frame N-1 but only the grid samples (phase 0) of frame N.  So: only those for
-        // the new frame now, and the full planes of the frame that becomes N-1 right here, just before the chain that
-        // gathers from them -- they are still in L2 / the Infinity Cache then, instead of a whole period old.
-        hf::launch_prep_phase0(c->g, c->pl, c->ring[0], c->py[0], c->puv[0], c->stream);
-        hf::launch_prep_frame(c->g, c->pl, c->ring[2], c->py[2], c->puv[2], c->stream);
-    } else {
-        hf::launch_prep_frame(c->g, c->pl, c->ring[0], c->py[0], c->puv[0], c->stream);
-    }
+    hf::launch_prep_frame(c->g, c->pl, c->ring[0], c->pp[0], c->stream);
     HF_HIP(c, hipGetLastError());
     if (c->io_in) HF_HIP(c, hipEventRecord(c->ev_slot_prep[0], c->stream));
     rotate_after_upload(c);
@@ -598,11 +588,9 @@ int hf_create(const hf_config* cfg, hf_ctx** out_ctx) {
     for (int i = 0; i < 3; i++) {
         HF_TRY(hipMalloc(&c->ring_store[i], c->in_bytes));
         c->ring[i] = c->ring_store[i];
-        HF_TRY(hipMalloc((void**)&c->py[i], c->pl.py_bytes));
-        HF_TRY(hipMalloc((void**)&c->puv[i], c->pl.puv_bytes));
+        HF_TRY(hipMalloc((void**)&c->pp[i], c->pl.bytes));
         HF_TRY(hipMemsetAsync(c->ring[i], 0, c->in_bytes, c->stream));
-        HF_TRY(hipMemsetAsync(c->py[i], 0, c->pl.py_bytes, c->stream));
-        HF_TRY(hipMemsetAsync(c->puv[i], 0, c->pl.puv_bytes, c->stream));
+        HF_TRY(hipMemsetAsync(c->pp[i], 0, c->pl.bytes, c->stream));
     }
     HF_TRY(hipMalloc(&c->out_frame, c->out_bytes));
     HF_TRY(hipMemsetAsync(c->out_frame, 0, c->out_bytes, c->stream));
@@ -648,7 +636,7 @@ void hf_destroy(hf_ctx* c) {
     hipSetDevice(c->device);
     if (c->stream) { leave_warp_stream(c); hipStreamSynchronize(c->stream); }  // clFinish (opticalFlowCalcSDR.cpp:186)
     for (auto& kv : c->graphs) hipGraphExecDestroy(kv.second);
-    for (int i = 0; i < 3; i++) { if (c->ring_store[i]) hipFree(c->ring_store[i]); if (c->py[i]) hipFree(c->py[i]); if (c->puv[i]) hipFree(c->puv[i]); }
+    for (int i = 0; i < 3; i++) { if (c->ring_store[i]) hipFree(c->ring_store[i]); if (c->pp[i]) hipFree(c->pp[i]); }
     if (c->tables) hipFree(c->tables);
     if (c->off_view) hipFree(c->off_view);
     if (c->out_frame) hipFree(c->out_frame);
@@ -709,7 +697,7 @@ int hf_update_frame_async(hf_ctx* c, const void* pinned_host_frame) {
     }
     HF_HIP(c, hipStreamWaitEvent(c->stream, c->ev_h2d, 0));
     c->ring[0] = c->ring_store[0];
-    hf::launch_prep_frame(c->g, c->pl, c->ring[0], c->py[0], c->puv[0], c->stream);
+    hf::launch_prep_frame(c->g, c->pl, c->ring[0], c->pp[0], c->stream);
     HF_HIP(c, hipGetLastError());
     HF_HIP(c, hipEventRecord(c->ev_slot_prep[0], c->stream));
     rotate_after_upload(c);

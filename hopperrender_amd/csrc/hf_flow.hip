@@ -4,16 +4,15 @@
 // determineLowestLayerKernelSDR.h:4-28, adjustOffsetArrayKernelSDR.h:4-21 and the fills of
 // opticalFlowCalcSDR.cpp:68-76.  Same results, different organisation (DESIGN.md "flow chain"):
 //
-//  1. PHASE PLANES.  A candidate samples frame N-1 at full-resolution x = (cx << rs) + offset, i.e.
+//  1. PHASE PLANE.  A candidate samples frame N-1 at full-resolution x = (cx << rs) + offset, i.e.
 //     every 2^rs-th element starting at an arbitrary phase: 1 useful sample per 8-16 bytes.  At upload
-//     each frame is re-laid out once as top-8-bit phase planes
-//         PY [y ][ph ][j] = top8(Y [y ][mirror((j << rs) + ph)])
-//         PUV[y'][ph2][j] = top8 pair (U,V) at UV[y'][mirror((j << rs) + 2*ph2) & ~1]
+//     each frame is re-laid out once as ONE plane of 4-byte elements (hf_kernels.h PhaseLayout)
+//         PP[y][ph2][j] = top8 of  Y[y][x], Y[y][x+1], U[y>>1][x&~1], V[y>>1][x&~1],   x = mirror((j << rs) + 2*ph2)
 //     with j running over [-MX, lw + MX) so the reference's edge reflection
 //     (calcDeltaSumsKernelSDR.h:86-95) is baked in.  Offsets are constant inside a window (below), so
-//     the samples of a run of grid pixels are CONSECUTIVE bytes of one phase row: a lane fetches the
-//     4 luma bytes of 4 pixels with one dword load and their 4 chroma pairs with one dwordx2 load,
-//     and scores them with three v_sad_u8.  The grid samples of frame N are phase 0 of its own planes.
+//     the samples of a run of grid pixels are CONSECUTIVE elements of one phase row: a lane fetches luma
+//     and chroma of 4 pixels with ONE dword-aligned 16-byte load (v_perm_b32 drops the luma byte of the
+//     other phase) and scores them with four v_sad_u8.  The grid samples of frame N are phase 0 of its own plane.
 //  2. PER-WINDOW STATE.  The chain starts from zero offsets (opticalFlowCalcSDR.cpp:68-69) and every
 //     update adds one value per window of a size the current size divides, so offsets, the offset bias
 //     (:105-109) and the neighbour bias (:112-144) are per-window constants:
@@ -24,16 +23,6 @@
 //     and Y of a level run in ONE launch (5 launches for levels 32..2).  Larger windows take two
 //     launches per axis (partial sums with one atomic per candidate per workgroup, then a tiny argmin).
 #include "hf_kernels.h"
-#include <cstdlib>
-
-#ifndef HF_FLOW_ALIGNED_LOADS
-#define HF_FLOW_ALIGNED_LOADS 0   // 1: strips through dword-aligned loads + v_alignbit.  Fewer addresser cycles but 2-3 loads per
-                                  // strip instead of 1: chain alone 98 -> 111 us, batch of 8 unchanged (35.2 us per pair),
-                                  // default bench +1 % (noise level) -- left off
-#endif
-#ifndef HF_PREP_NT_LOAD
-#define HF_PREP_NT_LOAD 0   // 1: non-temporal loads of the source frame in the phase-plane kernel
-#endif
 
 namespace hf {
 
@@ -59,141 +48,105 @@ template <> __device__ __forceinline__ unsigned top8<uint8_t>(uint8_t v) { retur
 template <> __device__ __forceinline__ unsigned top8<uint16_t>(uint16_t v) { return (unsigned)(v >> 8); }  // calcDeltaSumsKernelHDR.h:98
 
 // ------------------------------------------------------------------------------------------
-// phase planes
+// phase plane
 // ------------------------------------------------------------------------------------------
-// One workgroup per full-resolution row (luma rows, then chroma rows): the row is read once with
-// coalesced 16-byte loads, reduced to its top 8 bits in LDS, and written back as nph (nph2) phase rows
+__device__ __forceinline__ uint32_t pack_element(uint32_t ya, uint32_t yb, uint32_t u, uint32_t v) {
+    return ya | (yb << 8) | (u << 16) | (v << 24);
+}
+
+// Generic build (any geometry): one workgroup per full-resolution luma row.  The luma row and its chroma row are
+// read once with coalesced 16-byte loads, reduced to their top 8 bits in LDS, and written back as nph2 phase rows
 // including the mirrored margins.
 template <typename E>
-__global__ __launch_bounds__(256) void prep_phase_kernel(const E* __restrict__ f, uint8_t* __restrict__ py,
-                                                          uint16_t* __restrict__ puv, int H, int W, int S,
+__global__ __launch_bounds__(256) void prep_phase_kernel(const E* __restrict__ f, uint32_t* __restrict__ pp, int H, int W, int S,
                                                           PhaseLayout pl) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t row8[];   // W bytes: top 8 bits of the row
+    extern __shared__ __attribute__((aligned(16))) uint8_t row8[];   // [2][Wp]: top 8 bits of the luma row, of the chroma row
     constexpr int VEC = 16 / sizeof(E);
+    const int Wp = ((W + 15) / 16) * 16;
     const int row = blockIdx.x, tid = threadIdx.x;
-    const bool luma = row < H;
-    const E* __restrict__ src = luma ? f + (size_t)row * S : f + (size_t)H * S + (size_t)(row - H) * S;
-    const bool aligned = (((uintptr_t)src) & 15) == 0;
-    for (int i = tid * VEC; i < W; i += 256 * VEC) {
-        if (aligned && i + VEC <= W) {
-            __attribute__((aligned(16))) E v[VEC];
-            *(uint4*)v = *(const uint4*)(src + i);
+    for (int z = 0; z < 2; z++) {
+        const E* __restrict__ src = z ? f + (size_t)H * S + (size_t)(row >> 1) * S : f + (size_t)row * S;
+        uint8_t* dst8 = row8 + z * Wp;
+        const bool aligned = (((uintptr_t)src) & 15) == 0;
+        for (int i = tid * VEC; i < W; i += 256 * VEC) {
+            if (aligned && i + VEC <= W) {
+                __attribute__((aligned(16))) E v[VEC];
+                *(uint4*)v = *(const uint4*)(src + i);
 #pragma unroll
-            for (int k = 0; k < VEC; k++) row8[i + k] = (uint8_t)top8<E>(v[k]);
-        } else {
-            for (int k = 0; k < VEC && i + k < W; k++) row8[i + k] = (uint8_t)top8<E>(src[i + k]);
+                for (int k = 0; k < VEC; k++) dst8[i + k] = (uint8_t)top8<E>(v[k]);
+            } else {
+                for (int k = 0; k < VEC && i + k < W; k++) dst8[i + k] = (uint8_t)top8<E>(src[i + k]);
+            }
         }
     }
     __syncthreads();
     const int step = 1 << pl.rs;
-    if (luma) {
-        const int chunks = pl.lwp >> 2;                // 4 outputs (one dword) per item
-        uint32_t* __restrict__ dst = (uint32_t*)(py + (size_t)row * pl.nph * pl.lwp);
-        for (int t = tid; t < pl.nph * chunks; t += 256) {
-            const int ph = t / chunks, jc = t - ph * chunks;
-            uint32_t v = 0;
-#pragma unroll
-            for (int i = 0; i < 4; i++) v |= (uint32_t)row8[mirror_clamp((jc * 4 + i - pl.mx) * step + ph, W)] << (8 * i);
-            dst[t] = v;
-        }
-    } else {
-        const int chunks = pl.lwp >> 1;                // 2 outputs (one dword) per item
-        uint32_t* __restrict__ dst = (uint32_t*)(puv + (size_t)(row - H) * pl.nph2 * pl.lwp);
-        for (int t = tid; t < pl.nph2 * chunks; t += 256) {
-            const int ph2 = t / chunks, jc = t - ph2 * chunks;
-            uint32_t v = 0;
-#pragma unroll
-            for (int i = 0; i < 2; i++) {
-                const int x = mirror_clamp((jc * 2 + i - pl.mx) * step + 2 * ph2, W) & ~1;
-                v |= (uint32_t)(*(const uint16_t*)(row8 + x)) << (16 * i);
-            }
-            dst[t] = v;
-        }
+    uint32_t* __restrict__ dst = pp + (size_t)row * pl.nph2 * pl.lwp;
+    for (int t = tid; t < pl.nph2 * pl.lwp; t += 256) {
+        const int ph2 = t / pl.lwp, jc = t - ph2 * pl.lwp;
+        const int x = (jc - pl.mx) * step + 2 * ph2;
+        const int xa = mirror_clamp(x, W), xc = xa & ~1;
+        const uint32_t yb = pl.nph > 1 ? row8[mirror_clamp(x + 1, W)] : 0u;
+        dst[t] = pack_element(row8[xa], yb, row8[Wp + xc], row8[Wp + xc + 1]);
     }
 }
 
-// Fast path of the phase-plane build (no LDS): a thread takes the 4 << RS consecutive elements behind 4
-// consecutive grid columns, reduces them to their top 8 bits and emits one dword per phase (4 columns x 1 byte;
-// chroma: two dwords per phase pair, 4 columns x (U,V)).  A wave therefore reads 64 x 16..64 contiguous bytes
-// and writes 256 contiguous bytes per phase row.  The mirrored margins need no extra loads:
-//     PY [ph ][-1-k] = PY [nph-1-ph ][k]        PY [ph ][lw+k] = PY [nph-1-ph ][lw-1-k]
-//     PUV[ph2][-1-k] = PUV[nph2-1-ph2][k]       (same on the right; U,V keep their order inside a pair)
-// because reflecting x -> -x-1 (or 2W-x-1) maps phase ph of column j to phase nph-1-ph of column -j-1, so a
-// thread whose columns lie within `mx` of an edge also stores its dwords, columns reversed, into the margin.
+// Fast path of the plane build (no LDS): a thread takes the 4 << RS consecutive elements behind 4 consecutive grid
+// columns of TWO luma rows (2m, 2m + 1) and of their chroma row m, and emits one 16-byte store (4 columns) per phase
+// pair and luma row.  A wave therefore reads 64 x 16..64 contiguous bytes per row and writes 1 KB per phase row.
+// The mirrored margins need no extra loads:
+//     PP[ph2][-1-k] = swap(PP[nph2-1-ph2][k])        PP[ph2][lw+k] = swap(PP[nph2-1-ph2][lw-1-k])
+// (swap = the two luma bytes exchanged; rs = 0 has one luma byte per element and no swap), because reflecting
+// x -> -x-1 (or 2W-x-1) maps phase ph of column j to phase nph-1-ph of column -j-1 and keeps the chroma pair, so a
+// thread whose columns lie within `mx` of an edge also stores its elements, columns reversed, into the margin.
 // Requires W == lw << RS, lw % 4 == 0, mx <= lw and 16-byte aligned rows (else: prep_phase_kernel).
 template <typename E, int RS>
-__global__ __launch_bounds__(128) void prep_phase_fast_kernel(const E* __restrict__ f, uint8_t* __restrict__ py,
-                                                               uint16_t* __restrict__ puv, int H, int W, int S,
+__global__ __launch_bounds__(128) void prep_phase_fast_kernel(const E* __restrict__ f, uint32_t* __restrict__ pp, int H, int W, int S,
                                                                PhaseLayout pl) {
-    constexpr int NPH = 1 << RS, NE = 4 << RS;               // phases, elements per thread
+    constexpr int NPH = 1 << RS, NE = 4 << RS;               // phases, elements per thread and row
     constexpr int NPH2 = NPH > 1 ? NPH / 2 : 1;
-    const int row = blockIdx.y;
+    const int m = blockIdx.y;                                // chroma row = pair of luma rows
     const int t = blockIdx.x * 128 + threadIdx.x;            // group of 4 grid columns
     const int lw = W >> RS;
     if (4 * t >= lw) return;
-    const bool luma = row < H;
-    const E* __restrict__ src = (luma ? f + (size_t)row * S : f + (size_t)H * S + (size_t)(row - H) * S) + (size_t)t * NE;
-    __attribute__((aligned(16))) E e[NE];
-    typedef unsigned nt_v4 __attribute__((ext_vector_type(4)));
+    __attribute__((aligned(16))) E e[3][NE];                 // luma row 2m, luma row 2m + 1, chroma row m
 #pragma unroll
-    for (int i = 0; i < NE * (int)sizeof(E) / 16; i++) {
-#if HF_PREP_NT_LOAD
-        ((nt_v4*)e)[i] = __builtin_nontemporal_load((const nt_v4*)src + i);
-#else
-        ((uint4*)e)[i] = ((const uint4*)src)[i];
-#endif
-    }
-    if (NE * sizeof(E) < 16) {                               // RS = 0..1 with 8-bit elements: 4 or 8 bytes per thread
+    for (int z = 0; z < 3; z++) {
+        const E* __restrict__ src = (z < 2 ? f + (size_t)(2 * m + z) * S : f + (size_t)H * S + (size_t)m * S) + (size_t)t * NE;
+        if (NE * sizeof(E) >= 16) {
 #pragma unroll
-        for (int i = 0; i < NE; i++) e[i] = src[i];
+            for (int i = 0; i < NE * (int)sizeof(E) / 16; i++) ((uint4*)e[z])[i] = ((const uint4*)src)[i];
+        } else {                                             // RS = 0..1 with 8-bit elements: 4 or 8 bytes per thread
+#pragma unroll
+            for (int i = 0; i < NE; i++) e[z][i] = src[i];
+        }
     }
     const int j0 = 4 * t;                                    // first column of this thread
-    const int jl = pl.mx - 4 - j0;                           // plane index of the mirrored dword in the left margin
+    const int jl = pl.mx - 4 - j0;                           // plane index of the mirrored group in the left margin
     const int jr = pl.mx + 2 * lw - 4 - j0;                  // ... and in the right margin
     const bool left = j0 + 4 <= pl.mx, right = j0 >= lw - pl.mx;
-    if (luma) {
-        uint8_t* __restrict__ base = py + (size_t)row * NPH * pl.lwp;
 #pragma unroll
-        for (int ph = 0; ph < NPH; ph++) {
-            const uint32_t b0 = top8<E>(e[ph]), b1 = top8<E>(e[NPH + ph]), b2 = top8<E>(e[2 * NPH + ph]), b3 = top8<E>(e[3 * NPH + ph]);
-            *(uint32_t*)(base + (size_t)ph * pl.lwp + pl.mx + j0) = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
-            const uint32_t rev = b3 | (b2 << 8) | (b1 << 16) | (b0 << 24);
-            uint8_t* mrow = base + (size_t)(NPH - 1 - ph) * pl.lwp;
-            if (left) *(uint32_t*)(mrow + jl) = rev;
-            if (right) *(uint32_t*)(mrow + jr) = rev;
-        }
-    } else {
-        uint16_t* __restrict__ base = puv + (size_t)(row - H) * NPH2 * pl.lwp;
+    for (int z = 0; z < 2; z++) {
+        uint32_t* __restrict__ base = pp + (size_t)(2 * m + z) * NPH2 * pl.lwp;
 #pragma unroll
         for (int p2 = 0; p2 < NPH2; p2++) {
-            // pair of column c: elements (c << RS) + 2*p2, +1   (RS = 0: pair at c & ~1)
-            uint32_t pr[4];
+            uint32_t el[4], sw[4];
 #pragma unroll
             for (int c = 0; c < 4; c++) {
-                const int x = RS > 0 ? c * NPH + 2 * p2 : (c & ~1);
-                pr[c] = top8<E>(e[x]) | (top8<E>(e[x + 1]) << 8);
+                const int x = RS > 0 ? c * NPH + 2 * p2 : c;     // element index of the column's sample inside e[]
+                const int xc = x & ~1;
+                const uint32_t ya = top8<E>(e[z][x]), yb = RS > 0 ? top8<E>(e[z][x + 1]) : 0u;
+                const uint32_t u = top8<E>(e[2][xc]), v = top8<E>(e[2][xc + 1]);
+                el[c] = pack_element(ya, yb, u, v);
+                sw[c] = RS > 0 ? pack_element(yb, ya, u, v) : el[c];
             }
-            uint16_t* d = base + (size_t)p2 * pl.lwp + pl.mx + j0;
-            *(uint2*)d = make_uint2(pr[0] | (pr[1] << 16), pr[2] | (pr[3] << 16));
-            uint16_t* mrow = base + (size_t)(NPH2 - 1 - p2) * pl.lwp;
-            const uint2 rev = make_uint2(pr[3] | (pr[2] << 16), pr[1] | (pr[0] << 16));
-            if (left) *(uint2*)(mrow + jl) = rev;
-            if (right) *(uint2*)(mrow + jr) = rev;
+            *(uint4*)(base + (size_t)p2 * pl.lwp + pl.mx + j0) = make_uint4(el[0], el[1], el[2], el[3]);
+            uint32_t* mrow = base + (size_t)(NPH2 - 1 - p2) * pl.lwp;
+            const uint4 rev = make_uint4(sw[3], sw[2], sw[1], sw[0]);
+            if (left) *(uint4*)(mrow + jl) = rev;
+            if (right) *(uint4*)(mrow + jr) = rev;
         }
     }
-}
-
-// Only what the refinement chain reads of frame N (its "frame 2" operand): the grid samples = phase 0 of the rows
-// y = cy << rs (calcDeltaSumsKernelSDR.h:98-100).  One thread per grid point; 1/64 of the luma plane at rs = 3.
-template <typename E>
-__global__ __launch_bounds__(256) void prep_phase0_kernel(const E* __restrict__ f, uint8_t* __restrict__ py, uint16_t* __restrict__ puv,
-                                                          int H, int W, int S, int lw, int lh, int rs, PhaseLayout pl) {
-    const int cx = blockIdx.x * 64 + (threadIdx.x & 63), cy = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (cx >= lw || cy >= lh) return;
-    const int sx = min(cx << rs, W - 1), sy = min(cy << rs, H - 1);      // (the grid is ceil(W / 2^rs): its last column / row may start outside)
-    py[(size_t)sy * pl.nph * pl.lwp + pl.mx + cx] = (uint8_t)top8<E>(f[(size_t)sy * S + sx]);
-    const E* uv = f + (size_t)H * S + (size_t)(sy >> 1) * S + (sx & ~1);
-    puv[(size_t)(sy >> 1) * pl.nph2 * pl.lwp + pl.mx + cx] = (uint16_t)(top8<E>(uv[0]) | (top8<E>(uv[1]) << 8));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -251,128 +204,95 @@ __device__ __forceinline__ uint32_t window_bias(int cand, bool use_nb, const int
 // ------------------------------------------------------------------------------------------
 // strip SADs: PX consecutive grid pixels of one row, all candidates of one axis
 // ------------------------------------------------------------------------------------------
-template <int PX> struct StripTypes;
-template <> struct StripTypes<4> { using Y = uint32_t; using UV = uint64_t; };
-template <> struct StripTypes<2> { using Y = uint16_t; using UV = uint32_t; };
-
-template <typename T>
-__device__ __forceinline__ T load_unaligned(const void* p) {
-    T v;
-    __builtin_memcpy(&v, p, sizeof(T));
-    return v;
+// PX consecutive elements of a phase row.  Element addresses are dword-aligned by construction, so this is ONE
+// global_load_dwordx4 / dwordx2 on the fast path of the texture addresser (tools/ubench/gather_rate.hip: 17.5 clocks
+// per wave instruction for dwordx4 at a 4-byte boundary, against 17.3 + 33.4 for the unaligned dword + dwordx2 pair
+// the byte planes of round 1 needed).
+template <int PX> struct __attribute__((aligned(4))) Elems { uint32_t d[PX]; };
+template <int PX>
+__device__ __forceinline__ Elems<PX> load_elems(const uint32_t* __restrict__ p) {
+    Elems<PX> r;
+    __builtin_memcpy(&r, p, sizeof(r));
+    return r;
 }
-
-// A strip through DWORD-ALIGNED loads + funnel shift.  tools/ubench/gather_rate.hip, clocks per wave instruction in the
-// texture addresser: dword 6.1 aligned / 17.3 not; dwordx2 17.3 at a 4-byte boundary / 33.4 not; ushort 6.8 / 17.4.
-// A strip starts at an arbitrary byte (luma) or 2-byte (chroma) offset, so the plain loads were almost always the
-// slow kind.  The rows of the phase planes are padded (lwp >= lw + 2 mx + 8), so the extra dword stays inside the row.
-__device__ __forceinline__ uint32_t load_bytes4(const uint8_t* __restrict__ base, unsigned byte_off) {
-    const uint32_t* __restrict__ p = (const uint32_t*)(base + (byte_off & ~3u));
-    return __builtin_amdgcn_alignbit(p[1], p[0], (byte_off & 3u) * 8u);
-}
-__device__ __forceinline__ uint64_t load_bytes8(const uint8_t* __restrict__ base, unsigned byte_off) {
-    const uint32_t* __restrict__ p = (const uint32_t*)(base + (byte_off & ~3u));
-    const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
-    const unsigned sh = (byte_off & 3u) * 8u;
-    return (uint64_t)__builtin_amdgcn_alignbit(d1, d0, sh) | ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, sh) << 32);
-}
-template <typename T> __device__ __forceinline__ T load_strip_bytes(const void* base, unsigned byte_off);
-template <> __device__ __forceinline__ uint16_t load_strip_bytes<uint16_t>(const void* b, unsigned o) { return (uint16_t)load_bytes4((const uint8_t*)b, o); }
-template <> __device__ __forceinline__ uint32_t load_strip_bytes<uint32_t>(const void* b, unsigned o) { return load_bytes4((const uint8_t*)b, o); }
-template <> __device__ __forceinline__ uint64_t load_strip_bytes<uint64_t>(const void* b, unsigned o) { return load_bytes8((const uint8_t*)b, o); }
 
 template <int PX>
 struct Strip {
-    typename StripTypes<PX>::Y y2;    // frame-N luma bytes of the strip (masked)
-    typename StripTypes<PX>::UV uv2;  // frame-N chroma pairs of the strip (masked)
-    typename StripTypes<PX>::Y ymask;
-    typename StripTypes<PX>::UV uvmask;
+    uint32_t ref[PX];                 // frame-N samples of the strip: Y | 0 | U << 16 | V << 24 (0 outside the grid)
+    uint32_t vm[PX];                  // all ones for pixels inside the grid
     int cx0, cy;
     bool any;                         // at least one pixel inside the grid
 };
 
 template <int PX>
 __device__ __forceinline__ Strip<PX> load_strip(const Geom& g, const FlowStep& a, int cx0, int cy) {
-    using TY = typename StripTypes<PX>::Y;
-    using TUV = typename StripTypes<PX>::UV;
     Strip<PX> s;
     s.cx0 = cx0; s.cy = cy;
     const int n = cy < g.lh ? clampi(g.lw - cx0, 0, PX) : 0;
     s.any = n > 0;
-    s.ymask = n >= PX ? (TY)~(TY)0 : (TY)(((TY)1 << (8 * n)) - 1);
-    s.uvmask = n >= PX ? (TUV)~(TUV)0 : (TUV)(((TUV)1 << (16 * n)) - 1);
-    s.y2 = 0; s.uv2 = 0;
+#pragma unroll
+    for (int i = 0; i < PX; i++) { s.ref[i] = 0u; s.vm[i] = i < n ? 0xFFFFFFFFu : 0u; }
     if (s.any) {
         const PhaseLayout& pl = a.pl;
-        const int sy = cy << g.rs;   // grid samples of frame N = phase 0 of its own planes (:98-100, frame2 operands)
-        s.y2 = load_unaligned<TY>(a.py2 + (size_t)sy * pl.nph * pl.lwp + pl.mx + cx0) & s.ymask;
-        s.uv2 = load_unaligned<TUV>(a.puv2 + (size_t)(sy >> 1) * pl.nph2 * pl.lwp + pl.mx + cx0) & s.uvmask;
+        const int sy = cy << g.rs;   // grid samples of frame N = phase 0 of its own plane (:98-100, frame2 operands)
+        const Elems<PX> e = load_elems<PX>(a.pp2 + (size_t)sy * pl.nph2 * pl.lwp + pl.mx + cx0);
+#pragma unroll
+        for (int i = 0; i < PX; i++) s.ref[i] = e.d[i] & 0xFFFF00FFu & s.vm[i];
     }
     return s;
-}
-
-__device__ __forceinline__ uint32_t sad_strip(uint32_t y1, uint32_t y2, uint64_t uv1, uint64_t uv2) {
-    uint32_t s = __builtin_amdgcn_sad_u8(y1, y2, 0u);
-    s = __builtin_amdgcn_sad_u8((uint32_t)uv1, (uint32_t)uv2, s);
-    return __builtin_amdgcn_sad_u8((uint32_t)(uv1 >> 32), (uint32_t)(uv2 >> 32), s);
-}
-__device__ __forceinline__ uint32_t sad_strip(uint16_t y1, uint16_t y2, uint32_t uv1, uint32_t uv2) {
-    return __builtin_amdgcn_sad_u8(uv1, uv2, __builtin_amdgcn_sad_u8((uint32_t)y1, (uint32_t)y2, 0u));
 }
 
 // sad[cz] = sum over the strip of |dY| + |dU| + |dV| for candidate cz of `axis` (0 for cz >= R)
 template <int PX>
 __device__ __forceinline__ void strip_sads(uint32_t* sad, const Geom& g, const FlowStep& a, const Strip<PX>& s,
                                            int ox, int oy, int axis) {
-    using TY = typename StripTypes<PX>::Y;
-    using TUV = typename StripTypes<PX>::UV;
     const PhaseLayout& pl = a.pl;
     const int sx = s.cx0 << g.rs, sy = s.cy << g.rs;
-#ifdef HF_EXP_XONLY
-    axis = 0;
-#endif
     const int searched0 = axis ? oy : ox;
-    TY y1[16];
-    TUV uv1[16];
-    // 32-bit element offsets into the phase planes (a plane is < 2^31 elements), split by axis: an X step keeps the
+    const bool ragged = (g.lw & (PX - 1)) != 0;                       // kernel-uniform: some strip hangs over the right grid edge
+    Elems<PX> c1[16];
+    uint32_t sel[16];
+    // 32-bit element offsets into the plane (a plane is < 2^31 elements), split by axis: an X step keeps the
     // row (ny) and varies phase + column, a Y step keeps phase + column and varies the row -- the invariant half of
-    // the address is computed once per strip instead of once per candidate (the address arithmetic of the 32
-    // candidate loads was ~3/4 of the ~1000 VALU instructions a wave issues per step).
-    const int row_y = pl.nph * pl.lwp, row_uv = pl.nph2 * pl.lwp;     // elements per full-res row of PY / chroma row of PUV
+    // the address is computed once per strip instead of once per candidate.
+    const int row_el = pl.nph2 * pl.lwp;                              // elements per full-res row
     const int ny0 = mirror_clamp(sy + oy, g.H);                       // X step: the row
     const int nx0 = sx + ox;                                          // Y step: the column
     const int j0 = clampi(nx0 >> g.rs, -pl.mx, g.lw + pl.mx), ph0 = nx0 & (pl.nph - 1);
-    const int fix_y = axis ? ph0 * pl.lwp + pl.mx + j0 : ny0 * row_y + pl.mx;
-    const int fix_uv = axis ? (ph0 >> 1) * pl.lwp + pl.mx + j0 : (ny0 >> 1) * row_uv + pl.mx;
+    const int fix = axis ? (ph0 >> 1) * pl.lwp + pl.mx + j0 : ny0 * row_el + pl.mx;
 #pragma unroll
     for (int cz = 0; cz < 16; cz++) {
-        y1[cz] = 0; uv1[cz] = 0;
         if (cz < a.R && s.any) {                                  // R is uniform
             const int cand = (int)(int16_t)(searched0 + rel_offset(cz, a.R));  // short arithmetic, :75-76
-            int off_y, off_uv;
+            int off, par;
             if (axis) {
                 const int ny = mirror_clamp(sy + cand, g.H);
-                off_y = ny * row_y + fix_y;
-                off_uv = (ny >> 1) * row_uv + fix_uv;
+                off = ny * row_el + fix;
+                par = ph0 & 1;
             } else {
                 const int nx = sx + cand;
                 const int j = clampi(nx >> g.rs, -pl.mx, g.lw + pl.mx);        // never clamps: |offset| <= margin by construction
                 const int ph = nx & (pl.nph - 1);
-                off_y = ph * pl.lwp + j + fix_y;
-                off_uv = (ph >> 1) * pl.lwp + j + fix_uv;
+                off = (ph >> 1) * pl.lwp + j + fix;
+                par = ph & 1;
             }
-#if HF_FLOW_ALIGNED_LOADS
-            y1[cz] = load_strip_bytes<TY>(a.py1, (unsigned)off_y);
-            uv1[cz] = load_strip_bytes<TUV>(a.puv1, (unsigned)off_uv * 2u);
-#else
-            y1[cz] = load_unaligned<TY>(a.py1 + (unsigned)off_y);
-            uv1[cz] = load_unaligned<TUV>(a.puv1 + (unsigned)off_uv);
-#endif
+            c1[cz] = load_elems<PX>(a.pp1 + (unsigned)off);
+            sel[cz] = 0x03020c00u | (unsigned)par;                // v_perm_b32: luma byte of this phase, 0, U, V
         }
     }
 #pragma unroll
-    for (int cz = 0; cz < 16; cz++)
-        sad[cz] = (cz < a.R && s.any) ? sad_strip((TY)(y1[cz] & s.ymask), s.y2, (TUV)(uv1[cz] & s.uvmask), s.uv2) : 0u;
+    for (int cz = 0; cz < 16; cz++) {
+        uint32_t t = 0u;
+        if (cz < a.R && s.any) {
+#pragma unroll
+            for (int i = 0; i < PX; i++) {
+                uint32_t v = __builtin_amdgcn_perm(c1[cz].d[i], c1[cz].d[i], sel[cz]);
+                if (ragged) v &= s.vm[i];
+                t = __builtin_amdgcn_sad_u8(v, s.ref[i], t);
+            }
+        }
+        sad[cz] = t;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -708,80 +628,57 @@ PhaseLayout make_phase_layout(const Geom& g, int max_iterations) {
     pl.nph = 1 << g.rs;
     pl.nph2 = pl.nph > 1 ? pl.nph / 2 : 1;
     const int reach = (max_iterations + 1) * 64 + 8;   // |offset| <= iterations * (R/2)^2, + one candidate, R <= 16
-    pl.mx = (((reach >> g.rs) + 2 + 3) / 4) * 4;        // multiple of 4: margin dwords line up with the 4-column groups
-    pl.lwp = ((g.lw + 2 * pl.mx + 8 + 15) / 16) * 16;
-    pl.py_bytes = (size_t)g.H * pl.nph * pl.lwp;
-    pl.puv_bytes = (size_t)(g.H / 2) * pl.nph2 * pl.lwp * sizeof(uint16_t);
+    pl.mx = (((reach >> g.rs) + 2 + 3) / 4) * 4;        // multiple of 4: margin groups line up with the 4-column groups
+    pl.lwp = ((g.lw + 2 * pl.mx + 4 + 31) / 32) * 32;   // a strip may start at column lw + mx; rows start on a 128-byte line
+    pl.bytes = (size_t)g.H * pl.nph2 * pl.lwp * sizeof(uint32_t);
     return pl;
 }
 
 template <typename E>
-static bool launch_prep_fast(const Geom& g, const PhaseLayout& pl, const void* frame, uint8_t* py, uint16_t* puv, hipStream_t stream) {
+static bool launch_prep_fast(const Geom& g, const PhaseLayout& pl, const void* frame, uint32_t* pp, hipStream_t stream) {
     const int lw = g.W >> g.rs;
     const size_t row_bytes = (size_t)g.in_stride * sizeof(E);
-    // RS = 0 chroma pairs straddle nothing only when columns come in even pairs: lw % 4 == 0 covers it
     if ((lw << g.rs) != g.W || lw != g.lw || (lw & 3) || pl.mx > lw || (pl.mx & 3) || (row_bytes & 15) || (((uintptr_t)frame) & 15) ||
-        (pl.lwp & 3) || g.rs > 4)
+        (pl.lwp & 3) || g.rs > 4 || (g.H & 1))
         return false;
-    const dim3 grd((lw / 4 + 127) / 128, g.H + g.H / 2);
+    const dim3 grd((lw / 4 + 127) / 128, g.H / 2);
     const E* f = (const E*)frame;
     switch (g.rs) {
-        case 0: prep_phase_fast_kernel<E, 0><<<grd, 128, 0, stream>>>(f, py, puv, g.H, g.W, g.in_stride, pl); break;
-        case 1: prep_phase_fast_kernel<E, 1><<<grd, 128, 0, stream>>>(f, py, puv, g.H, g.W, g.in_stride, pl); break;
-        case 2: prep_phase_fast_kernel<E, 2><<<grd, 128, 0, stream>>>(f, py, puv, g.H, g.W, g.in_stride, pl); break;
-        case 3: prep_phase_fast_kernel<E, 3><<<grd, 128, 0, stream>>>(f, py, puv, g.H, g.W, g.in_stride, pl); break;
-        default: prep_phase_fast_kernel<E, 4><<<grd, 128, 0, stream>>>(f, py, puv, g.H, g.W, g.in_stride, pl); break;
+        case 0: prep_phase_fast_kernel<E, 0><<<grd, 128, 0, stream>>>(f, pp, g.H, g.W, g.in_stride, pl); break;
+        case 1: prep_phase_fast_kernel<E, 1><<<grd, 128, 0, stream>>>(f, pp, g.H, g.W, g.in_stride, pl); break;
+        case 2: prep_phase_fast_kernel<E, 2><<<grd, 128, 0, stream>>>(f, pp, g.H, g.W, g.in_stride, pl); break;
+        case 3: prep_phase_fast_kernel<E, 3><<<grd, 128, 0, stream>>>(f, pp, g.H, g.W, g.in_stride, pl); break;
+        default: prep_phase_fast_kernel<E, 4><<<grd, 128, 0, stream>>>(f, pp, g.H, g.W, g.in_stride, pl); break;
     }
     return true;
 }
 
-void launch_prep_frame(const Geom& g, const PhaseLayout& pl, const void* frame, uint8_t* py, uint16_t* puv, hipStream_t stream) {
-    if (g.hdr ? launch_prep_fast<uint16_t>(g, pl, frame, py, puv, stream) : launch_prep_fast<uint8_t>(g, pl, frame, py, puv, stream)) return;
-    const int rows = g.H + g.H / 2;
-    const size_t smem = (size_t)((g.W + 15) / 16) * 16 + 16;
-    if (g.hdr) prep_phase_kernel<uint16_t><<<rows, 256, smem, stream>>>((const uint16_t*)frame, py, puv, g.H, g.W, g.in_stride, pl);
-    else prep_phase_kernel<uint8_t><<<rows, 256, smem, stream>>>((const uint8_t*)frame, py, puv, g.H, g.W, g.in_stride, pl);
-}
-
-void launch_prep_phase0(const Geom& g, const PhaseLayout& pl, const void* frame, uint8_t* py, uint16_t* puv, hipStream_t stream) {
-    const dim3 grd((g.lw + 63) / 64, (g.lh + 3) / 4);
-    if (g.hdr) prep_phase0_kernel<uint16_t><<<grd, 256, 0, stream>>>((const uint16_t*)frame, py, puv, g.H, g.W, g.in_stride, g.lw, g.lh, g.rs, pl);
-    else prep_phase0_kernel<uint8_t><<<grd, 256, 0, stream>>>((const uint8_t*)frame, py, puv, g.H, g.W, g.in_stride, g.lw, g.lh, g.rs, pl);
+void launch_prep_frame(const Geom& g, const PhaseLayout& pl, const void* frame, uint32_t* pp, hipStream_t stream) {
+    if (g.hdr ? launch_prep_fast<uint16_t>(g, pl, frame, pp, stream) : launch_prep_fast<uint8_t>(g, pl, frame, pp, stream)) return;
+    const size_t smem = 2 * (size_t)((g.W + 15) / 16) * 16;
+    if (g.hdr) prep_phase_kernel<uint16_t><<<g.H, 256, smem, stream>>>((const uint16_t*)frame, pp, g.H, g.W, g.in_stride, pl);
+    else prep_phase_kernel<uint8_t><<<g.H, 256, smem, stream>>>((const uint8_t*)frame, pp, g.H, g.W, g.in_stride, pl);
 }
 
 void launch_flow_level_small(const Geom& g, const FlowBatch& b, hipStream_t stream) {
     const int ws = b.s[0].cur.window;
     const int tw = ws == 2 ? 16 : 32;
     const int tiles_x = (g.lw + tw - 1) / tw, tiles_y = (g.lh + 31) / 32;
-    const dim3 grd(xcd_grid(tiles_x, tiles_y, 1, b.n));
-    static const bool split = !(getenv("HF_FLOW_SPLIT") && atoi(getenv("HF_FLOW_SPLIT")) == 0);
-    const dim3 sgrd(xcd_grid(tiles_x, tiles_y, 4, b.n));
-    if (split && ws <= 16) {
-        switch (ws) {
-            case 16: flow_level_small_kernel<16, true><<<sgrd, 64, 0, stream>>>(g, b); break;
-            case 8: flow_level_small_kernel<8, true><<<sgrd, 64, 0, stream>>>(g, b); break;
-            case 4: flow_level_small_kernel<4, true><<<sgrd, 64, 0, stream>>>(g, b); break;
-            default: flow_level_small_kernel<2, true><<<sgrd, 64, 0, stream>>>(g, b); break;
-        }
-        return;
-    }
+    // windows <= 16 never span waves: one-wave workgroups (SPLIT), see flow_level_small_kernel
+    const dim3 grd(xcd_grid(tiles_x, tiles_y, 1, b.n)), sgrd(xcd_grid(tiles_x, tiles_y, 4, b.n));
     switch (ws) {
         case 32: flow_level_small_kernel<32, false><<<grd, 256, 0, stream>>>(g, b); break;
-        case 16: flow_level_small_kernel<16, false><<<grd, 256, 0, stream>>>(g, b); break;
-        case 8: flow_level_small_kernel<8, false><<<grd, 256, 0, stream>>>(g, b); break;
-        case 4: flow_level_small_kernel<4, false><<<grd, 256, 0, stream>>>(g, b); break;
-        default: flow_level_small_kernel<2, false><<<grd, 256, 0, stream>>>(g, b); break;
+        case 16: flow_level_small_kernel<16, true><<<sgrd, 64, 0, stream>>>(g, b); break;
+        case 8: flow_level_small_kernel<8, true><<<sgrd, 64, 0, stream>>>(g, b); break;
+        case 4: flow_level_small_kernel<4, true><<<sgrd, 64, 0, stream>>>(g, b); break;
+        default: flow_level_small_kernel<2, true><<<sgrd, 64, 0, stream>>>(g, b); break;
     }
 }
 
+constexpr int kBigWavesPerBlock = 4;   // measured on MI355X (2160p HDR chain): 4 waves per workgroup 108.2 us, 2: 109.0 us, 1: 111.9 us (more atomics)
 void launch_flow_big_partial(const Geom& g, const FlowBatch& b, hipStream_t stream) {
-    // measured on MI355X (2160p HDR chain): 4 waves per workgroup 108.2 us, 2: 109.0 us, 1: 111.9 us (more atomics)
-    static const int wpb = getenv("HF_FLOW_BIG_WPB") ? atoi(getenv("HF_FLOW_BIG_WPB")) : 4;
-    const int th = 4 * (wpb == 1 || wpb == 2 ? wpb : 4);
-    const dim3 grd(xcd_grid((g.lw + 63) / 64, (g.lh + th - 1) / th, 1, b.n));
-    if (wpb == 1) flow_big_partial_kernel<1><<<grd, 64, 0, stream>>>(g, b);
-    else if (wpb == 2) flow_big_partial_kernel<2><<<grd, 128, 0, stream>>>(g, b);
-    else flow_big_partial_kernel<4><<<grd, 256, 0, stream>>>(g, b);
+    const dim3 grd(xcd_grid((g.lw + 63) / 64, (g.lh + 4 * kBigWavesPerBlock - 1) / (4 * kBigWavesPerBlock), 1, b.n));
+    flow_big_partial_kernel<kBigWavesPerBlock><<<grd, 64 * kBigWavesPerBlock, 0, stream>>>(g, b);
 }
 
 void launch_flow_big_argmin(const Geom& g, const FlowBatch& b, hipStream_t stream) {

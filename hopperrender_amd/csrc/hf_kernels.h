@@ -19,12 +19,19 @@ struct Geom {
     int lw, lh;          // low-res grid
 };
 
-// Phase-plane layout of a frame (hf_flow.hip): PY[y][ph][j], PUV[y/2][ph/2][j], j in [-mx, lwp - mx).
+// Phase-plane layout of a frame (hf_flow.hip).  ONE plane of 4-byte elements, one element per grid column, per pair of
+// luma phases and per full-resolution luma row:
+//     PP[y][ph2][j] = Y[y][x] | Y[y][x + 1] << 8 | U[y >> 1][x & ~1] << 16 | V[y >> 1][x & ~1] << 24      (top 8 bits each)
+//     x = (j << rs) + 2 * ph2, mirrored once at the frame edge; j in [-mx, lwp - mx).
+// A candidate sample of `PX` consecutive grid pixels is PX consecutive elements: one DWORD-ALIGNED 16-byte load (luma and
+// chroma together), whatever the candidate offset is.  (Round 1 kept byte planes for luma and 2-byte planes for chroma:
+// their 4- and 8-byte strips started at arbitrary byte offsets, and a vector load that is not dword-aligned takes a 3-4x
+// slower path through the texture addresser -- the chain kernels ran at 78 % TA busy.)
 struct PhaseLayout {
-    int rs, nph, nph2;       // 2^rs luma phases, max(1, nph/2) chroma phases
+    int rs, nph, nph2;       // 2^rs luma phases, max(1, nph/2) phase pairs
     int mx;                  // left margin in grid units (covers every reachable offset, reflection baked in)
-    int lwp;                 // row pitch in elements (multiple of 16)
-    size_t py_bytes, puv_bytes;
+    int lwp;                 // row pitch in elements (multiple of 4)
+    size_t bytes;            // H * nph2 * lwp * 4
 };
 PhaseLayout make_phase_layout(const Geom& g, int max_iterations);
 
@@ -53,10 +60,8 @@ struct PendingArgmin {
 // One level (or one axis of a level for windows > 32) of the refinement chain
 // (calcDeltaSums + determineLowestLayer + adjustOffsetArray of the reference).
 struct FlowStep {
-    const uint8_t* py1;      // frame N-1 phase planes (candidates are sampled here)
-    const uint16_t* puv1;
-    const uint8_t* py2;      // frame N phase planes (its phase 0 = the grid samples)
-    const uint16_t* puv2;
+    const uint32_t* pp1;     // frame N-1 phase plane (candidates are sampled here)
+    const uint32_t* pp2;     // frame N phase plane (its phase 0 = the grid samples)
     PhaseLayout pl;
     FlowLevel cur, prev;     // prev.tx == nullptr on the first level
     uint32_t* sums;          // [n_windows][16] raw SAD sums (windows > 32 only)
@@ -92,9 +97,7 @@ struct BlurBatch {
 };
 
 // Re-lay a freshly uploaded frame as phase planes (once per frame).
-void launch_prep_frame(const Geom& g, const PhaseLayout& pl, const void* frame, uint8_t* py, uint16_t* puv, hipStream_t stream);
-// Only the entries the chain reads of its NEWER frame (phase 0 of the rows cy << rs); the full planes can follow later.
-void launch_prep_phase0(const Geom& g, const PhaseLayout& pl, const void* frame, uint8_t* py, uint16_t* puv, hipStream_t stream);
+void launch_prep_frame(const Geom& g, const PhaseLayout& pl, const void* frame, uint32_t* pp, hipStream_t stream);
 // Windows <= 32: X and Y step of one level in a single launch.
 void launch_flow_level_small(const Geom& g, const FlowBatch& b, hipStream_t stream);
 // Windows > 32, one axis: partial SAD sums (atomics), then argmin + table update.

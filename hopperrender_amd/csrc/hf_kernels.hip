@@ -62,8 +62,13 @@ __device__ __forceinline__ int mirror_flow(int pos, int dim) {  // blurFlowKerne
     return clampi(pos, 0, dim - 1);
 }
 
-// Both planes per workgroup (sequentially through the same LDS tile) so that the kernel can also
-// emit the packed (x | y << 16) copy of the blurred flow that warp_fast_kernel reads with one load.
+// One workgroup = 16 x 16 outputs, both planes: the offsets of the (16 + 2r)^2 neighbourhood go through LDS once as
+// packed x | y << 16 words, then a horizontal and a vertical pass of 2r taps each (blurFlowKernelSDR.h:79-91 sums
+// the same (2r)^2 taps in one double loop; integer sums are order-independent).  The kernel also emits the packed
+// copy of the blurred flow that warp_fast_kernel reads with one load, and re-zeroes the window sums of the chain.
+__device__ __forceinline__ int div_trunc(int s, int d, int log2d) {   // C division (truncation toward zero), :89-90
+    return log2d >= 0 ? (s + ((s >> 31) & (d - 1))) >> log2d : s / d;
+}
 __global__ __launch_bounds__(256) void blur_flow_kernel(const BlurBatch batch, int lw, int lh, int r, int zero_count) {
     const BlurItem& it = batch.s[blockIdx.z];   // blockIdx.z: pair of the batch
     const FlowLevel& L = it.last;
@@ -76,41 +81,46 @@ __global__ __launch_bounds__(256) void blur_flow_kernel(const BlurBatch batch, i
     }
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int T = 16 + 2 * r;                     // tile edge
-    int* rows = (int*)smem;                       // [2][T][16] horizontal sums
-    int16_t* tile = (int16_t*)(rows + 2 * T * 16); // [2][T][T]
+    uint32_t* tile = (uint32_t*)smem;             // [T][T] packed offsets
+    int* hx = (int*)(tile + T * T);               // [T][16] horizontal sums of x
+    int* hy = hx + T * 16;                        // [T][16] ... of y
     const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * 16 - r, y0 = blockIdx.y * 16 - r;
     const int tx = tid & 15, ty = tid >> 4;
+    const int x0 = blockIdx.x * 16 - r, y0 = blockIdx.y * 16 - r;
+    for (int py = ty; py < T; py += 16) {         // offsets are stored per window of the last level
+        const int wrow = (mirror_flow(y0 + py, lh) >> L.log2w) * L.nwx;
+        for (int px = tx; px < T; px += 16) {
+            const int w = wrow + (mirror_flow(x0 + px, lw) >> L.log2w);
+            const uint32_t ox = L.tx ? (uint32_t)(uint16_t)L.tx[w] : 0u, oy = L.ty ? (uint32_t)(uint16_t)L.ty[w] : 0u;
+            tile[py * T + px] = ox | (oy << 16);
+        }
+    }
+    __syncthreads();
+    for (int row = ty; row < T; row += 16) {      // taps -r .. r-1 (blurFlowKernelSDR.h:82-83)
+        const uint32_t* p = tile + row * T + tx;
+        int sx = 0, sy = 0;
+        for (int k = 0; k < 2 * r; k++) {
+            const uint32_t w = p[k];
+            sx += (int)(int16_t)(w & 0xFFFFu);
+            sy += (int)w >> 16;
+        }
+        hx[row * 16 + tx] = sx;
+        hy[row * 16 + tx] = sy;
+    }
+    __syncthreads();
+    int sx = 0, sy = 0;
+    for (int k = 0; k < 2 * r; k++) {
+        sx += hx[(ty + k) * 16 + tx];
+        sy += hy[(ty + k) * 16 + tx];
+    }
+    const int d = 4 * r * r, log2d = (r & (r - 1)) == 0 ? 2 + 2 * (31 - __builtin_clz(r)) : -1;
+    const int rx = (int)(int16_t)div_trunc(sx, d, log2d), ry = (int)(int16_t)div_trunc(sy, d, log2d);
     const int gx = blockIdx.x * 16 + tx, gy = blockIdx.y * 16 + ty;
-    // both planes go through every stage together: one round of global loads and two barriers per workgroup
-    for (int i = tid; i < T * T; i += 256) {      // offsets are stored per window of the last level
-        const int py = i / T, px = i - py * T;
-        const int w = (mirror_flow(y0 + py, lh) >> L.log2w) * L.nwx + (mirror_flow(x0 + px, lw) >> L.log2w);
-        tile[i] = L.tx ? L.tx[w] : (int16_t)0;
-        tile[T * T + i] = L.ty ? L.ty[w] : (int16_t)0;
-    }
-    __syncthreads();
-    for (int i = tid; i < 2 * T * 16; i += 256) {     // taps -r .. r-1 (blurFlowKernelSDR.h:82-83)
-        const int z = i >= T * 16, k16 = i - z * T * 16;
-        const int row = k16 >> 4, col = k16 & 15;
-        const int16_t* p = tile + z * T * T + row * T + col;
-        int s = 0;
-        for (int k = 0; k < 2 * r; k++) s += p[k];
-        rows[i] = s;
-    }
-    __syncthreads();
-    int res[2];
-#pragma unroll
-    for (int z = 0; z < 2; z++) {
-        int s = 0;
-        for (int k = 0; k < 2 * r; k++) s += rows[z * T * 16 + (ty + k) * 16 + tx];
-        res[z] = (int)(int16_t)(s / (4 * r * r));      // C truncation, :89-90
-    }
     if (gx < lw && gy < lh) {
-        const size_t p = (size_t)gy * lw + gx;
-        blurred[p] = (int16_t)res[0];
-        blurred[(size_t)lw * lh + p] = (int16_t)res[1];
-        packed[p] = ((uint32_t)res[0] & 0xFFFFu) | ((uint32_t)res[1] << 16);
+        const size_t q = (size_t)gy * lw + gx;
+        blurred[q] = (int16_t)rx;
+        blurred[(size_t)lw * lh + q] = (int16_t)ry;
+        packed[q] = ((uint32_t)rx & 0xFFFFu) | ((uint32_t)ry << 16);
     }
 }
 
@@ -708,11 +718,9 @@ __global__ void rcp_probe_kernel(const float* in, float* out, int n) {
 void launch_blur_flow(const Geom& g, const BlurBatch& b, int radius, int zero_count, hipStream_t stream) {
     const dim3 grd((g.lw + 15) / 16, (g.lh + 15) / 16, b.n);
     const int T = 16 + 2 * radius;
-    const size_t smem = 2 * ((size_t)T * 16 * sizeof(int) + (size_t)T * T * sizeof(int16_t));
-    if (smem > 48 * 1024) {   // large radii (up to 64: 101 KB of the CU's 160 KB LDS) need the opt-in
-        static bool raised = false;
-        if (!raised) raised = hipFuncSetAttribute((const void*)blur_flow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess;
-    }
+    const size_t smem = (size_t)T * T * sizeof(uint32_t) + 2 * (size_t)T * 16 * sizeof(int);
+    if (smem > 48 * 1024)     // large radii (up to 64: 101 KB of the CU's 160 KB LDS) need the opt-in; the attribute is per device
+        (void)hipFuncSetAttribute((const void*)blur_flow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     blur_flow_kernel<<<grd, 256, smem, stream>>>(b, g.lw, g.lh, radius, zero_count);
 }
 
