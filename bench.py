@@ -4,17 +4,26 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload hdr2160_24to120] [--radius 16]
     (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-A STEP = one source-frame period for every one of the `--streams` independent frame-pair streams a
-rank owns: upload-free updateFrame (device-resident source frame -> ring), calculateOpticalFlow
-(16-step refinement + blur), then the warpFrames(t, BlendedFrame) calls the reference filter would
-issue for that period (24->120 fps: 5 or 6 outputs, reference HopperRender.cpp:944-948,1192-1197),
-each into its own output frame in HBM.  Streams are independent (flow has no temporal state), so
-ranks shard them with NO collective: weak scaling.
+A STEP = `--periods-per-step` (64) consecutive source-frame periods for every one of the `--streams` independent
+frame-pair streams a rank owns.  One period of one stream = updateFrame of a device-resident source frame (zero-copy
+reference into the 3-frame ring + phase-plane build), calculateOpticalFlow (16-step refinement + blur), then the
+warpFrames(t, BlendedFrame) calls the reference filter would issue for that period (24->120 fps: 5 or 6 outputs,
+reference HopperRender.cpp:944-948,1192-1197), each into its own output frame in HBM.  Streams are grouped into
+batches (hf_batch): one phase-plane launch, one batched refinement chain and ONE fused warp launch per batch and period.
+Streams are independent (flow has no temporal state), so ranks shard them with NO collective:
+weak scaling.
 
-One JSON line on rank 0.  `roofline` prices the dominant kernel (warp_kernel, HBM-bound) from HIP
-events recorded on the kernels' own streams during the timed region; `cpu_baseline` times the plain-C
-oracle port on a bounded sample; `reference_opencl` times the reference's own OpenCL path
-(oracle/_ref) on the same GPU when it is available.
+One JSON line on rank 0:
+  value              whole-job interpolated frames/s, inputs and outputs resident in HBM
+  roofline           the HBM roofline of the PIPELINE as SURVEY.md 8(d) defines it: frac = value x B_out / 8 TB/s,
+                     B_out = 3F + 4N algorithmic bytes per output frame; plus the dominant kernel (the fused period warp)
+                     alone on the GPU, priced both with the algorithmic bytes it stands for and with its real HBM traffic
+                     (profiles/roofline_traffic.json, generated from rocprofv3 PMC passes by tools/pmc_traffic.py), and its
+                     launch duration inside the timed region (HIP events of the dispatch itself)
+  host_io            the same path with host buffers: pinned asynchronous H2D / D2H on side streams (PCIe-inclusive,
+                     never `value`)
+  cpu_baseline       the plain-C oracle port on a bounded sample, 1 thread and all host cores
+  reference_opencl   the reference's own OpenCL path (oracle/_ref) on the same GPU when it is available
 """
 import argparse
 import json
@@ -26,10 +35,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # HIP multiplexes all streams of a process onto GPU_MAX_HW_QUEUES hardware queues (default 4, one of which the
-# null stream takes): two HIP streams that share a queue run strictly one after the other.  Measured on MI355X
-# (tools/scan3.sh): 4 pair streams on 4 queues of their own 44.0k frames/s vs 40.0k on 3 shared ones; with 6 or more
-# queues in use the device gets slower again (31k).  So: 5 queues = 1 (null stream) + 4 for the pair streams /
-# batches.  Must be set before the HIP runtime initialises; an explicit setting by the caller wins.
+# null stream takes): two HIP streams that share a queue run strictly one after the other, and with 6 or more queues in
+# use the device gets slower again (DESIGN.md "Hardware queues").  So: 1 (null stream) + one queue per batch stream,
+# at most 5.  Must be set before the HIP runtime initialises; an explicit setting by the caller wins.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "5")
 
 WORKLOADS = {
@@ -40,37 +48,34 @@ WORKLOADS = {
     "sdr1080_24to120": (0, 1080, 1920, 83333, "1920x1080 SDR (NV12), 24->120 fps"),
     "sdr360_24to60": (0, 360, 640, 166667, "640x360 SDR, 24->60 fps (plumbing size)"),
 }
+# per workload: (pair streams per GPU, pairs per flow batch) -- measured operating points, DESIGN.md section 5
+OPERATING_POINT = {"hdr2160_24to120": (8, 4), "hdr2160_24to60": (8, 4), "sdr1080_24to60": (16, 8), "sdr1080_24to120": (16, 8),
+                   "sdr360_24to60": (16, 8)}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+WARP_SYMBOL = {1: "warp_fast_kernel<unsigned short, 8, 2, 2, 16, true>", 0: "warp_fast_kernel<unsigned char, 4, 2, 2, 8, true>"}
 
 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--periods-per-step", type=int, default=64, help="consecutive source periods per pair stream in one step")
     ap.add_argument("--workload", default="hdr2160_24to120", choices=sorted(WORKLOADS))
     ap.add_argument("--radius", type=int, default=16)
     ap.add_argument("--neighbor", type=int, default=6)
     ap.add_argument("--blur-radius", type=int, default=4)
-    ap.add_argument("--streams", type=int, default=8, help="independent frame-pair streams per GPU")
-    ap.add_argument("--batch", type=int, default=2,
-                    help="pair streams per flow batch (hf_batch): the refinement chains of `batch` independent pairs run as one "
-                         "set of launches on one HIP stream; streams/batch batches run side by side")
+    ap.add_argument("--streams", type=int, default=0, help="independent frame-pair streams per GPU (0: the workload's operating point)")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="pair streams per hf_batch: their phase planes, refinement chains and period warps run as one set of launches on "
+                         "one HIP stream; streams/batch batches run side by side (0: the workload's operating point; 1: no batching)")
     ap.add_argument("--pool", type=int, default=6, help="distinct synthetic source frames resident in HBM, per pair stream")
-    ap.add_argument("--dual-stream-contexts", action="store_true",
-                    help="two HIP streams per pair stream: the warps of a period overlap its flow chain (measured equal "
-                         "throughput at 4 pair streams, lower per-launch roofline; default: one stream per pair stream)")
-    ap.add_argument("--priority-streams", action="store_true",
-                    help="per pair stream: flow chain on a high-priority stream, warps on a low-priority stream")
-    ap.add_argument("--no-fused-warp", action="store_true", help="one warp launch per output frame instead of one per source period")
-    ap.add_argument("--shared-warp-stream", action="store_true",
-                    help="issue the warp kernels of all pair streams on one shared stream per GPU (measured slower: 26.5k vs 33k frames/s)")
-    ap.add_argument("--no-lazy-argmin", action="store_true", help="HF_FLAG_NO_LAZY_ARGMIN: 6 more (tiny) launches per flow chain (A-B: cost of kernel boundaries)")
-    ap.add_argument("--defer-prep", action="store_true", help="HF_FLAG_DEFER_PREP (full phase planes one period later, right before their use)")
+    ap.add_argument("--member-warps", action="store_true", help="A-B: one fused warp launch and one phase-plane launch per member instead of per batch")
+    ap.add_argument("--dual-stream-contexts", action="store_true", help="A-B: HF_FLAG_DUAL_STREAM members (warps overlap the context's own chain)")
+    ap.add_argument("--no-fused-warp", action="store_true", help="A-B: one warp launch per output frame instead of one per source period")
+    ap.add_argument("--no-lazy-argmin", action="store_true", help="A-B: HF_FLAG_NO_LAZY_ARGMIN, 6 more (tiny) launches per flow chain")
     ap.add_argument("--timing-events", action="store_true",
                     help="keep the reference's per-call timing events (m_ofcCalcTime, m_warpCalcTime); default off in the bench")
-    ap.add_argument("--warp-turnstile", action="store_true",
-                    help="HF_FLAG_WARP_TURNSTILE: the warp launches of all pair streams run one at a time")
     ap.add_argument("--copy-in", action="store_true",
                     help="updateFrame copies the device-resident source frame into the ring (default: zero-copy reference)")
     ap.add_argument("--profile-every", type=int, default=8,
@@ -80,6 +85,7 @@ def parse_args():
     ap.add_argument("--no-profile", action="store_true", help="no per-kernel HIP events in the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference", action="store_true")
+    ap.add_argument("--no-host-io", action="store_true")
     ap.add_argument("--cpu-sample-pairs", type=int, default=8)
     return ap.parse_args()
 
@@ -107,15 +113,15 @@ def cpu_baseline(hdr, H, W, target, radius, neighbor, frames, n_pairs):
             "sample": f"{n_pairs} source pairs ({outs} output frames) of the same workload, oracle/hf_oracle.c, 1 thread, {dt:.1f} s"}
 
 
-def cpu_baseline_all_cores(hdr, H, W, target, radius, neighbor, frames, pairs_per_thread=2, max_threads=64):
-    """The same oracle port with one source pair per host thread at a time (pairs are independent units, SURVEY.md
-    section 8(e); the C calls release the GIL)."""
+def cpu_baseline_all_cores(hdr, H, W, target, radius, neighbor, frames):
+    """The same oracle port with one source pair per host thread (pairs are independent units, SURVEY.md section 8(e);
+    the C calls release the GIL), on EVERY core the process may run on."""
     from concurrent.futures import ThreadPoolExecutor
     from hopperrender_amd.protocol import SOURCE_24, BlendSchedule
     from oracle import oracle
     g = oracle.make_geom(hdr, H, W)
-    threads = max(1, min(len(os.sched_getaffinity(0)), max_threads))
-    n_pairs = threads * pairs_per_thread
+    threads = max(1, len(os.sched_getaffinity(0)))
+    n_pairs = threads
     plan = BlendSchedule(SOURCE_24, target).plan(n_pairs + 1)[1:]
 
     def one(i):
@@ -130,7 +136,7 @@ def cpu_baseline_all_cores(hdr, H, W, target, radius, neighbor, frames, pairs_pe
         outs = sum(ex.map(one, range(n_pairs)))
     dt = time.perf_counter() - t0
     return {"value": outs / dt, "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"{n_pairs} source pairs ({outs} output frames), one pair per thread at a time, {threads} threads, {dt:.1f} s"}
+            "sample": f"{n_pairs} source pairs ({outs} output frames), one pair per thread, {threads} threads = all host cores, {dt:.1f} s"}
 
 
 def reference_opencl(hdr, H, W, target, radius, neighbor, frames):
@@ -153,6 +159,68 @@ def reference_opencl(hdr, H, W, target, radius, neighbor, frames):
                     "back-to-back calculateOpticalFlow / warpFrames calls, no host transfers"}
 
 
+def host_io_block(cls, H, W, target, radius, neighbor, frames, dev, n_periods=24):
+    """PCIe-inclusive rates of ONE context fed from and read back into host memory (never the bench `value`):
+    the reference's blocking protocol with pageable and with pinned buffers, and the asynchronous variant
+    (hf_update_frame_async / hf_download_frame_async: pinned buffers, H2D and D2H on side streams)."""
+    import numpy as np
+    from hopperrender_amd import capi
+    from hopperrender_amd.calc import PinnedArray
+    from hopperrender_amd.protocol import SOURCE_24, BlendSchedule
+    res = {}
+    plan = BlendSchedule(SOURCE_24, target).plan(n_periods + 4)
+    for pinned in (False, True):
+        c = cls(H, W, 0, 0, 8, neighbor, 0.0, 255.0, 270, device_index=dev, search_radius=radius)
+        n_el = c.output_frame_bytes // np.dtype(c.dtype).itemsize
+        pins = []
+        if pinned:
+            pins = [PinnedArray(f.size, c.dtype) for f in frames[:4]]
+            for p, f in zip(pins, frames):
+                p.array[:] = f
+            src = [p.array for p in pins]
+            outp = PinnedArray(n_el, c.dtype); out = outp.array; pins.append(outp)
+        else:
+            src, out = frames[:4], np.empty(n_el, c.dtype)
+        for k in range(3):
+            c.updateFrame(src[k])
+        c.calculateOpticalFlow()
+        t0 = time.perf_counter(); nout = 0
+        for i in range(n_periods):
+            c.updateFrame(src[i % 4]); c.calculateOpticalFlow()
+            for t in plan[i + 3]:
+                c.warpFrames(t, 2); c.downloadFrame(out); nout += 1
+        dt = time.perf_counter() - t0
+        res["blocking_pinned" if pinned else "blocking_pageable"] = {"frames_per_s": round(nout / dt, 1), "d2h_GB_per_s": round(nout * c.output_frame_bytes / dt / 1e9, 2)}
+        c.close()
+        for p in pins:
+            p.free()
+    c = cls(H, W, 0, 0, 8, neighbor, 0.0, 255.0, 270, device_index=dev, search_radius=radius, flags=capi.HF_FLAG_ASYNC | capi.HF_FLAG_DUAL_STREAM)
+    n_el = c.output_frame_bytes // np.dtype(c.dtype).itemsize
+    ins = [PinnedArray(f.size, c.dtype) for f in frames[:4]]
+    for p, f in zip(ins, frames):
+        p.array[:] = f
+    outs = [PinnedArray(n_el, c.dtype) for _ in range(8)]
+    for k in range(3):
+        c.updateFrameAsync(ins[k])
+    c.calculateOpticalFlow(); c.sync()
+    t0 = time.perf_counter(); nout = 0
+    for i in range(n_periods):
+        c.updateFrameAsync(ins[i % 4]); c.calculateOpticalFlow()
+        for t in plan[i + 3]:
+            c.warpFrames(t, 2); c.downloadFrameAsync(outs[nout % 8]); nout += 1
+        if i % 2 == 1:
+            c.sync()     # bound the number of in-flight host buffers (8 outputs here)
+    c.sync(); dt = time.perf_counter() - t0
+    res["async_pinned_side_streams"] = {"frames_per_s": round(nout / dt, 1), "d2h_GB_per_s": round(nout * c.output_frame_bytes / dt / 1e9, 2),
+                                       "h2d_GB_per_s": round(n_periods * c.input_frame_bytes / dt / 1e9, 2)}
+    c.close()
+    for p in ins + outs:
+        p.free()
+    res["note"] = (f"one context, {n_periods} source periods, frames enter and leave through host memory (PCIe Gen5 x16); "
+                   "output frames returned to the host; never the bench `value`")
+    return res
+
+
 def main():
     a = parse_args()
     import numpy as np
@@ -167,9 +235,10 @@ def main():
     backend = os.environ.get("HF_BENCH_BACKEND", "nccl")
     dev_index = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(dev_index)
+
     def init_dist():
         # Called AFTER the pair streams exist: HIP deals streams to its few hardware queues in creation order, and the
-        # communicator's own streams must not push two pair streams onto one queue (DESIGN.md "Hardware queues").
+        # communicator's own streams must not push two batch streams onto one queue (DESIGN.md "Hardware queues").
         if world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             if backend == "nccl":
@@ -183,11 +252,18 @@ def main():
     import __graft_entry__
     __graft_entry__.build(quiet=True)
     from hopperrender_amd import capi, synth
-    from hopperrender_amd.calc import DeviceBuffer, OpticalFlowCalcHDR, OpticalFlowCalcSDR
+    from hopperrender_amd.calc import DeviceBuffer, FlowBatch, OpticalFlowCalcHDR, OpticalFlowCalcSDR
     from hopperrender_amd.protocol import SOURCE_24, BlendSchedule
 
     hdr, H, W, target, desc = WORKLOADS[a.workload]
     dev = dev_index
+    op_streams, op_batch = OPERATING_POINT[a.workload]
+    if a.streams <= 0:
+        a.streams = op_streams
+    if a.batch <= 0:
+        a.batch = min(op_batch, a.streams)
+    if a.streams % a.batch:
+        raise SystemExit("--streams must be a multiple of --batch")
 
     # ---- synthetic source frames, resident in HBM before the timed region ----
     scene = synth.Scene(H, W, bool(hdr), seed=1234 + rank)
@@ -203,33 +279,21 @@ def main():
             bufs.append(b)
         pools.append(bufs)
 
-    def update(c, ptr):
-        if a.copy_in:
-            c.updateFrameDevice(ptr)
-        else:
-            c.updateFrameDeviceRef(ptr)
-
     flags = capi.HF_FLAG_ASYNC | (0 if a.no_profile else capi.HF_FLAG_PROFILE)
     if not a.timing_events:
         flags |= capi.HF_FLAG_NO_TIMING   # the m_ofcCalcTime / m_warpCalcTime events are barrier packets between the kernels
     if a.no_fused_warp:
         flags |= capi.HF_FLAG_NO_FUSED_WARP
-    if a.shared_warp_stream:
-        flags |= capi.HF_FLAG_SHARED_WARP_STREAM
-    if a.priority_streams:
-        flags |= capi.HF_FLAG_PRIORITY_STREAMS
     if a.dual_stream_contexts:
         flags |= capi.HF_FLAG_DUAL_STREAM
-    if a.warp_turnstile:
-        flags |= capi.HF_FLAG_WARP_TURNSTILE
-    if a.defer_prep:
-        flags |= capi.HF_FLAG_DEFER_PREP
     if a.no_lazy_argmin:
         flags |= capi.HF_FLAG_NO_LAZY_ARGMIN
     cls = OpticalFlowCalcHDR if hdr else OpticalFlowCalcSDR
     calcs, outbufs, plans = [], [], []
-    total_steps = a.warmup + a.steps
+    P = a.periods_per_step
+    total_periods = (a.warmup + a.steps) * P
     max_out = 6 if target == 83333 else 3
+    schedule = BlendSchedule(SOURCE_24, target).plan(total_periods + 3)[3:]
     for s in range(a.streams):
         c = cls(H, W, 0, 0, 8, a.neighbor, 0.0, 255.0, 270, device_index=dev, search_radius=a.radius,
                 blur_radius=a.blur_radius, flags=flags)
@@ -237,56 +301,63 @@ def main():
         if not a.no_profile:
             c.setProfileInterval(a.profile_every, max(1, a.profile_every // 4))
         outbufs.append([DeviceBuffer(c.output_frame_bytes, dev) for _ in range(max_out)])
-        plans.append(BlendSchedule(SOURCE_24, target).plan(total_steps + 3)[3:])
+        plans.append(schedule)
         for k in range(3):  # prime the 3-frame ring and the previous-flow slot (m_frameCount >= 3)
-            update(c, pools[s][(s + k) % a.pool].ptr)
+            c.updateFrameDeviceRef(pools[s][(s + k) % a.pool].ptr)
         c.calculateOpticalFlow()
         c.sync()
 
     out_ptrs = [[b.ptr for b in bufs] for bufs in outbufs]
-    batches = []
-    if a.batch > 1 and (a.shared_warp_stream or a.priority_streams):
-        a.batch = 1          # hf_batch members are single-stream contexts
-    if a.batch > 1:
-        from hopperrender_amd.calc import FlowBatch
-        if a.streams % a.batch:
-            raise SystemExit("--streams must be a multiple of --batch")
-        batches = [FlowBatch(calcs[k:k + a.batch]) for k in range(0, a.streams, a.batch)]
+    batches = [FlowBatch(calcs[k:k + a.batch]) for k in range(0, a.streams, a.batch)] if a.batch > 1 else []
 
-    def run_step_batched(i):
-        """Per batch: the new source frame of every member pair, ONE batched flow calculation, then every member's
-        outputs of the period (one fused warp launch each) -- all on the batch's stream."""
+    def src_ptr(s, i):
+        return pools[s][(s + 3 + i) % a.pool].ptr
+
+    def run_period_batched(i):
+        """Per batch: the new source frame of every member pair (one phase-plane launch), ONE batched flow calculation,
+        then every member's outputs of the period in ONE fused warp launch -- all on the batch's stream."""
         n = 0
         for bi, b in enumerate(batches):
-            lo = bi * a.batch
-            for s in range(lo, lo + a.batch):
-                update(calcs[s], pools[s][(s + 3 + i) % a.pool].ptr)
+            lo, hi = bi * a.batch, (bi + 1) * a.batch
+            if a.member_warps or a.copy_in:
+                for s in range(lo, hi):
+                    (calcs[s].updateFrameDevice if a.copy_in else calcs[s].updateFrameDeviceRef)(src_ptr(s, i))
+            else:
+                b.updateFramesDeviceRef([src_ptr(s, i) for s in range(lo, hi)])
             if a.diagnose != "no-flow":
                 b.calculateOpticalFlow()
-            for s in range(lo, lo + a.batch):
-                ts = plans[s][i]
-                if a.diagnose != "no-warp":
-                    calcs[s].interpolateOnly(ts, out_ptrs[s], 2)
-                n += len(ts)
+            if a.diagnose != "no-warp":
+                if a.member_warps:
+                    for s in range(lo, hi):
+                        calcs[s].interpolateOnly(plans[s][i], out_ptrs[s], 2)
+                else:
+                    b.interpolatePeriod([plans[s][i] for s in range(lo, hi)], out_ptrs[lo:hi], 2)
+            n += sum(len(plans[s][i]) for s in range(lo, hi))
         return n
 
-    def run_step(i):
+    def run_period(i):
         if batches:
-            return run_step_batched(i)
+            return run_period_batched(i)
         n = 0
         for s, c in enumerate(calcs):
             ts = plans[s][i]
             if a.diagnose == "no-flow":
-                c.updateFrameDeviceRef(pools[s][(s + 3 + i) % a.pool].ptr)
+                c.updateFrameDeviceRef(src_ptr(s, i))
                 c.interpolateOnly(ts, out_ptrs[s], 2)
             elif a.diagnose == "no-warp":
-                c.interpolatePeriod(pools[s][(s + 3 + i) % a.pool].ptr, [], [], 2)
+                c.interpolatePeriod(src_ptr(s, i), [], [], 2)
             elif a.copy_in:
-                c.updateFrameDevice(pools[s][(s + 3 + i) % a.pool].ptr)
+                c.updateFrameDevice(src_ptr(s, i))
                 c.interpolatePeriod(0, ts, out_ptrs[s], 2)
             else:
-                c.interpolatePeriod(pools[s][(s + 3 + i) % a.pool].ptr, ts, out_ptrs[s], 2)
+                c.interpolatePeriod(src_ptr(s, i), ts, out_ptrs[s], 2)
             n += len(ts)
+        return n
+
+    def run_step(k):
+        n = 0
+        for i in range(k * P, (k + 1) * P):
+            n += run_period(i)
         return n
 
     def sync_all():
@@ -295,8 +366,8 @@ def main():
         torch.cuda.synchronize()
 
     init_dist()
-    for i in range(a.warmup):
-        run_step(i)
+    for k in range(a.warmup):
+        run_step(k)
     sync_all()
     for c in calcs:
         if not a.no_profile:
@@ -307,8 +378,8 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     frames_out = 0
-    for i in range(a.warmup, a.warmup + a.steps):
-        frames_out += run_step(i)
+    for k in range(a.warmup, a.warmup + a.steps):
+        frames_out += run_step(k)
     host_enqueue_s = time.perf_counter() - t0     # the host is done issuing; the GPU may still be busy
     sync_all()
     if world > 1:
@@ -331,15 +402,17 @@ def main():
             for k in prof:
                 prof[k] += p[k]
 
-    # Context for the roofline figure, OUTSIDE the timed region: the same kernels alone on the GPU (one stream,
-    # back-to-back launches).  In the timed region up to `streams` launches share the GPU, so a launch takes
-    # longer there although the aggregate rate is higher.
+    # Context for the roofline figure, OUTSIDE the timed region: the dominant kernel alone on the GPU (one stream,
+    # one member's fused period launch at a time, source frames rotating so that they come from HBM).
     isolated = None
     if rank == 0 and not a.no_profile:
+        for b in batches:
+            b.close()
+        batches = []
         c = calcs[0]
         c.setProfileInterval(1, 1)
         c.resetProfile()
-        for i in range(20):
+        for i in range(24):
             c.updateFrameDeviceRef(pools[0][i % a.pool].ptr)
             c.calculateOpticalFlow()
             c.sync()                                   # chain alone ...
@@ -352,56 +425,76 @@ def main():
     if rank == 0:
         st = calcs[0].stats()
         N = st["low_width"] * st["low_height"]
-        bpp = 2 if hdr else 1
         F = st["output_frame_bytes"]
         b_out = 3 * F + 4 * N  # read 2 source frames + write 1 + blurred flow once
-        roof = None
+        value = frames_total / elapsed_max
+        pipeline_gbs = value / n_gpus * b_out / 1e9              # per GPU: the roofline is a per-device bound
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(a.workload, {})
+            except Exception:
+                traffic = None
+        roof = {"bound": "hbm", "achieved": round(pipeline_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(pipeline_gbs / HBM_PEAK_GBS, 4), "frac_of_measured_copy_bw_6290": round(pipeline_gbs / 6290.0, 4),
+                "definition": "pipeline: frames/s per GPU x B_out (SURVEY.md 8(d)), B_out = 3F + 4N algorithmic bytes per output frame",
+                "algorithmic_bytes_per_unit": b_out,
+                "traffic": (traffic or {}).get("warp_kernel_hbm_bytes_per_launch"),
+                "traffic_note": "HBM bytes of one fused period launch of the dominant kernel (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                                "profiles/roofline_traffic.json generated by tools/pmc_traffic.py)",
+                "kernel": WARP_SYMBOL[hdr]}
         if prof["warp_launches"]:
             avg_ms = prof["warp_ms"] / prof["warp_launches"]
-            fpl = prof["warp_frames"] / prof["warp_launches"]     # output frames per launch (a period is one fused launch)
-            b_launch = b_out * fpl                                 # per-unit bytes x units one launch processes
-            achieved = b_launch / (avg_ms * 1e-3) / 1e9
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
-            if os.path.exists(tpath):
-                try:
-                    traffic = json.load(open(tpath)).get(a.workload, {}).get("warp_kernel_hbm_bytes_per_launch")
-                except Exception:
-                    traffic = None
-            roof = {"bound": "hbm", "kernel": "warp_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "algorithmic_bytes_per_unit": b_out, "units_per_launch": round(fpl, 3),
-                    "algorithmic_bytes_per_launch": int(b_launch), "avg_launch_us": round(avg_ms * 1e3, 2),
-                    "launches": prof["warp_launches"], "sampled_every": a.profile_every,
-                    "frac_of_measured_copy_bw_6290": round(achieved / 6290.0, 4),
-                    "note": "in the timed region (HIP events on the launching stream); pair streams overlap, so a launch "
-                            "shares the GPU with up to pair_streams_per_gpu-1 others"}
-            if isolated:
-                iso = b_out * isolated["fpl"] / (isolated["warp_us"] * 1e-6) / 1e9
-                roof["isolated"] = {"avg_launch_us": round(isolated["warp_us"], 2), "achieved": round(iso, 1),
-                                    "frac": round(iso / HBM_PEAK_GBS, 4), "frac_of_measured_copy_bw_6290": round(iso / 6290.0, 4),
-                                    "note": "same kernel alone on the GPU (one stream), measured after the timed region"}
+            fpl = prof["warp_frames"] / prof["warp_launches"]     # output frames per launch (a batch's period is one fused launch)
+            roof["kernel_in_pipeline"] = {
+                "avg_launch_us": round(avg_ms * 1e3, 2), "output_frames_per_launch": round(fpl, 3),
+                "algorithmic_GBps": round(b_out * fpl / (avg_ms * 1e-3) / 1e9, 1), "launches_sampled": prof["warp_launches"],
+                "note": "HIP events of the dispatch itself inside the timed region; the other batch streams' kernels share the GPU "
+                        "while it runs, so this is neither a kernel roofline nor a pipeline one"}
+        if isolated:
+            alg = b_out * isolated["fpl"] / (isolated["warp_us"] * 1e-6) / 1e9
+            iso = {"avg_launch_us": round(isolated["warp_us"], 2), "output_frames_per_launch": round(isolated["fpl"], 3),
+                   "algorithmic_GBps": round(alg, 1), "algorithmic_frac": round(alg / HBM_PEAK_GBS, 4),
+                   "note": "the same kernel alone on the GPU (one member's fused period per launch, sources from HBM), after the timed "
+                           "region.  'algorithmic' credits 3F + 4N per output frame although the fused launch reads the two source "
+                           "frames once for all its outputs; 'real' prices the bytes the PMC counters saw"}
+            if traffic and traffic.get("warp_kernel_hbm_bytes_per_launch") and abs(traffic.get("units_per_launch", 0) - isolated["fpl"]) < 0.75:
+                real = traffic["warp_kernel_hbm_bytes_per_launch"] / (isolated["warp_us"] * 1e-6) / 1e9
+                iso["real_GBps"] = round(real, 1)
+                iso["real_frac"] = round(real / HBM_PEAK_GBS, 4)
+            roof["kernel_isolated"] = iso
         out = {
             **({"DIAGNOSTIC_NOT_A_BENCHMARK": a.diagnose} if a.diagnose else {}),
             "metric": "interpolated frames/sec + ms/flow-calc, 2160p HDR, 1/2/4/8 MI355X",
-            "value": round(frames_total / elapsed_max, 1),
+            "value": round(value, 1),
             "unit": "frames/s",
             "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(1e3 * elapsed_max / a.steps, 4),
+            "timed_region_s": round(elapsed_max, 3),
             "host_enqueue_ms_per_step": round(1e3 * host_enqueue_s / a.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u16" if hdr else "u8", "data": "synthetic",
             "config": {"workload": a.workload, "description": desc, "search_radius": a.radius,
                        "delta_scalar": 8, "neighbor_scalar": a.neighbor, "blur_radius": a.blur_radius,
-                       "pair_streams_per_gpu": a.streams, "flow_batch": a.batch, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "warp_stream": "shared per GPU" if a.shared_warp_stream else ("own stream, overlapping the context's flow chain" if a.dual_stream_contexts else "same stream as the flow chain"), "source_frames": "copied into the ring" if a.copy_in else "referenced in place (zero-copy)", "source_periods_per_step": a.streams,
+                       "pair_streams_per_gpu": a.streams, "flow_batch": a.batch, "batch_streams_per_gpu": a.streams // a.batch,
+                       "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                       "launches_per_batch_and_period": "1 phase-plane build + 12-launch chain graph + 1 fused warp" if (batches or a.batch > 1) and not a.member_warps else "per member",
+                       "source_frames": "copied into the ring" if a.copy_in else "referenced in place (zero-copy)",
+                       "source_periods_per_step": a.streams * P, "source_periods_per_stream_and_step": P,
                        "output_frames_total": int(frames_total), "parallelism": f"pair-sharded x{n_gpus}, no collective",
                        "frame_bytes": F, "flow_grid": [st["low_width"], st["low_height"]], "res_scalar": st["res_scalar"]},
             "ms_per_flow_calc": round(prof["flow_ms"] / prof["flow_chains"], 4) if prof["flow_chains"] else None,
-            "ms_per_flow_calc_note": "device time of one refinement chain + blur while the other pair streams keep the GPU busy"
+            "ms_per_flow_calc_note": "device time of one refinement chain + blur while the other batch streams keep the GPU busy"
                                      + (f"; chains run {a.batch} pairs per launch (hf_batch): this is the batch's time / {a.batch}" if a.batch > 1 else ""),
             "ms_per_flow_calc_isolated": round(isolated["flow_chain_us"] / 1e3, 4) if isolated else None,
             "roofline": roof,
         }
+        if not a.no_host_io and world == 1:
+            try:
+                out["host_io"] = host_io_block(cls, H, W, target, a.radius, a.neighbor, host_frames, dev)
+            except Exception as e:
+                out["host_io"] = {"error": repr(e)}
         if not a.no_cpu_baseline and world == 1:   # reported baselines: rank 0 at N = 1 only
             try:
                 out["cpu_baseline"] = cpu_baseline(hdr, H, W, target, a.radius, a.neighbor, host_frames, a.cpu_sample_pairs)

@@ -44,8 +44,8 @@ def build_flow(force=False):
     os.makedirs(LIBDIR, exist_ok=True)
     extra = os.environ.get("HF_CXXFLAGS", "").split()   # experiments only (e.g. -DHF_EXP=1)
     force = force or bool(extra)
-    srcs = [os.path.join(CSRC, f) for f in ("hf_kernels.hip", "hf_flow.hip", "hf_capi.hip")]
-    deps = srcs + [os.path.join(CSRC, "hf_kernels.h"), os.path.join(INCLUDE, "hopperflow.h")]
+    srcs = [os.path.join(CSRC, f) for f in ("hf_kernels.hip", "hf_flow.hip", "hf_capi.hip", "hf_filter.cpp")]
+    deps = srcs + [os.path.join(CSRC, "hf_kernels.h"), os.path.join(INCLUDE, "hopperflow.h"), os.path.join(INCLUDE, "config.h")]
     if force or _stale(LIB_FLOW, deps):
         objs = []
         hdrs = deps[len(srcs):]
@@ -63,7 +63,7 @@ def build_adapter(force=False):
     src = os.path.join(CSRC, "opticalFlowCalc.cpp")
     if not os.path.exists(src):
         return None
-    deps = [src, os.path.join(INCLUDE, "opticalFlowCalc.h"), os.path.join(INCLUDE, "hopperflow.h")]
+    deps = [src, os.path.join(INCLUDE, "opticalFlowCalc.h"), os.path.join(INCLUDE, "hopperflow.h"), os.path.join(INCLUDE, "config.h")]
     if force or _stale(LIB_ADAPTER, deps + [LIB_FLOW]):
         _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", "-I", INCLUDE, src, "-o", LIB_ADAPTER,
               "-L", LIBDIR, "-lhopperflow", "-Wl,-rpath,$ORIGIN", "-Wl,--no-undefined"])

@@ -295,9 +295,28 @@ class FlowBatch:
         self._b = out
 
     def calculateOpticalFlow(self):
-        rc = self._lib.hf_batch_calculate_optical_flow(self._b)
+        self._check(self._lib.hf_batch_calculate_optical_flow(self._b))
+
+    def _check(self, rc):
         if rc != 0:
             raise capi.HopperFlowError(rc, (self._lib.hf_batch_last_error(self._b) or b"").decode())
+
+    def updateFramesDeviceRef(self, dev_ptrs):
+        """updateFrameDeviceRef of every member; the phase planes of all new frames are built by one launch."""
+        arr = (C.c_void_p * len(self.members))(*[int(p) for p in dev_ptrs])
+        self._check(self._lib.hf_batch_update_frames_device_ref(self._b, arr))
+
+    def interpolatePeriod(self, scalars, out_ptrs, mode=BlendedFrame):
+        """The warps of one source period of every member in ONE launch.  scalars[i] / out_ptrs[i]: member i's lists."""
+        n, K = len(self.members), capi.HF_MAX_PERIOD_OUTPUTS
+        counts = (C.c_int * n)(*[len(ts) for ts in scalars])
+        t = (C.c_float * (n * K))()
+        outs = (C.c_void_p * (n * K))()
+        for i, ts in enumerate(scalars):
+            for k, x in enumerate(ts):
+                t[i * K + k] = float(x)
+                outs[i * K + k] = int(out_ptrs[i][k])
+        self._check(self._lib.hf_batch_interpolate_period(self._b, counts, t, outs, int(mode)))
 
     def __len__(self):
         return self._lib.hf_batch_size(self._b)

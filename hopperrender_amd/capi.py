@@ -12,13 +12,10 @@ HF_FLAG_ASYNC = 0x1
 HF_FLAG_NO_GRAPH = 0x2
 HF_FLAG_PROFILE = 0x4
 HF_FLAG_NO_LAZY_ARGMIN = 0x8
-HF_FLAG_SHARED_WARP_STREAM = 0x10
-HF_FLAG_PRIORITY_STREAMS = 0x20
 HF_FLAG_DUAL_STREAM = 0x40
 HF_FLAG_NO_FUSED_WARP = 0x80
-HF_FLAG_WARP_TURNSTILE = 0x100
 HF_FLAG_NO_TIMING = 0x200
-HF_FLAG_DEFER_PREP = 0x400
+HF_MAX_PERIOD_OUTPUTS = 6
 
 (HF_OK, HF_ERR_INVALID_ARGUMENT, HF_ERR_NO_DEVICE, HF_ERR_OUT_OF_MEMORY, HF_ERR_HIP, HF_ERR_STATE) = (0, -1, -2, -3, -4, -5)
 
@@ -51,6 +48,20 @@ class HfProfile(C.Structure):
                 ("copy_ms", C.c_double), ("flow_chains", C.c_uint64), ("flow_ms", C.c_double), ("warp_frames", C.c_uint64)]
 
 
+class HfFilterConfig(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("scene_change_threshold", C.c_int32), ("source_frame_time", C.c_int64),
+                ("target_frame_time", C.c_int64), ("frame_output_mode", C.c_int32), ("auto_adjust", C.c_int32),
+                ("active", C.c_int32), ("reserved", C.c_int32)]
+
+
+class HfFilterState(C.Structure):
+    _fields_ = [("num_int_frames", C.c_int32), ("active", C.c_int32), ("blending_scalar", C.c_double),
+                ("total_warp_duration", C.c_double), ("playback_frame_time", C.c_int64),
+                ("peak_scene_change_delta", C.c_uint32), ("peak_scene_change_delta2", C.c_uint32),
+                ("frame_delta_history", C.c_uint32), ("scene_change_history", C.c_uint32),
+                ("average_frame_delta", C.c_int32), ("scene_change_delta1", C.c_int32), ("scene_change_delta2", C.c_int32)]
+
+
 # name -> (restype, argtypes); must list every symbol include/hopperflow.h declares (tests check this)
 _vp, _i, _f = C.c_void_p, C.c_int, C.c_float
 SIGNATURES = {
@@ -75,6 +86,8 @@ SIGNATURES = {
     "hf_batch_create": (_i, [C.POINTER(_vp), _i, C.POINTER(_vp)]),
     "hf_batch_destroy": (None, [_vp]),
     "hf_batch_calculate_optical_flow": (_i, [_vp]),
+    "hf_batch_update_frames_device_ref": (_i, [_vp, C.POINTER(_vp)]),
+    "hf_batch_interpolate_period": (_i, [_vp, C.POINTER(_i), C.POINTER(C.c_float), C.POINTER(_vp), _i]),
     "hf_batch_size": (_i, [_vp]),
     "hf_batch_last_error": (C.c_char_p, [_vp]),
     "hf_download_frame_device": (_i, [_vp, _vp]),
@@ -96,6 +109,20 @@ SIGNATURES = {
     "hf_memcpy_d2h": (_i, [_i, _vp, _vp, C.c_size_t]),
     "hf_host_malloc_pinned": (_i, [C.c_size_t, C.POINTER(_vp)]),
     "hf_host_free_pinned": (_i, [_vp]),
+    "hf_filter_create": (_i, [C.POINTER(HfFilterConfig), C.POINTER(_vp)]),
+    "hf_filter_destroy": (None, [_vp]),
+    "hf_filter_new_segment": (_i, [_vp, C.c_double]),
+    "hf_filter_set_playback_frame_time": (_i, [_vp, C.c_int64]),
+    "hf_filter_is_active": (_i, [_vp]),
+    "hf_filter_begin_source_frame": (_i, [_vp]),
+    "hf_filter_blending_scalar": (C.c_double, [_vp]),
+    "hf_filter_advance_blending_scalar": (None, [_vp]),
+    "hf_filter_add_warp_duration": (None, [_vp, C.c_double]),
+    "hf_filter_auto_adjust": (_i, [_vp, C.c_double, C.POINTER(C.c_int32)]),
+    "hf_filter_push_frame_delta": (_i, [_vp, C.c_uint32, C.c_uint32]),
+    "hf_filter_detect_scene_change": (_i, [_vp, C.c_uint32]),
+    "hf_filter_get_state": (_i, [_vp, C.POINTER(HfFilterState)]),
+    "hf_filter_deliver": (_i, [_vp, _vp, _vp, C.POINTER(_vp), _i, C.POINTER(_i), C.POINTER(C.c_int32)]),
 }
 
 _lib = None

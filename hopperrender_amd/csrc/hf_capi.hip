@@ -27,6 +27,7 @@
 #include <tuple>
 #include <vector>
 
+#include "../../include/config.h"
 #include "../../include/hopperflow.h"
 #include "hf_kernels.h"
 
@@ -34,30 +35,13 @@ namespace {
 
 thread_local std::string g_create_error;
 
-constexpr int kMinSearchRadius = 5;    // config.h:8
-constexpr int kMaxSearchRadius = 16;   // config.h:9
-constexpr int kCalcTimeInterval = 240; // config.h:17
+constexpr int kMinSearchRadius = MIN_SEARCH_RADIUS;    // include/config.h (reference config.h:8)
+constexpr int kMaxSearchRadius = MAX_SEARCH_RADIUS;    // config.h:9
+constexpr int kCalcTimeInterval = CALC_TIME_INTERVAL;  // config.h:17
+static_assert(kMaxSearchRadius <= 16, "the chain kernels keep 16 candidates per step in registers");
 constexpr int kMaxSteps = 32;          // 2 * log2(max window)
 
-// HF_FLAG_SHARED_WARP_STREAM: one stream per device on which the (bandwidth-bound) warp kernels of all
-// contexts of this process are issued, so they run one after the other at full rate while the
-// latency-bound refinement chains of the other contexts fill the gaps on their own streams.
-std::mutex g_warp_stream_mutex;
-std::map<int, hipStream_t> g_warp_streams;
-hipStream_t shared_warp_stream(int device) {
-    std::lock_guard<std::mutex> lock(g_warp_stream_mutex);
-    auto it = g_warp_streams.find(device);
-    if (it != g_warp_streams.end()) return it->second;
-    hipStream_t s = nullptr;
-    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
-    g_warp_streams[device] = s;
-    return s;
-}
-
-// HF_FLAG_WARP_TURNSTILE: the event behind the most recently issued warp launch of any such context, per device
 std::shared_mutex g_capture_mutex;   // shared: a stream capture is in progress; exclusive: a legacy-stream copy (util_copy)
-std::mutex g_turnstile_mutex;
-std::map<int, hipEvent_t> g_turnstile_last;
 
 }  // namespace
 
@@ -67,10 +51,10 @@ struct hf_ctx {
     int device = 0;
     hipStream_t stream = nullptr;                      // stream the context issues on (a batch's shared stream while it is a member)
     hipStream_t own_stream = nullptr;                  // the stream this context created and destroys
-    hipStream_t warp_stream = nullptr;                 // == stream unless HF_FLAG_SHARED_WARP_STREAM / HF_FLAG_PRIORITY_STREAMS
-    hipStream_t own_warp_stream = nullptr;             // HF_FLAG_PRIORITY_STREAMS: this context's low-priority warp stream
+    hipStream_t warp_stream = nullptr;                 // == stream unless HF_FLAG_DUAL_STREAM
+    hipStream_t own_warp_stream = nullptr;             // HF_FLAG_DUAL_STREAM: this context's second stream
     hipEvent_t ev_chain_done = nullptr, ev_warps_done = nullptr;
-    hipEvent_t ev_turn = nullptr;                      // HF_FLAG_WARP_TURNSTILE: recorded behind this context's warp launches
+    struct hf_batch* batch = nullptr;                  // the batch this context is a member of
     hipEvent_t ev_flow[2] = {nullptr, nullptr};        // recorded behind the chain that wrote blurred[i] (swapped with it)
     bool ev_flow_valid[2] = {false, false};
     bool dual() const { return (cfg.flags & HF_FLAG_DUAL_STREAM) != 0; }
@@ -351,17 +335,19 @@ void collect_spans(hf_ctx* c) {  // stream must be idle
     c->spans.clear();
 }
 
-// Warp/copy launches go to c->warp_stream.  With a shared warp stream the two streams are tied together by
-// events: the warp stream waits for everything enqueued on c->stream so far, and leave_warp_stream() makes
-// c->stream wait for the warps again, so every other call keeps its plain in-order semantics.
+// Warp launches go to c->warp_stream (HF_FLAG_DUAL_STREAM: a second stream).  The two streams are tied together by
+// events: the warp stream waits for what the warps read, and leave_warp_stream() makes c->stream wait for the warps
+// again, so every other call keeps its plain in-order semantics.
 int enter_warp_stream(hf_ctx* c) {
     if (c->warp_stream == c->stream || c->on_warp_stream) return HF_OK;
-    if (c->dual()) {
+    if (c->dual() && c->ev_flow_valid[0]) {
         // warpFrames reads frames N-2/N-1 and the PREVIOUS flow (blurred[0]); the chain that may have just been
         // enqueued on c->stream writes the OTHER flow buffer, so the warps only wait for the chain that produced
-        // blurred[0] and run side by side with the current one
-        if (c->ev_flow_valid[0]) HF_HIP(c, hipStreamWaitEvent(c->warp_stream, c->ev_flow[0], 0));
+        // blurred[0] (recorded behind the uploads of both frames) and run side by side with the current one
+        HF_HIP(c, hipStreamWaitEvent(c->warp_stream, c->ev_flow[0], 0));
     } else {
+        // no tagged flow yet (the filter warps as soon as m_frameCount >= 3, before a second flow calculation):
+        // order the warps behind everything enqueued so far, uploads included
         HF_HIP(c, hipEventRecord(c->ev_chain_done, c->stream));
         HF_HIP(c, hipStreamWaitEvent(c->warp_stream, c->ev_chain_done, 0));
     }
@@ -370,28 +356,9 @@ int enter_warp_stream(hf_ctx* c) {
 }
 int leave_warp_stream(hf_ctx* c) {
     if (!c->on_warp_stream) return HF_OK;
-    // ev_warps_done was recorded right behind this context's last warp launch (not here: by now other
-    // contexts have queued their warps on the shared stream and we must not wait for those)
+    // ev_warps_done was recorded right behind this context's last warp launch
     HF_HIP(c, hipStreamWaitEvent(c->stream, c->ev_warps_done, 0));
     c->on_warp_stream = false;
-    return HF_OK;
-}
-
-// HF_FLAG_WARP_TURNSTILE: wait for the previously issued warp launch (of any context on this device) ...
-int turnstile_enter(hf_ctx* c) {
-    if (!(c->cfg.flags & HF_FLAG_WARP_TURNSTILE)) return HF_OK;
-    std::lock_guard<std::mutex> lock(g_turnstile_mutex);
-    auto it = g_turnstile_last.find(c->device);
-    if (it != g_turnstile_last.end() && it->second && it->second != c->ev_turn)   // our own last launch is ordered by the stream
-        HF_HIP(c, hipStreamWaitEvent(c->warp_stream, it->second, 0));
-    return HF_OK;
-}
-// ... and publish this context's launches as the ones to wait for
-int turnstile_leave(hf_ctx* c) {
-    if (!(c->cfg.flags & HF_FLAG_WARP_TURNSTILE)) return HF_OK;
-    std::lock_guard<std::mutex> lock(g_turnstile_mutex);
-    HF_HIP(c, hipEventRecord(c->ev_turn, c->warp_stream));
-    g_turnstile_last[c->device] = c->ev_turn;
     return HF_OK;
 }
 
@@ -436,10 +403,10 @@ int io_init(hf_ctx* c) {
 }
 
 // Before a warp/copy writes into an output-ring slot: wait for the asynchronous readback that still uses it.
-int guard_output_slot(hf_ctx* c, hipStream_t launch_stream) {
+int guard_output_slot(hf_ctx* c, const void* target, hipStream_t launch_stream) {
     if (!c->io_out) return HF_OK;
     for (int i = 0; i < hf_ctx::kOutRing; i++)
-        if (c->out_target == c->out_ring[i] && c->d2h_pending[i]) {
+        if (target == c->out_ring[i] && c->d2h_pending[i]) {
             HF_HIP(c, hipStreamWaitEvent(launch_stream, c->ev_d2h[i], 0));
             c->d2h_pending[i] = false;
         }
@@ -501,6 +468,16 @@ int hf_create(const hf_config* cfg, hf_ctx** out_ctx) {
         return fail(nullptr, HF_ERR_NO_DEVICE, "Error in function detectDevices: no HIP device available");
     if (cfg->device_index < 0 || cfg->device_index >= ndev)
         return fail(nullptr, HF_ERR_NO_DEVICE, "Error in function detectDevices: device %d of %d", cfg->device_index, ndev);
+    {   // detectDevices (opticalFlowCalc.cpp:48-55,88-89): the device must offer the memory, LDS and workgroup size the
+        // calculator needs.  The reference prices 9 H S_in + 3 H S_out (HDR worst case) + offset / sum arrays; this build
+        // keeps 3 frames + 3 phase planes + 1 output frame + small tables, priced exactly below once the geometry is known.
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, cfg->device_index) != hipSuccess)
+            return fail(nullptr, HF_ERR_NO_DEVICE, "Error in function detectDevices: cannot query device %d", cfg->device_index);
+        if (prop.maxThreadsPerBlock < 256 || prop.sharedMemPerBlock < 2048 || prop.warpSize != 64)
+            return fail(nullptr, HF_ERR_NO_DEVICE, "Error in function detectDevices: device %d (%s) lacks 256-thread workgroups, 2 KB of LDS or 64-wide wavefronts",
+                        cfg->device_index, prop.name);
+    }
 
     hf_ctx* c = new (std::nothrow) hf_ctx();
     if (!c) return fail(nullptr, HF_ERR_OUT_OF_MEMORY, "hf_create: host allocation failed");
@@ -558,33 +535,29 @@ int hf_create(const hf_config* cfg, hf_ctx** out_ctx) {
     int rc = HF_OK;
     auto bail = [&](int code) { std::string e = c->err; hf_destroy(c); g_create_error = e; return code; };
     if ((rc = set_device(c))) return bail(rc);
+    {   // detectDevices, memory half (opticalFlowCalc.cpp:39-43,88: requiredVRAM vs CL_DEVICE_GLOBAL_MEM_SIZE)
+        const size_t required = 3 * c->in_bytes + 3 * c->pl.bytes + c->out_bytes + c->tables_bytes + c->sums_bytes +
+                                2 * c->plane_elems * sizeof(int16_t) * 3 + 2 * c->plane_elems * sizeof(uint32_t);
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < required) {
+            fail(c, HF_ERR_NO_DEVICE, "Error in function detectDevices: not enough VRAM available! Required: %zu MB, Available: %zu MB",
+                 required / 1024 / 1024, free_b / 1024 / 1024);
+            return bail(HF_ERR_NO_DEVICE);
+        }
+    }
 #define HF_TRY(call) do { hipError_t _e = (call); if (_e != hipSuccess) { \
         fail(c, _e == hipErrorOutOfMemory ? HF_ERR_OUT_OF_MEMORY : HF_ERR_HIP, "HIP error %d (%s) in %s", (int)_e, hipGetErrorString(_e), #call); \
         return bail(_e == hipErrorOutOfMemory ? HF_ERR_OUT_OF_MEMORY : HF_ERR_HIP); } } while (0)
+    HF_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     if (cfg->flags & HF_FLAG_DUAL_STREAM) {
-        HF_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         HF_TRY(hipStreamCreateWithFlags(&c->own_warp_stream, hipStreamNonBlocking));
         HF_TRY(hipEventCreateWithFlags(&c->ev_flow[0], hipEventDisableTiming));
         HF_TRY(hipEventCreateWithFlags(&c->ev_flow[1], hipEventDisableTiming));
-    } else if (cfg->flags & HF_FLAG_PRIORITY_STREAMS) {
-        // latency-bound chain on a high-priority stream, bandwidth-bound warps on a low-priority one: when
-        // several contexts share a GPU the short chain kernels are not starved by other contexts' warps
-        int lo = 0, hi = 0;
-        HF_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));   // lo = least priority (numerically greatest)
-        HF_TRY(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi));
-        HF_TRY(hipStreamCreateWithPriority(&c->own_warp_stream, hipStreamNonBlocking, lo));
-    } else {
-        HF_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     }
     c->own_stream = c->stream;
     c->warp_stream = c->own_warp_stream ? c->own_warp_stream : c->stream;
-    if (cfg->flags & HF_FLAG_SHARED_WARP_STREAM) {
-        c->warp_stream = shared_warp_stream(c->device);
-        if (!c->warp_stream) { fail(c, HF_ERR_HIP, "cannot create the shared warp stream"); return bail(HF_ERR_HIP); }
-    }
     HF_TRY(hipEventCreateWithFlags(&c->ev_chain_done, hipEventDisableTiming));
     HF_TRY(hipEventCreateWithFlags(&c->ev_warps_done, hipEventDisableTiming));
-    HF_TRY(hipEventCreateWithFlags(&c->ev_turn, hipEventDisableTiming));
     for (int i = 0; i < 3; i++) {
         HF_TRY(hipMalloc(&c->ring_store[i], c->in_bytes));
         c->ring[i] = c->ring_store[i];
@@ -654,12 +627,6 @@ void hf_destroy(hf_ctx* c) {
     for (hipEvent_t e : c->ev_flow) if (e) hipEventDestroy(e);
     if (c->ev_chain_done) hipEventDestroy(c->ev_chain_done);
     if (c->ev_warps_done) hipEventDestroy(c->ev_warps_done);
-    if (c->ev_turn) {
-        std::lock_guard<std::mutex> lock(g_turnstile_mutex);
-        auto it = g_turnstile_last.find(c->device);
-        if (it != g_turnstile_last.end() && it->second == c->ev_turn) it->second = nullptr;   // the stream was drained above
-        hipEventDestroy(c->ev_turn);
-    }
     hipEvent_t evs[] = {c->ev_upload, c->ev_flow_end, c->ev_warp_start, c->ev_warp_end, c->ev_user0, c->ev_user1};
     for (hipEvent_t e : evs) if (e) hipEventDestroy(e);
     if (c->own_warp_stream) hipStreamDestroy(c->own_warp_stream);
@@ -682,6 +649,7 @@ int hf_update_frame_device(hf_ctx* c, const void* device_frame) {
 int hf_update_frame_async(hf_ctx* c, const void* pinned_host_frame) {
     HF_CHECK_CTX(c);
     if (!pinned_host_frame) return fail(c, HF_ERR_INVALID_ARGUMENT, "hf_update_frame_async: null frame");
+    if (c->batch) return fail(c, HF_ERR_STATE, "hf_update_frame_async: the context is a member of a batch (asynchronous host I/O uses side streams of its own)");
     if (int rc = set_device(c)) return rc;
     if (int rc = io_init(c)) return rc;
     // the slot about to be overwritten holds the oldest frame: its last readers are the warp/copy launches
@@ -707,6 +675,7 @@ int hf_update_frame_async(hf_ctx* c, const void* pinned_host_frame) {
 int hf_download_frame_async(hf_ctx* c, void* pinned_host_out) {
     HF_CHECK_CTX(c);
     if (!pinned_host_out) return fail(c, HF_ERR_INVALID_ARGUMENT, "hf_download_frame_async: null buffer");
+    if (c->batch) return fail(c, HF_ERR_STATE, "hf_download_frame_async: the context is a member of a batch (asynchronous host I/O uses side streams of its own)");
     if (int rc = set_device(c)) return rc;
     if (int rc = io_init(c)) return rc;
     hipStream_t last = c->on_warp_stream ? c->warp_stream : c->stream;   // where the frame was just produced
@@ -809,7 +778,7 @@ int hf_calculate_optical_flow(hf_ctx* c) {
     return HF_OK;
 }
 
-// ---- batched flow calculation (throughput drivers; include/hopperflow.h) ----
+// ---- batches (throughput drivers; include/hopperflow.h) ----
 struct hf_batch {
     std::vector<hf_ctx*> members;
     std::vector<hipStream_t> own_streams;   // the members' own streams, restored by hf_batch_destroy
@@ -820,7 +789,7 @@ struct hf_batch {
     std::string err;
 };
 
-static std::string g_batch_error;
+static thread_local std::string g_batch_error;
 static int batch_fail(hf_batch* b, int code, const std::string& msg) {
     (b ? b->err : g_batch_error) = "[HopperRender] " + msg;
     return code;
@@ -837,23 +806,25 @@ int hf_batch_create(hf_ctx* const* members, int n, hf_batch** out) {
         hf_ctx* m = members[i];
         if (!m) return batch_fail(nullptr, HF_ERR_INVALID_ARGUMENT, "hf_batch_create: null member");
         for (int j = 0; j < i; j++) if (members[j] == m) return batch_fail(nullptr, HF_ERR_INVALID_ARGUMENT, "hf_batch_create: duplicate member");
+        if (m->batch) return batch_fail(nullptr, HF_ERR_STATE, "hf_batch_create: member " + std::to_string(i) + " already belongs to a batch");
         const hf::Geom &a = l->g, &b = m->g;
         const bool same = a.hdr == b.hdr && a.H == b.H && a.W == b.W && a.in_stride == b.in_stride && a.out_stride == b.out_stride &&
                           a.rs == b.rs && m->device == l->device && m->cfg.iterations == l->cfg.iterations &&
                           m->cfg.blur_radius == l->cfg.blur_radius;
         if (!same) return batch_fail(nullptr, HF_ERR_INVALID_ARGUMENT, "hf_batch_create: members differ in geometry, device, iterations or blur radius");
-        if (!m->async() || (m->warp_stream != m->stream && !m->dual()) || m->io_in || m->dual() != l->dual())
+        if (!m->async() || m->io_in || m->dual() != l->dual())
             return batch_fail(nullptr, HF_ERR_INVALID_ARGUMENT, "hf_batch_create: members must be HF_FLAG_ASYNC contexts (all single-stream or all HF_FLAG_DUAL_STREAM) without async host I/O");
     }
     if (hipSetDevice(l->device) != hipSuccess) return batch_fail(nullptr, HF_ERR_HIP, "hf_batch_create: hipSetDevice failed");
+    for (int i = 0; i < n; i++)   // before any member is touched: a failure leaves every context as it was
+        if (int rc = sync_ctx(members[i])) return batch_fail(nullptr, rc, "hf_batch_create: member sync failed: " + members[i]->err);
     hf_batch* b = new (std::nothrow) hf_batch();
     if (!b) return batch_fail(nullptr, HF_ERR_OUT_OF_MEMORY, "hf_batch_create: host allocation failed");
     b->stream = l->stream;
     if (l->dual()) {
         // the members' warps go to a few shared streams (round robin) instead of one stream per member: the device
         // runs only a handful of hardware queues side by side (DESIGN.md "Hardware queues")
-        static const int ws_env = getenv("HF_BATCH_WARP_STREAMS") ? atoi(getenv("HF_BATCH_WARP_STREAMS")) : 0;
-        const int nws = ws_env > 0 ? ws_env : (n < 3 ? n : 3);
+        const int nws = n < 3 ? n : 3;
         for (int i = 0; i < nws; i++) {
             hipStream_t ws = nullptr;
             if (hipStreamCreateWithFlags(&ws, hipStreamNonBlocking) != hipSuccess) {
@@ -866,7 +837,6 @@ int hf_batch_create(hf_ctx* const* members, int n, hf_batch** out) {
     }
     for (int i = 0; i < n; i++) {
         hf_ctx* m = members[i];
-        if (int rc = sync_ctx(m)) { delete b; return batch_fail(nullptr, rc, "hf_batch_create: member sync failed"); }
         b->members.push_back(m);
         b->own_streams.push_back(m->stream);
         b->own_warp_streams.push_back(m->warp_stream);
@@ -875,6 +845,7 @@ int hf_batch_create(hf_ctx* const* members, int n, hf_batch** out) {
         m->graphs.clear();
         m->stream = b->stream;
         m->warp_stream = m->dual() ? b->warp_streams[(size_t)i % b->warp_streams.size()] : b->stream;
+        m->batch = b;
     }
     *out = b;
     return HF_OK;
@@ -894,9 +865,36 @@ void hf_batch_destroy(hf_batch* b) {
         m->stream = b->own_streams[i];
         m->warp_stream = b->own_warp_streams[i];
         m->on_warp_stream = false;
+        m->batch = nullptr;
     }
     for (hipStream_t ws : b->warp_streams) hipStreamDestroy(ws);
     delete b;
+}
+
+int hf_batch_update_frames_device_ref(hf_batch* b, const void* const* device_frames) {
+    if (!b) return batch_fail(nullptr, HF_ERR_INVALID_ARGUMENT, "null batch");
+    if (!device_frames) return batch_fail(b, HF_ERR_INVALID_ARGUMENT, "hf_batch_update_frames_device_ref: null argument");
+    hf_ctx* l = b->members[0];
+    const int n = (int)b->members.size();
+    if (hipSetDevice(l->device) != hipSuccess) return batch_fail(b, HF_ERR_HIP, "hipSetDevice failed");
+    hf::PrepBatch pb{};
+    pb.n = n;
+    for (int i = 0; i < n; i++) {
+        hf_ctx* m = b->members[i];
+        if (!device_frames[i]) return batch_fail(b, HF_ERR_INVALID_ARGUMENT, "hf_batch_update_frames_device_ref: null frame");
+        if (int rc = leave_warp_stream(m)) return batch_fail(b, rc, m->err);
+        if (m->timing()) {
+            if (hipEventRecord(m->ev_upload, b->stream) != hipSuccess) return batch_fail(b, HF_ERR_HIP, "hipEventRecord failed");
+            m->upload_recorded = true;
+        }
+        m->ring[0] = const_cast<void*>(device_frames[i]);   // the ring references the caller's frame (hf_update_frame_device_ref)
+        pb.frame[i] = m->ring[0];
+        pb.pp[i] = m->pp[0];
+    }
+    hf::launch_prep_frames(l->g, l->pl, pb, b->stream);     // the phase planes of all new frames in one launch
+    if (hipGetLastError() != hipSuccess) return batch_fail(b, HF_ERR_HIP, "phase-plane launch failed");
+    for (hf_ctx* m : b->members) rotate_after_upload(m);
+    return HF_OK;
 }
 
 int hf_batch_calculate_optical_flow(hf_batch* b) {
@@ -950,8 +948,7 @@ int hf_warp_frames(hf_ctx* c, float t, int mode) {
     const float scale = c->g.hdr ? 256.0f : 1.0f;  // opticalFlowCalcHDR.cpp:151-152
     if (!c->warp_started && c->timing()) { HF_HIP(c, hipEventRecord(c->ev_warp_start, c->stream)); c->warp_started = true; }
     if (int rc = enter_warp_stream(c)) return rc;
-    if (int rc = guard_output_slot(c, c->warp_stream)) return rc;
-    if (!c->in_period) if (int rc = turnstile_enter(c)) return rc;
+    if (int rc = guard_output_slot(c, c->out_target, c->warp_stream)) return rc;
     // frames N-2 / N-1 and the PREVIOUS flow (:154-156)
     // profiled launches carry start/stop events of the dispatch itself (hipExtLaunchKernel), i.e. the kernel's
     // execution time as rocprof reports it, not the time the launch spent queued behind other streams
@@ -960,7 +957,6 @@ int hf_warp_frames(hf_ctx* c, float t, int mode) {
                     c->p.black_level * scale, c->p.white_level * scale, c->warp_stream,
                     span >= 0 ? c->spans[span].b : nullptr, span >= 0 ? c->spans[span].e : nullptr);
     if (c->on_warp_stream && !c->in_period) HF_HIP(c, hipEventRecord(c->ev_warps_done, c->warp_stream));
-    if (!c->in_period) if (int rc = turnstile_leave(c)) return rc;
     if (int rc = note_launch(c, c->warp_stream)) return rc;
     HF_HIP(c, hipGetLastError());
     return HF_OK;
@@ -973,7 +969,7 @@ int hf_copy_frame(hf_ctx* c) {
     const int idx = c->p.frame_count >= 3 ? 0 : c->p.frame_count >= 2 ? 1 : 2;  // opticalFlowCalcSDR.cpp:173
     if (int rc = leave_warp_stream(c)) return rc;
     if (!c->warp_started && c->timing()) { HF_HIP(c, hipEventRecord(c->ev_warp_start, c->stream)); c->warp_started = true; }
-    if (int rc = guard_output_slot(c, c->stream)) return rc;
+    if (int rc = guard_output_slot(c, c->out_target, c->stream)) return rc;
     const int span = span_begin(c, 1);
     hf::launch_copy(c->g, c->ring[idx], c->out_target, c->p.black_level * scale, c->p.white_level * scale, c->stream);
     span_end(c, span);
@@ -983,6 +979,16 @@ int hf_copy_frame(hf_ctx* c) {
 
 int hf_interpolate_period(hf_ctx* c, const void* device_frame, int n_out, const float* t, void* const* device_out, int mode) {
     return hf_interpolate_period_ex(c, device_frame, n_out, t, device_out, mode, 1);
+}
+
+// Fills the period descriptor of one context: frames N-2 / N-1, the PREVIOUS flow (:154-156), levels, outputs.
+static void fill_period(hf_ctx* c, int n, const float* t, void* const* outs, hf::WarpPeriod& p) {
+    const float scale = c->g.hdr ? 256.0f : 1.0f;
+    p.frame12 = c->ring[0]; p.frame21 = c->ring[1];
+    p.flow = c->blurred[0]; p.flow_xy = c->blurred_xy[0];
+    p.black = c->p.black_level * scale; p.white = c->p.white_level * scale;
+    p.n_out = n;
+    for (int i = 0; i < n; i++) { p.ts[i] = t[i]; p.outs[i] = outs[i] ? outs[i] : c->out_frame; }
 }
 
 int hf_interpolate_period_ex(hf_ctx* c, const void* device_frame, int n_out, const float* t, void* const* device_out, int mode,
@@ -1002,18 +1008,16 @@ int hf_interpolate_period_ex(hf_ctx* c, const void* device_frame, int n_out, con
     const bool fuse = n_out >= 2 && !(c->cfg.flags & HF_FLAG_NO_FUSED_WARP);
     int done = 0;
     if (fuse) {
-        const float scale = c->g.hdr ? 256.0f : 1.0f;
         if (int rc = enter_warp_stream(c)) return rc;
-        if (int rc = turnstile_enter(c)) return rc;
         while (done < n_out) {
             const int n = n_out - done < hf::kMaxWarpOutputs ? n_out - done : hf::kMaxWarpOutputs;
-            void* outs[hf::kMaxWarpOutputs];
-            for (int i = 0; i < n; i++) outs[i] = device_out[done + i] ? device_out[done + i] : c->out_frame;
+            hf::WarpPeriod p;
+            fill_period(c, n, t + done, device_out + done, p);
+            for (int i = 0; i < n; i++) if (int rc = guard_output_slot(c, p.outs[i], c->warp_stream)) return rc;
             if (!c->warp_started && c->timing()) { HF_HIP(c, hipEventRecord(c->ev_warp_start, c->stream)); c->warp_started = true; }
             const int span = span_open(c, 0);
-            const bool ok = hf::launch_warp_period(c->g, c->ring[0], c->ring[1], c->blurred[0], c->blurred_xy[0], n, outs, t + done, mode,
-                                                   c->p.black_level * scale, c->p.white_level * scale, c->warp_stream,
-                                                   span >= 0 ? c->spans[span].b : nullptr, span >= 0 ? c->spans[span].e : nullptr);
+            const bool ok = hf::launch_warp_periods(c->g, 1, &p, mode, c->warp_stream,
+                                                    span >= 0 ? c->spans[span].b : nullptr, span >= 0 ? c->spans[span].e : nullptr);
             if (!ok) {   // shape not eligible: drop the unused span and fall back to one launch per output
                 if (span >= 0) { c->ev_pool.push_back(c->spans[span].b); c->ev_pool.push_back(c->spans[span].e); c->spans.pop_back(); }
                 break;
@@ -1022,7 +1026,6 @@ int hf_interpolate_period_ex(hf_ctx* c, const void* device_frame, int n_out, con
             HF_HIP(c, hipGetLastError());
             done += n;
         }
-        if (int rc = turnstile_leave(c)) return rc;
         if (done > 0) {
             if (c->on_warp_stream) HF_HIP(c, hipEventRecord(c->ev_warps_done, c->warp_stream));
             if (int rc = note_launch(c, c->warp_stream)) return rc;
@@ -1039,6 +1042,39 @@ int hf_interpolate_period_ex(hf_ctx* c, const void* device_frame, int n_out, con
     c->out_target = saved;
     if (rc == HF_OK && done < n_out && c->on_warp_stream) HF_HIP(c, hipEventRecord(c->ev_warps_done, c->warp_stream));
     return rc;
+}
+
+int hf_batch_interpolate_period(hf_batch* b, const int* n_out, const float* t, void* const* device_out, int mode) {
+    if (!b) return batch_fail(nullptr, HF_ERR_INVALID_ARGUMENT, "null batch");
+    if (!n_out || !t || !device_out) return batch_fail(b, HF_ERR_INVALID_ARGUMENT, "hf_batch_interpolate_period: null argument");
+    if (mode < 0 || mode > 6) return batch_fail(b, HF_ERR_INVALID_ARGUMENT, "warpFrames: frame output mode outside [0, 6]");
+    hf_ctx* l = b->members[0];
+    const int n = (int)b->members.size();
+    if (hipSetDevice(l->device) != hipSuccess) return batch_fail(b, HF_ERR_HIP, "hipSetDevice failed");
+    bool one_launch = !l->dual() && !(l->cfg.flags & HF_FLAG_NO_FUSED_WARP);
+    for (int m = 0; m < n; m++) {
+        if (n_out[m] < 0 || n_out[m] > HF_MAX_PERIOD_OUTPUTS) return batch_fail(b, HF_ERR_INVALID_ARGUMENT, "hf_batch_interpolate_period: n_out outside [0, 6]");
+        for (int i = 0; i < n_out[m]; i++)
+            if (t[m * HF_MAX_PERIOD_OUTPUTS + i] > 1.0f)
+                return batch_fail(b, HF_ERR_INVALID_ARGUMENT, "Error in function warpFrames: blending scalar is greater than 1.0");
+        one_launch = one_launch && n_out[m] >= 1;
+    }
+    if (one_launch) {
+        // every member's period in ONE launch on the batch stream (single-stream members: program order does the rest)
+        hf::WarpPeriod periods[hf::kMaxFlowBatch];
+        for (int m = 0; m < n; m++) fill_period(b->members[m], n_out[m], t + m * HF_MAX_PERIOD_OUTPUTS, device_out + m * HF_MAX_PERIOD_OUTPUTS, periods[m]);
+        const int span = span_open(l, 0);
+        if (hf::launch_warp_periods(l->g, n, periods, mode, b->stream, span >= 0 ? l->spans[span].b : nullptr, span >= 0 ? l->spans[span].e : nullptr)) {
+            if (span >= 0) { int f = 0; for (int m = 0; m < n; m++) f += n_out[m]; l->spans[span].frames = f; }
+            if (hipGetLastError() != hipSuccess) return batch_fail(b, HF_ERR_HIP, "fused warp launch failed");
+            return HF_OK;
+        }
+        if (span >= 0) { l->ev_pool.push_back(l->spans[span].b); l->ev_pool.push_back(l->spans[span].e); l->spans.pop_back(); }
+    }
+    for (int m = 0; m < n; m++)   // not eligible (diagnostic modes, odd shapes, dual-stream members): member by member
+        if (int rc = hf_interpolate_period_ex(b->members[m], nullptr, n_out[m], t + m * HF_MAX_PERIOD_OUTPUTS, device_out + m * HF_MAX_PERIOD_OUTPUTS, mode, 0))
+            return batch_fail(b, rc, b->members[m]->err);
+    return HF_OK;
 }
 
 static int download_common(hf_ctx* c, void* dst, hipMemcpyKind kind) {

@@ -58,8 +58,9 @@ __device__ __forceinline__ uint32_t pack_element(uint32_t ya, uint32_t yb, uint3
 // read once with coalesced 16-byte loads, reduced to their top 8 bits in LDS, and written back as nph2 phase rows
 // including the mirrored margins.
 template <typename E>
-__global__ __launch_bounds__(256) void prep_phase_kernel(const E* __restrict__ f, uint32_t* __restrict__ pp, int H, int W, int S,
-                                                          PhaseLayout pl) {
+__global__ __launch_bounds__(256) void prep_phase_kernel(const PrepBatch batch, int H, int W, int S, PhaseLayout pl) {
+    const E* __restrict__ f = (const E*)batch.frame[blockIdx.y];     // blockIdx.y: frame of the batch
+    uint32_t* __restrict__ pp = batch.pp[blockIdx.y];
     extern __shared__ __attribute__((aligned(16))) uint8_t row8[];   // [2][Wp]: top 8 bits of the luma row, of the chroma row
     constexpr int VEC = 16 / sizeof(E);
     const int Wp = ((W + 15) / 16) * 16;
@@ -101,8 +102,9 @@ __global__ __launch_bounds__(256) void prep_phase_kernel(const E* __restrict__ f
 // thread whose columns lie within `mx` of an edge also stores its elements, columns reversed, into the margin.
 // Requires W == lw << RS, lw % 4 == 0, mx <= lw and 16-byte aligned rows (else: prep_phase_kernel).
 template <typename E, int RS>
-__global__ __launch_bounds__(128) void prep_phase_fast_kernel(const E* __restrict__ f, uint32_t* __restrict__ pp, int H, int W, int S,
-                                                               PhaseLayout pl) {
+__global__ __launch_bounds__(128) void prep_phase_fast_kernel(const PrepBatch batch, int H, int W, int S, PhaseLayout pl) {
+    const E* __restrict__ f = (const E*)batch.frame[blockIdx.z];     // blockIdx.z: frame of the batch
+    uint32_t* __restrict__ pp = batch.pp[blockIdx.z];
     constexpr int NPH = 1 << RS, NE = 4 << RS;               // phases, elements per thread and row
     constexpr int NPH2 = NPH > 1 ? NPH / 2 : 1;
     const int m = blockIdx.y;                                // chroma row = pair of luma rows
@@ -635,29 +637,35 @@ PhaseLayout make_phase_layout(const Geom& g, int max_iterations) {
 }
 
 template <typename E>
-static bool launch_prep_fast(const Geom& g, const PhaseLayout& pl, const void* frame, uint32_t* pp, hipStream_t stream) {
+static bool launch_prep_fast(const Geom& g, const PhaseLayout& pl, const PrepBatch& b, hipStream_t stream) {
     const int lw = g.W >> g.rs;
     const size_t row_bytes = (size_t)g.in_stride * sizeof(E);
-    if ((lw << g.rs) != g.W || lw != g.lw || (lw & 3) || pl.mx > lw || (pl.mx & 3) || (row_bytes & 15) || (((uintptr_t)frame) & 15) ||
-        (pl.lwp & 3) || g.rs > 4 || (g.H & 1))
+    if ((lw << g.rs) != g.W || lw != g.lw || (lw & 3) || pl.mx > lw || (pl.mx & 3) || (row_bytes & 15) || (pl.lwp & 3) || g.rs > 4 || (g.H & 1))
         return false;
-    const dim3 grd((lw / 4 + 127) / 128, g.H / 2);
-    const E* f = (const E*)frame;
+    for (int i = 0; i < b.n; i++) if (((uintptr_t)b.frame[i]) & 15) return false;
+    const dim3 grd((lw / 4 + 127) / 128, g.H / 2, b.n);
     switch (g.rs) {
-        case 0: prep_phase_fast_kernel<E, 0><<<grd, 128, 0, stream>>>(f, pp, g.H, g.W, g.in_stride, pl); break;
-        case 1: prep_phase_fast_kernel<E, 1><<<grd, 128, 0, stream>>>(f, pp, g.H, g.W, g.in_stride, pl); break;
-        case 2: prep_phase_fast_kernel<E, 2><<<grd, 128, 0, stream>>>(f, pp, g.H, g.W, g.in_stride, pl); break;
-        case 3: prep_phase_fast_kernel<E, 3><<<grd, 128, 0, stream>>>(f, pp, g.H, g.W, g.in_stride, pl); break;
-        default: prep_phase_fast_kernel<E, 4><<<grd, 128, 0, stream>>>(f, pp, g.H, g.W, g.in_stride, pl); break;
+        case 0: prep_phase_fast_kernel<E, 0><<<grd, 128, 0, stream>>>(b, g.H, g.W, g.in_stride, pl); break;
+        case 1: prep_phase_fast_kernel<E, 1><<<grd, 128, 0, stream>>>(b, g.H, g.W, g.in_stride, pl); break;
+        case 2: prep_phase_fast_kernel<E, 2><<<grd, 128, 0, stream>>>(b, g.H, g.W, g.in_stride, pl); break;
+        case 3: prep_phase_fast_kernel<E, 3><<<grd, 128, 0, stream>>>(b, g.H, g.W, g.in_stride, pl); break;
+        default: prep_phase_fast_kernel<E, 4><<<grd, 128, 0, stream>>>(b, g.H, g.W, g.in_stride, pl); break;
     }
     return true;
 }
 
-void launch_prep_frame(const Geom& g, const PhaseLayout& pl, const void* frame, uint32_t* pp, hipStream_t stream) {
-    if (g.hdr ? launch_prep_fast<uint16_t>(g, pl, frame, pp, stream) : launch_prep_fast<uint8_t>(g, pl, frame, pp, stream)) return;
+void launch_prep_frames(const Geom& g, const PhaseLayout& pl, const PrepBatch& b, hipStream_t stream) {
+    if (g.hdr ? launch_prep_fast<uint16_t>(g, pl, b, stream) : launch_prep_fast<uint8_t>(g, pl, b, stream)) return;
     const size_t smem = 2 * (size_t)((g.W + 15) / 16) * 16;
-    if (g.hdr) prep_phase_kernel<uint16_t><<<g.H, 256, smem, stream>>>((const uint16_t*)frame, pp, g.H, g.W, g.in_stride, pl);
-    else prep_phase_kernel<uint8_t><<<g.H, 256, smem, stream>>>((const uint8_t*)frame, pp, g.H, g.W, g.in_stride, pl);
+    const dim3 grd(g.H, b.n);
+    if (g.hdr) prep_phase_kernel<uint16_t><<<grd, 256, smem, stream>>>(b, g.H, g.W, g.in_stride, pl);
+    else prep_phase_kernel<uint8_t><<<grd, 256, smem, stream>>>(b, g.H, g.W, g.in_stride, pl);
+}
+
+void launch_prep_frame(const Geom& g, const PhaseLayout& pl, const void* frame, uint32_t* pp, hipStream_t stream) {
+    PrepBatch b{};
+    b.n = 1; b.frame[0] = frame; b.pp[0] = pp;
+    launch_prep_frames(g, pl, b, stream);
 }
 
 void launch_flow_level_small(const Geom& g, const FlowBatch& b, hipStream_t stream) {

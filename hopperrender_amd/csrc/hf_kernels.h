@@ -19,6 +19,9 @@ struct Geom {
     int lw, lh;          // low-res grid
 };
 
+constexpr int kMaxFlowBatch = 8;       // contexts per hf_batch (FlowBatch below)
+constexpr int kMaxWarpOutputs = 6;     // outputs of one source period at 24 -> 120 fps (HopperRender.cpp:944-948)
+
 // Phase-plane layout of a frame (hf_flow.hip).  ONE plane of 4-byte elements, one element per grid column, per pair of
 // luma phases and per full-resolution luma row:
 //     PP[y][ph2][j] = Y[y][x] | Y[y][x + 1] << 8 | U[y >> 1][x & ~1] << 16 | V[y >> 1][x & ~1] << 24      (top 8 bits each)
@@ -80,7 +83,6 @@ struct FlowStep {
 // 480x270 chain is 135..1080 workgroups of latency-bound work per launch -- far too little for 256 CUs -- and
 // the device runs at most a handful of HW queues side by side, so a throughput driver (SURVEY.md 8(e):
 // independent pairs) gets its parallelism from the batch, not from more streams.  n == 1 is the drop-in path.
-constexpr int kMaxFlowBatch = 8;
 struct FlowBatch {
     int n;
     FlowStep s[kMaxFlowBatch];
@@ -98,6 +100,13 @@ struct BlurBatch {
 
 // Re-lay a freshly uploaded frame as phase planes (once per frame).
 void launch_prep_frame(const Geom& g, const PhaseLayout& pl, const void* frame, uint32_t* pp, hipStream_t stream);
+// The same for n frames of one geometry in one launch (hf_batch).
+struct PrepBatch {
+    int n;
+    const void* frame[kMaxFlowBatch];
+    uint32_t* pp[kMaxFlowBatch];
+};
+void launch_prep_frames(const Geom& g, const PhaseLayout& pl, const PrepBatch& b, hipStream_t stream);
 // Windows <= 32: X and Y step of one level in a single launch.
 void launch_flow_level_small(const Geom& g, const FlowBatch& b, hipStream_t stream);
 // Windows > 32, one axis: partial SAD sums (atomics), then argmin + table update.
@@ -109,12 +118,21 @@ void launch_expand_offsets(const Geom& g, const FlowLevel& last, int16_t* out, h
 // zero_count: elements of BlurItem::zero to clear.
 void launch_blur_flow(const Geom& g, const BlurBatch& b, int radius, int zero_count, hipStream_t stream);
 void launch_pack_flow(const Geom& g, const int16_t* flow, uint32_t* packed, hipStream_t stream);
-constexpr int kMaxWarpOutputs = 6;   // outputs of one source period at 24 -> 120 fps (HopperRender.cpp:944-948)
-// All outputs of one source period in ONE launch (fast path only: modes 0-2 etc.); returns false when the shape
-// does not qualify and the caller must fall back to one launch_warp per output.
-bool launch_warp_period(const Geom& g, const void* frame12, const void* frame21, const int16_t* flow, const uint32_t* flow_xy,
-                        int n_out, void* const* outs, const float* ts, int mode, float black, float white, hipStream_t stream,
-                        hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+// All outputs of one source period in ONE launch (fast path only: modes 0-2 etc.), for up to kMaxFlowBatch contexts of
+// the same geometry at once; returns false when the shape of a member does not qualify and the caller must fall back to
+// one launch_warp per output.
+struct WarpPeriod {
+    const void* frame12;
+    const void* frame21;
+    const int16_t* flow;
+    const uint32_t* flow_xy;
+    int n_out;
+    void* outs[kMaxWarpOutputs];
+    float ts[kMaxWarpOutputs];
+    float black, white;      // already scaled for HDR
+};
+bool launch_warp_periods(const Geom& g, int n, const WarpPeriod* periods, int mode, hipStream_t stream,
+                         hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 // warpFrameKernel, both planes in one launch.  black/white already scaled for HDR.
 void launch_warp(const Geom& g, const void* frame12, const void* frame21, const int16_t* flow, const uint32_t* flow_xy,
                  void* out, float t, int mode, float black, float white, hipStream_t stream,

@@ -14,8 +14,6 @@
 #include "hf_kernels.h"
 #include <type_traits>
 
-#include <cstdlib>
-
 #include <hip/hip_ext.h>
 
 namespace hf {
@@ -223,6 +221,12 @@ struct WarpArgs {
     int n_out;
     float s12v[kMaxWarpOutputs], s21v[kMaxWarpOutputs];
     void* outv[kMaxWarpOutputs];
+};
+// The fused period launches of up to kMaxFlowBatch contexts of one geometry as ONE launch (hf_batch): the unit index
+// selects the member, so a batch of 8 pairs is one bandwidth-bound launch instead of 8 serialised ones.
+struct WarpBatchArgs {
+    int n;
+    WarpArgs s[kMaxFlowBatch];
 };
 
 // One output element of warpFrameKernel (all modes).
@@ -657,7 +661,7 @@ __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a,
 // VB = bytes of output per thread and row: 16, or 8 for small frames (<= 1080p 8-bit), where 16-byte threads
 // leave too few waves to hide the per-wave latency chain (one round of fat waves: 9.4 us for 9.3 MB).
 template <typename E, int GROUP, int ROWS, int MODE, int VB, bool DW>
-__global__ __launch_bounds__(64 * HF_WARP_WAVES) void warp_fast_kernel(const Geom g, const WarpArgs a, int y_groups) {
+__global__ __launch_bounds__(64 * HF_WARP_WAVES) void warp_fast_kernel(const Geom g, const WarpBatchArgs batch, int y_groups) {
     constexpr int VEC = VB / sizeof(E);
     // row group: luma groups first, then chroma; one row group per wave => the plane test is a scalar branch
     // Work decomposition: a wave tile = 64 lanes x VEC elements of one row group; tiles are numbered
@@ -665,14 +669,19 @@ __global__ __launch_bounds__(64 * HF_WARP_WAVES) void warp_fast_kernel(const Geo
     // workgroups are dealt to the XCDs in contiguous bands: linear block id b runs on XCD b % 8
     // (MI355X_MICROARCH.md "Workgroup dispatch"), so block b works on band (b % 8).  Measured on the
     // 2160p HDR blend: 20.7 us with the naive 2-D grid (every XCD walks a 1 KB wide column stripe)
-    // -> 19.0 us banded.  Placement only affects speed.
+    // -> 19.0 us banded.  Placement only affects speed.  Units are ordered (member, tile): with a batch every XCD
+    // works on whole members, i.e. each source frame is pulled into ONE L2.
     const int wpr = (g.W + 64 * VEC - 1) / (64 * VEC);            // wave tiles per row group
     const int n_tiles = wpr * (y_groups + ((g.H >> 1) + ROWS - 1) / ROWS);
-    const int n_blocks = (n_tiles + HF_WARP_WAVES - 1) / HF_WARP_WAVES;
-    const int per_band = (n_blocks + 7) >> 3;
-    const int blk = (blockIdx.x & 7) * per_band + (blockIdx.x >> 3);
+    const int n_blocks = (n_tiles + HF_WARP_WAVES - 1) / HF_WARP_WAVES;   // per member
+    const int total = n_blocks * batch.n;
+    const int per_band = (total + 7) >> 3;
+    const int u = (blockIdx.x & 7) * per_band + (blockIdx.x >> 3);
+    if (u >= total) return;
+    const int member = u / n_blocks, blk = u - member * n_blocks;
+    const WarpArgs& a = batch.s[member];
     const int tile = blk * HF_WARP_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (blk >= n_blocks || tile >= n_tiles) return;
+    if (tile >= n_tiles) return;
     const int rg = tile / wpr;
     const int cx0 = ((tile - rg * wpr) * 64 + (threadIdx.x & 63)) * VEC;
     const int uv_groups = ((g.H >> 1) + ROWS - 1) / ROWS;
@@ -729,19 +738,28 @@ void launch_pack_flow(const Geom& g, const int16_t* flow, uint32_t* packed, hipS
     pack_flow_kernel<<<(n + 255) / 256, 256, 0, stream>>>(flow, packed, n);
 }
 
-// Fast-path launch for VB bytes per thread and row.  Returns false when the shape does not qualify.
-template <typename E, int VB, bool ALL_ROWS>
-static bool launch_warp_fast(const Geom& g, const WarpArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+// Fast-path launch for VB bytes per thread and row (all members of `b` in one launch).  Returns false when the
+// shape of any member does not qualify.
+template <typename E, int VB>
+static bool launch_warp_fast(const Geom& g, const WarpBatchArgs& b, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
     constexpr int VEC = VB / sizeof(E);
-    const bool aligned = (g.out_stride % VEC) == 0 && (((uintptr_t)a.out) & (VB - 1)) == 0;
     const int cell = 1 << g.rs;
     const int group = cell < VEC ? cell : VEC;
-    // blend shortcuts of the fast kernel need 0 <= t <= 1 and levels that cannot produce NaN;
-    // chroma runs are read with element-pair granularity: needs an even input stride
-    const bool sane = a.s12 >= 0.0f && a.s12 <= 1.0f && a.white != a.black && a.white != 0.0f &&
-                      a.white == a.white && a.black == a.black;
-    const bool fast = aligned && a.mode >= 0 && a.mode <= 2 && (a.mode != 2 || sane) && a.flow_xy && (g.in_stride % 2) == 0 &&
-                      g.W >= 2 * VEC && group * (int)sizeof(E) >= 4 && VEC % group == 0 && VEC / group <= 4;
+    const int mode = b.s[0].mode;
+    bool fast = mode >= 0 && mode <= 2 && (g.in_stride % 2) == 0 && (g.out_stride % VEC) == 0 &&
+                g.W >= 2 * VEC && group * (int)sizeof(E) >= 4 && VEC % group == 0 && VEC / group <= 4;
+    // dword-aligned source loads (load_run_dw) need dword-aligned frames and rows that end on a dword
+    bool dw = ((size_t)g.in_stride * sizeof(E)) % 4 == 0 && ((size_t)g.W * sizeof(E)) % 4 == 0 && ((size_t)g.H * g.in_stride * sizeof(E)) % 4 == 0;
+    for (int m = 0; m < b.n && fast; m++) {
+        const WarpArgs& a = b.s[m];
+        // blend shortcuts of the fast kernel need 0 <= t <= 1 and levels that cannot produce NaN;
+        // chroma runs are read with element-pair granularity: needs an even input stride
+        const bool sane = a.white != a.black && a.white != 0.0f && a.white == a.white && a.black == a.black;
+        fast = fast && a.mode == mode && (mode != 2 || sane) && a.flow_xy && a.n_out >= 1 && a.n_out <= kMaxWarpOutputs;
+        for (int i = 0; i < a.n_out && fast; i++)
+            fast = fast && a.s12v[i] >= 0.0f && a.s12v[i] <= 1.0f && (((uintptr_t)a.outv[i]) & (VB - 1)) == 0;
+        dw = dw && (((uintptr_t)a.frame12 | (uintptr_t)a.frame21) & 3) == 0;
+    }
     if (!fast) return false;
     const int rows = 2;  // rows per thread (divides the 2^rs rows of a flow cell); measured on MI355X, 2160p HDR blend: 1 row 25.9 us, 2 rows 24.3 us, 4 rows 30.2 us
                          // (re-measured with the final kernel, fused period HBM-cold: 2 rows 51.1 us, 4 rows 59.3 us -- halving the
@@ -749,13 +767,13 @@ static bool launch_warp_fast(const Geom& g, const WarpArgs& a, hipStream_t strea
     const int y_groups = (g.H + rows - 1) / rows, uv_groups = ((g.H >> 1) + rows - 1) / rows;
     const int wpr = (g.W + 64 * VEC - 1) / (64 * VEC);
     const int n_blocks = (wpr * (y_groups + uv_groups) + HF_WARP_WAVES - 1) / HF_WARP_WAVES;
-    const dim3 fg(((n_blocks + 7) / 8) * 8);
+    const dim3 fg(((n_blocks * b.n + 7) / 8) * 8);
 #define HF_WARP_FAST(G, D)                                                                   \
     do {                                                                                     \
         /* ev0/ev1 (may be null): timestamps of the dispatch itself, like rocprof's kernel trace */ \
-        if (a.mode == 0) hipExtLaunchKernelGGL((warp_fast_kernel<E, G, 2, 0, VB, D>), fg, dim3(64 * HF_WARP_WAVES), 0, stream, ev0, ev1, 0, g, a, y_groups);      \
-        else if (a.mode == 1) hipExtLaunchKernelGGL((warp_fast_kernel<E, G, 2, 1, VB, D>), fg, dim3(64 * HF_WARP_WAVES), 0, stream, ev0, ev1, 0, g, a, y_groups); \
-        else hipExtLaunchKernelGGL((warp_fast_kernel<E, G, 2, 2, VB, D>), fg, dim3(64 * HF_WARP_WAVES), 0, stream, ev0, ev1, 0, g, a, y_groups);                  \
+        if (mode == 0) hipExtLaunchKernelGGL((warp_fast_kernel<E, G, 2, 0, VB, D>), fg, dim3(64 * HF_WARP_WAVES), 0, stream, ev0, ev1, 0, g, b, y_groups);      \
+        else if (mode == 1) hipExtLaunchKernelGGL((warp_fast_kernel<E, G, 2, 1, VB, D>), fg, dim3(64 * HF_WARP_WAVES), 0, stream, ev0, ev1, 0, g, b, y_groups); \
+        else hipExtLaunchKernelGGL((warp_fast_kernel<E, G, 2, 2, VB, D>), fg, dim3(64 * HF_WARP_WAVES), 0, stream, ev0, ev1, 0, g, b, y_groups);                  \
     } while (0)
 #define HF_WARP_GROUP(D)                                  \
     do {                                                  \
@@ -763,10 +781,6 @@ static bool launch_warp_fast(const Geom& g, const WarpArgs& a, hipStream_t strea
         else if (group == VEC / 2) HF_WARP_FAST(VEC / 2, D); \
         else HF_WARP_FAST(VEC / 4, D);                    \
     } while (0)
-    // dword-aligned source loads (load_run_dw) need dword-aligned frames and rows that end on a dword
-    static const bool dw_env = !(getenv("HF_WARP_DW") && atoi(getenv("HF_WARP_DW")) == 0);
-    const bool dw = dw_env && (((uintptr_t)a.frame12 | (uintptr_t)a.frame21) & 3) == 0 && ((size_t)g.in_stride * sizeof(E)) % 4 == 0 &&
-                    ((size_t)g.W * sizeof(E)) % 4 == 0 && ((size_t)g.H * g.in_stride * sizeof(E)) % 4 == 0;
     if (dw) HF_WARP_GROUP(true);
     else HF_WARP_GROUP(false);
 #undef HF_WARP_GROUP
@@ -774,14 +788,20 @@ static bool launch_warp_fast(const Geom& g, const WarpArgs& a, hipStream_t strea
     return true;
 }
 
+// frames up to 1080p 8-bit: 8 bytes per thread (twice the waves); larger frames: 16 bytes per thread
+template <typename E>
+static bool launch_warp_fast_any(const Geom& g, const WarpBatchArgs& b, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+    const bool small = (size_t)g.W * g.H * sizeof(E) <= (size_t)1920 * 1088;
+    if (small && launch_warp_fast<E, 8>(g, b, stream, ev0, ev1)) return true;
+    return launch_warp_fast<E, 16>(g, b, stream, ev0, ev1);
+}
+
 template <typename E>
 static void launch_warp_t(const Geom& g, const WarpArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
     constexpr int VEC = 16 / sizeof(E);  // generic kernel: 16-byte stores
-    // frames up to 1080p: 8 bytes per thread (twice the waves); larger frames: 16 bytes per thread
-    static const int vb_env = getenv("HF_WARP_VB") ? atoi(getenv("HF_WARP_VB")) : 0;
-    const bool small = vb_env ? vb_env == 8 : (size_t)g.W * g.H * sizeof(E) <= (size_t)1920 * 1088;
-    if (small && launch_warp_fast<E, 8, false>(g, a, stream, ev0, ev1)) return;
-    if (launch_warp_fast<E, 16, true>(g, a, stream, ev0, ev1)) return;
+    WarpBatchArgs b;
+    b.n = 1; b.s[0] = a;
+    if (launch_warp_fast_any<E>(g, b, stream, ev0, ev1)) return;
     const bool aligned = (g.out_stride % VEC) == 0 && (((uintptr_t)a.out) & 15) == 0;
     const dim3 grd((g.W + 64 * VEC - 1) / (64 * VEC), (g.H + (g.H >> 1) + 3) / 4);
     if (aligned) hipExtLaunchKernelGGL((warp_kernel<E, VEC, true>), grd, dim3(256), 0, stream, ev0, ev1, 0, g, a);
@@ -798,25 +818,21 @@ void launch_warp(const Geom& g, const void* frame12, const void* frame21, const 
     else launch_warp_t<uint8_t>(g, a, stream, ev0, ev1);
 }
 
-bool launch_warp_period(const Geom& g, const void* frame12, const void* frame21, const int16_t* flow, const uint32_t* flow_xy,
-                        int n_out, void* const* outs, const float* ts, int mode, float black, float white, hipStream_t stream,
-                        hipEvent_t ev0, hipEvent_t ev1) {
-    if (n_out < 1 || n_out > kMaxWarpOutputs) return false;
-    WarpArgs a;
-    a.frame12 = frame12; a.frame21 = frame21; a.flow = flow; a.flow_xy = flow_xy; a.out = outs[0];
-    a.mode = mode; a.black = black; a.white = white;
-    a.n_out = n_out;
-    // the eligibility test looks at (s12, out): every output must pass it
-    for (int i = 0; i < n_out; i++) {
-        a.s12v[i] = ts[i]; a.s21v[i] = 1.0f - ts[i]; a.outv[i] = outs[i];
-        if (!(ts[i] >= 0.0f && ts[i] <= 1.0f) || (((uintptr_t)outs[i]) & 15)) return false;
+bool launch_warp_periods(const Geom& g, int n, const WarpPeriod* periods, int mode, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+    if (n < 1 || n > kMaxFlowBatch) return false;
+    WarpBatchArgs b;
+    b.n = n;
+    for (int m = 0; m < n; m++) {
+        const WarpPeriod& p = periods[m];
+        if (p.n_out < 1 || p.n_out > kMaxWarpOutputs) return false;
+        WarpArgs& a = b.s[m];
+        a.frame12 = p.frame12; a.frame21 = p.frame21; a.flow = p.flow; a.flow_xy = p.flow_xy; a.out = p.outs[0];
+        a.mode = mode; a.black = p.black; a.white = p.white;
+        a.n_out = p.n_out;
+        for (int i = 0; i < p.n_out; i++) { a.s12v[i] = p.ts[i]; a.s21v[i] = 1.0f - p.ts[i]; a.outv[i] = p.outs[i]; }
+        a.s12 = a.s12v[0]; a.s21 = a.s21v[0];
     }
-    a.s12 = a.s12v[0]; a.s21 = a.s21v[0];
-    const size_t el = g.hdr ? 2 : 1;
-    static const int vb_env = getenv("HF_WARP_VB") ? atoi(getenv("HF_WARP_VB")) : 0;
-    const bool small = vb_env ? vb_env == 8 : (size_t)g.W * g.H * el <= (size_t)1920 * 1088;
-    if (g.hdr) return (small && launch_warp_fast<uint16_t, 8, false>(g, a, stream, ev0, ev1)) || launch_warp_fast<uint16_t, 16, true>(g, a, stream, ev0, ev1);
-    return (small && launch_warp_fast<uint8_t, 8, false>(g, a, stream, ev0, ev1)) || launch_warp_fast<uint8_t, 16, true>(g, a, stream, ev0, ev1);
+    return g.hdr ? launch_warp_fast_any<uint16_t>(g, b, stream, ev0, ev1) : launch_warp_fast_any<uint8_t>(g, b, stream, ev0, ev1);
 }
 
 template <typename E>

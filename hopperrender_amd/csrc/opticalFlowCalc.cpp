@@ -35,6 +35,12 @@ void OpticalFlowCalc::init(bool hdr, int frameHeight, int frameWidth, int inputS
         fputs((msg + "\n").c_str(), stderr);
         throw std::runtime_error(msg);
     }
+    m_deltaScalar = deltaScalar;                  // opticalFlowCalcSDR.cpp:214-216,223-224
+    m_neighborBiasScalar = neighborScalar;
+    m_outputBlackLevel = blackLevel;
+    m_outputWhiteLevel = whiteLevel;
+    m_opticalFlowSearchRadius = MIN_SEARCH_RADIUS;
+    m_frameCount = 0;
     pull();
     hf_stats st{};
     hf_get_stats(m_ctx, &st);
@@ -58,17 +64,12 @@ void OpticalFlowCalc::push() {
     check(hf_set_params(m_ctx, &p), "push");
 }
 
+// Only what the calculator owns (include/opticalFlowCalc.h): results, timings, geometry.  The caller-owned inputs are
+// never written back -- the reference's settings thread pokes them while the streaming thread is inside a blocking call
+// (HopperRender.cpp:1385-1390) and that write must survive the call.
 void OpticalFlowCalc::pull() {
-    hf_params p{};
     hf_stats s{};
-    check(hf_get_params(m_ctx, &p), "pull");
     check(hf_get_stats(m_ctx, &s), "pull");
-    m_deltaScalar = p.delta_scalar;
-    m_neighborBiasScalar = p.neighbor_scalar;
-    m_outputBlackLevel = p.black_level;
-    m_outputWhiteLevel = p.white_level;
-    m_opticalFlowSearchRadius = p.search_radius;
-    m_frameCount = p.frame_count;
     m_totalFrameDelta = s.total_frame_delta;
     m_ofcCalcTime = s.ofc_calc_time;
     m_ofcAvgCalcTime = s.ofc_avg_calc_time;
@@ -86,6 +87,7 @@ void OpticalFlowCalc::pull() {
 void OpticalFlowCalcImpl::updateFrame(unsigned char* inputPlanes) {
     push();
     check(hf_update_frame(m_ctx, inputPlanes), __func__);
+    m_frameCount++;   // opticalFlowCalcSDR.cpp:28 -- on the field itself: NewSegment's reset (HopperRender.cpp:840) is not overwritten
     pull();
 }
 

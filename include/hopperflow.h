@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HF_ABI_VERSION 1
+#define HF_ABI_VERSION 2
 
 typedef struct hf_ctx hf_ctx;
 
@@ -36,7 +36,8 @@ typedef enum hf_status {
     HF_ERR_NO_DEVICE = -2,        /* no HIP device satisfies the request (reference: detectDevices throws, opticalFlowCalc.cpp:97-109) */
     HF_ERR_OUT_OF_MEMORY = -3,
     HF_ERR_HIP = -4,              /* a HIP runtime call failed (reference: CHECK_ERROR, opticalFlowCalc.h:15-22) */
-    HF_ERR_STATE = -5             /* call made in a state the reference would have mis-rendered (e.g. warp before any flow) */
+    HF_ERR_STATE = -5             /* the object is in a state that excludes the call: a context that already belongs to a
+                                     batch handed to hf_batch_create, asynchronous host I/O on a batch member */
 } hf_status;
 
 /* Frame output modes of warpFrames (reference HopperRender.h:10-18, warpFrameKernelSDR.h:133-183). */
@@ -53,14 +54,9 @@ typedef enum hf_output_mode {
 #define HF_FLAG_ASYNC 0x1 /* calls only enqueue; results/timings valid after hf_sync(). Default: every
                              call blocks like the reference (CL_TRUE transfers, clWaitForEvents). */
 #define HF_FLAG_NO_GRAPH 0x2 /* launch the flow chain eagerly instead of replaying a hipGraph (debug) */
+#define HF_FLAG_PROFILE 0x4  /* bracket every warp/copy launch and every flow chain with HIP events on ctx's
+                                stream; totals are read with hf_get_profile() (bench.py's live roofline figure) */
 #define HF_FLAG_NO_LAZY_ARGMIN 0x8 /* large windows: take every argmin in a launch of its own (debug / A-B timing) */
-#define HF_FLAG_SHARED_WARP_STREAM 0x10 /* batch hosts: warp kernels of all contexts of a device are issued on one shared
-                                           stream (they are bandwidth-bound: back-to-back beats side by side), the
-                                           latency-bound flow chains of the other contexts overlap them.  Measured slower
-                                           than one stream per context on MI355X, like the next three */
-#define HF_FLAG_PRIORITY_STREAMS 0x20 /* batch hosts: the context's flow chain runs on a high-priority stream, its warp
-                                         kernels on a low-priority one (tied by events), so the short latency-bound
-                                         chain kernels are not starved by other contexts' bandwidth-bound warps */
 #define HF_FLAG_DUAL_STREAM 0x40 /* async hosts: warp kernels on a second stream of the context.  warpFrames consumes the
                                     PREVIOUS flow and frames N-2/N-1 (opticalFlowCalcSDR.cpp:154-156) while
                                     calculateOpticalFlow produces the next flow from N-1/N into the other buffer, so the two
@@ -69,16 +65,8 @@ typedef enum hf_output_mode {
 #define HF_FLAG_NO_TIMING 0x200 /* do not record the events behind m_ofcCalcTime / m_warpCalcTime (hf_stats times stay 0).
                                    Every timing event is a barrier packet on the stream: measured 5-6 us each between
                                    back-to-back kernels, ~15 us per source period in a throughput pipeline */
-#define HF_FLAG_DEFER_PREP 0x400 /* updateFrame builds only the grid samples of the new frame and the full phase planes of the
-                                    PREVIOUS one (the frame the next flow calculation gathers from), so they are still cached.
-                                    Measured: no effect on throughput (51.6 k either way) -- the chain is not held back by
-                                    cold phase planes */
-#define HF_FLAG_WARP_TURNSTILE 0x100 /* the warp launches of all such contexts on a device run one at a time (each waits
-                                        for the previously issued one): two bandwidth-bound warps gain nothing from
-                                        overlapping each other, the other streams' flow chains fill in instead.
-                                        Measured: shorter launches (105 vs 160 us) but 41.7 k instead of 45.8 k frames/s */
-#define HF_FLAG_PROFILE 0x4  /* bracket every warp/copy launch and every flow chain with HIP events on ctx's
-                                stream; totals are read with hf_get_profile() (bench.py's live roofline figure) */
+/* (0x10, 0x20, 0x100, 0x400 were round-1 stream-topology experiments -- shared warp stream, priority streams, warp
+ *  turnstile, deferred phase planes -- all measured slower or equal; removed, findings in DESIGN.md section 4) */
 
 /* The nine constructor arguments of OpticalFlowCalcSDR/HDR (opticalFlowCalcSDR.cpp:206-208)
  * plus build-side extensions (0 selects the reference behaviour for each). */
@@ -180,10 +168,9 @@ int hf_interpolate_period_ex(hf_ctx* ctx, const void* device_frame, int n_out, c
  * geometry/parameters into a batch: hf_batch_calculate_optical_flow() runs the calculateOpticalFlow() of every
  * member as ONE set of launches (each kernel handles all pairs).  Results per member are bit-identical to
  * hf_calculate_optical_flow(member).
- *   - members: HF_FLAG_ASYNC contexts without async host I/O, all single-stream or all HF_FLAG_DUAL_STREAM (no
- *     SHARED/PRIORITY flags), same device, frame geometry, iterations, blur radius; at call time the same search
+ *   - members: HF_FLAG_ASYNC contexts without async host I/O, all single-stream or all HF_FLAG_DUAL_STREAM, same device, frame geometry, iterations, blur radius; at call time the same search
  *     radius / delta / neighbor scalar.  DUAL_STREAM members issue their warps on up to 3 streams the batch shares
- *     out round robin (they overlap the batched chain; measured slower than 4 single-stream batches of 2).
+ *     out round robin (they overlap the batched chain; measured slower than single-stream batches).
  *   - while the batch exists all members issue on ONE stream (the first member's): their hf_update_frame_device*,
  *     hf_interpolate_period_ex(..., update_and_flow = 0), hf_sync ... calls keep working and stay in program order
  *     with the batched chain.  Destroy the batch before its members. */
@@ -191,8 +178,17 @@ typedef struct hf_batch hf_batch;
 int hf_batch_create(hf_ctx* const* members, int n, hf_batch** out_batch);
 void hf_batch_destroy(hf_batch* batch);
 int hf_batch_calculate_optical_flow(hf_batch* batch);
+/* hf_update_frame_device_ref(member i, device_frames[i]) for every member, the phase planes of all new frames built by
+ * ONE launch. */
+int hf_batch_update_frames_device_ref(hf_batch* batch, const void* const* device_frames);
+/* hf_interpolate_period_ex(member i, NULL, n_out[i], t + 6 i, device_out + 6 i, mode, 0) for every member: the warps of
+ * one source period of EVERY member in ONE launch (single-stream members, modes 0-2, every n_out[i] >= 1; otherwise
+ * member by member).  t and device_out are [batch size][HF_MAX_PERIOD_OUTPUTS] arrays; a NULL device_out entry
+ * selects the member's internal output frame. */
+#define HF_MAX_PERIOD_OUTPUTS 6
+int hf_batch_interpolate_period(hf_batch* batch, const int* n_out, const float* t, void* const* device_out, int mode);
 int hf_batch_size(const hf_batch* batch);
-const char* hf_batch_last_error(const hf_batch* batch);   /* batch == NULL: error of the last failed hf_batch_create */
+const char* hf_batch_last_error(const hf_batch* batch);   /* batch == NULL: error of the last failed hf_batch_create (per thread) */
 
 /* Device-to-device copy of the output frame into caller-owned device memory. */
 int hf_download_frame_device(hf_ctx* ctx, void* device_out);
@@ -231,6 +227,49 @@ int hf_get_profile(hf_ctx* ctx, hf_profile* out); /* synchronises ctx */
  * back-to-back launches, so throughput runs sample instead of bracketing everything. */
 int hf_set_profile_interval(hf_ctx* ctx, int warp_every, int flow_every);
 int hf_reset_profile(hf_ctx* ctx);
+
+/* ---- caller protocol: what the reference's filter does AROUND the calculator (HopperRender.cpp:938-1197,1438-1463) ----
+ * Host logic only (no GPU work of its own): how many output frames a source period gets and at which blending scalars,
+ * the scene-change decision on the m_totalFrameDelta stream (warp vs copy -- it decides output pixels), the search-radius
+ * governor.  A C++ host that keeps the reference's own filter code does not need these; tests/cpp/replay_filter.cpp,
+ * the Python mirror (hopperrender_amd/protocol.py) and any cgo / JNI host do.  Times are 100-ns units (REFERENCE_TIME). */
+typedef struct hf_filter hf_filter;
+typedef struct hf_filter_config {
+    uint32_t struct_size;
+    int32_t scene_change_threshold;  /* m_iSceneChangeThreshold; < 0 -> DEFAULT_SCENE_CHANGE_THRESHOLD 200 (config.h:27) */
+    int64_t source_frame_time;       /* m_rtSourceFrameTime, <= 0 -> 417083 = 23.976 fps (HopperRender.cpp:162) */
+    int64_t target_frame_time;       /* m_rtTargetFrameTime, <= 0 -> 166667 = 60 fps (:163) */
+    int32_t frame_output_mode;       /* m_iFrameOutput (hf_output_mode), BlendedFrame = 2 */
+    int32_t auto_adjust;             /* run the governor in hf_filter_deliver (AUTO_SEARCH_RADIUS_ADJUST, config.h:12) */
+    int32_t active;                  /* interpolation requested (m_iIntActiveState != Deactivated) */
+    int32_t reserved;
+} hf_filter_config;
+typedef struct hf_filter_state {
+    int32_t num_int_frames;          /* m_iNumIntFrames of the current source period */
+    int32_t active;                  /* m_iIntActiveState == Active */
+    double blending_scalar;          /* m_dBlendingScalar */
+    double total_warp_duration;      /* m_dTotalWarpDuration, seconds */
+    int64_t playback_frame_time;     /* m_rtCurrPlaybackFrameTime */
+    uint32_t peak_scene_change_delta, peak_scene_change_delta2;  /* m_iPeakSceneChangeDelta{,2} (1-second window) */
+    uint32_t frame_delta_history, scene_change_history;          /* entries in the two sliding windows */
+    int32_t average_frame_delta, scene_change_delta1, scene_change_delta2;  /* of the last decision (:1139-1144) */
+} hf_filter_state;
+int hf_filter_create(const hf_filter_config* cfg, hf_filter** out_filter);
+void hf_filter_destroy(hf_filter* filter);
+int hf_filter_new_segment(hf_filter* filter, double rate);                       /* NewSegment (:834-845); the caller zeroes m_frameCount (:840) */
+int hf_filter_set_playback_frame_time(hf_filter* filter, int64_t playback_frame_time);
+int hf_filter_is_active(const hf_filter* filter);
+int hf_filter_begin_source_frame(hf_filter* filter);                            /* :944-948, returns m_iNumIntFrames */
+double hf_filter_blending_scalar(const hf_filter* filter);                      /* m_dBlendingScalar */
+void hf_filter_advance_blending_scalar(hf_filter* filter);                      /* :1192-1197 */
+void hf_filter_add_warp_duration(hf_filter* filter, double warp_calc_time);     /* :1189 */
+int hf_filter_auto_adjust(hf_filter* filter, double ofc_calc_time, int32_t* search_radius); /* :1438-1463; returns -1/0/+1 */
+int hf_filter_push_frame_delta(hf_filter* filter, uint32_t frame_count, uint32_t total_frame_delta);   /* :959-972 */
+int hf_filter_detect_scene_change(hf_filter* filter, uint32_t frame_count);     /* :1126-1176; 1 = copyFrame instead of warpFrames */
+int hf_filter_get_state(const hf_filter* filter, hf_filter_state* out);
+/* One DeliverToRenderer (:938-1197) on a blocking context: host_out[i] receives output frame i (n = return of
+ * hf_filter_begin_source_frame <= max_out), kinds[i] (optional) = 1 warp / 0 copy. */
+int hf_filter_deliver(hf_filter* filter, hf_ctx* ctx, const void* host_in, void* const* host_out, int max_out, int* n_out, int32_t* kinds);
 
 /* ---- plain device-memory helpers so non-HIP hosts (ctypes, cgo, JNI) can stage frames ---- */
 int hf_device_count(void);

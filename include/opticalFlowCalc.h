@@ -8,15 +8,21 @@
 //   * no <CL/cl.h>, no OutputDebugStringA, no `max` macro leak (reference opticalFlowCalc.h:2-14);
 //   * the cl_* handles, grids and kernels (opticalFlowCalc.h:51-86), which the filter never touches,
 //     are gone; the device state lives behind the opaque hf_ctx;
-//   * the public fields are SNAPSHOTS: they are pushed to the context at the start of every call and
-//     refreshed from it at the end, which is exactly when the reference's kernels read them
-//     (clSetKernelArg per call, opticalFlowCalcSDR.cpp:85-86,160-161);
+//   * ownership of the public fields follows the reference.  The fields the CALLER writes -- m_deltaScalar,
+//     m_neighborBiasScalar, m_outputBlackLevel, m_outputWhiteLevel (settings thread, HopperRender.cpp:1385-1390),
+//     m_opticalFlowSearchRadius (governor, :1445-1458) and m_frameCount (NewSegment, :840) -- are only ever READ by this
+//     class: every call hands their current values to the context first, which is when the reference's kernels see
+//     them (clSetKernelArg per call, opticalFlowCalcSDR.cpp:85-86,160-161), and nothing is written back, so a value
+//     poked by another thread while a blocking call is in flight survives and is used by the next call, as in the
+//     reference.  updateFrame() increments m_frameCount in place (opticalFlowCalcSDR.cpp:28).  The fields the
+//     CALCULATOR owns -- m_totalFrameDelta, the timings, the geometry -- are refreshed after every call;
 //   * init(...) / blendFrames(t) exist as the aliases BASELINE.json's north_star names.
 // Errors are std::runtime_error with the reference's "[HopperRender] ..." prefix (opticalFlowCalc.h:15-22).
 #pragma once
 
 #include <stdexcept>
 
+#include "config.h"      // the reference reaches config.h through this header (opticalFlowCalc.h:8)
 #include "hopperflow.h"
 
 class OpticalFlowCalc {
@@ -65,8 +71,8 @@ protected:
     // "init" = the constructor body of the reference (opticalFlowCalcSDR.cpp:206-325)
     void init(bool hdr, int frameHeight, int frameWidth, int inputStride, int outputStride, int deltaScalar,
               int neighborScalar, float blackLevel, float whiteLevel, int maxCalcRes);
-    void push();            // public fields -> context
-    void pull();            // context -> public fields
+    void push();            // caller-owned public fields -> context
+    void pull();            // context -> calculator-owned public fields
     void check(int rc, const char* func);
     hf_ctx* m_ctx = nullptr;
 };

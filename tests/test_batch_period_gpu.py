@@ -1,0 +1,120 @@
+"""GPU: the batched period calls of hf_batch -- hf_batch_update_frames_device_ref (the phase planes of every member's
+new frame in one launch) and hf_batch_interpolate_period (the warps of a source period of EVERY member in one launch)
+-- must give each member exactly what its own hf_update_frame_device_ref / hf_interpolate_period_ex give."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("hdr,H,W,n,R,mode", [(0, 360, 640, 3, 8, 2), (1, 360, 640, 8, 16, 2), (0, 1080, 1920, 4, 16, 2),
+                                             (1, 2160, 3840, 2, 5, 2), (0, 274, 486, 5, 16, 2), (1, 360, 640, 4, 9, 0),
+                                             (0, 360, 640, 3, 9, 1), (0, 360, 640, 2, 7, 4), (1, 338, 600, 3, 6, 2)])
+def test_batched_period_equals_single_contexts(native_lib, hdr, H, W, n, R, mode):
+    from hopperrender_amd import capi, synth
+    from hopperrender_amd.calc import DeviceBuffer, FlowBatch, OpticalFlowCalcHDR, OpticalFlowCalcSDR
+    from hopperrender_amd.protocol import SOURCE_24, TARGET_120, BlendSchedule
+    cls = OpticalFlowCalcHDR if hdr else OpticalFlowCalcSDR
+    scenes = [synth.Scene(H, W, bool(hdr), 300 + 11 * i) for i in range(n)]
+    frames = [[sc.frame(k) for k in range(6)] for sc in scenes]
+    dev = [[DeviceBuffer(f.nbytes) for f in fs] for fs in frames]
+    for i in range(n):
+        for k in range(6):
+            dev[i][k].upload(frames[i][k])
+    singles = [cls(H, W, search_radius=R, flags=capi.HF_FLAG_ASYNC) for _ in range(n)]
+    members = [cls(H, W, search_radius=R, flags=capi.HF_FLAG_ASYNC) for _ in range(n)]
+    batch = FlowBatch(members)
+    # members run different phases of the 24 -> 120 schedule: 5 or 6 outputs each, different scalars
+    plans = [BlendSchedule(SOURCE_24, TARGET_120).plan(10 + i)[i:] for i in range(n)]
+    K = 6
+    outs_s = [[DeviceBuffer(singles[0].output_frame_bytes) for _ in range(K)] for _ in range(n)]
+    outs_b = [[DeviceBuffer(singles[0].output_frame_bytes) for _ in range(K)] for _ in range(n)]
+    dt = np.uint16 if hdr else np.uint8
+    for k in range(6):
+        for i in range(n):
+            singles[i].updateFrameDeviceRef(dev[i][k].ptr)
+        batch.updateFramesDeviceRef([dev[i][k].ptr for i in range(n)])
+        if k < 2:
+            continue
+        for i in range(n):
+            singles[i].calculateOpticalFlow()
+        batch.calculateOpticalFlow()
+        ts = [plans[i][k] for i in range(n)]
+        for i in range(n):
+            singles[i].interpolateOnly(ts[i], [b.ptr for b in outs_s[i]], mode)
+        batch.interpolatePeriod(ts, [[b.ptr for b in outs_b[i]] for i in range(n)], mode)
+        for i in range(n):
+            singles[i].sync(); members[i].sync()
+            assert members[i].m_frameCount == singles[i].m_frameCount == k + 1
+            assert members[i].m_totalFrameDelta == singles[i].m_totalFrameDelta, (k, i)
+            assert (members[i].readBlurredFlow(1) == singles[i].readBlurredFlow(1)).all(), (k, i)
+            for j in range(len(ts[i])):
+                assert (outs_s[i][j].download(dt) == outs_b[i][j].download(dt)).all(), (k, i, j)
+    batch.close()
+    for c in singles + members:
+        c.close()
+
+
+def test_batched_period_matches_oracle(native_lib):
+    """... and through the oracle the reference: one batched period at 180p against the CPU restatement."""
+    from hopperrender_amd import capi, synth
+    from hopperrender_amd.calc import DeviceBuffer, FlowBatch, OpticalFlowCalcSDR
+    from oracle import oracle
+    H, W, R, n = 180, 320, 8, 3
+    g = oracle.make_geom(0, H, W)
+    scenes = [synth.Scene(H, W, False, 900 + i) for i in range(n)]
+    frames = [[sc.frame(k) for k in range(4)] for sc in scenes]
+    dev = [[DeviceBuffer(f.nbytes) for f in fs] for fs in frames]
+    for i in range(n):
+        for k in range(4):
+            dev[i][k].upload(frames[i][k])
+    members = [OpticalFlowCalcSDR(H, W, search_radius=R, flags=capi.HF_FLAG_ASYNC) for _ in range(n)]
+    batch = FlowBatch(members)
+    outs = [[DeviceBuffer(members[0].output_frame_bytes) for _ in range(3)] for _ in range(n)]
+    ts = [[0.0, 0.3996, 0.7992], [0.1988, 0.5984, 0.998], [0.5]]
+    for k in range(4):
+        batch.updateFramesDeviceRef([dev[i][k].ptr for i in range(n)])
+        if k >= 2:
+            batch.calculateOpticalFlow()
+    batch.interpolatePeriod(ts, [[b.ptr for b in outs[i]] for i in range(n)], 2)
+    for i in range(n):
+        members[i].sync()
+        _, blur, tot, oob = oracle.calculate_optical_flow(frames[i][1], frames[i][2], g, R)
+        assert oob == 0
+        assert (members[i].readBlurredFlow(0) == blur).all()
+        for j, t in enumerate(ts[i]):
+            ref = oracle.warp_frames(frames[i][1], frames[i][2], blur, g, np.float32(t), 2)
+            assert (outs[i][j].download(np.uint8) == ref).all(), (i, j)
+    batch.close()
+    for c in members:
+        c.close()
+
+
+def test_batch_state_errors(native_lib):
+    """HF_ERR_STATE: a context joins one batch at a time; asynchronous host I/O is not available to batch members.
+    A failed hf_batch_create leaves every context as it was."""
+    from hopperrender_amd import capi, synth
+    from hopperrender_amd.calc import FlowBatch, OpticalFlowCalcSDR, PinnedArray
+    a, b, c = (OpticalFlowCalcSDR(180, 320, flags=capi.HF_FLAG_ASYNC) for _ in range(3))
+    odd = OpticalFlowCalcSDR(184, 320, flags=capi.HF_FLAG_ASYNC)
+    ba = FlowBatch([a, b])
+    with pytest.raises(capi.HopperFlowError) as e:
+        FlowBatch([c, a])
+    assert e.value.code == capi.HF_ERR_STATE and "already belongs to a batch" in str(e.value)
+    with pytest.raises(capi.HopperFlowError) as e:
+        FlowBatch([c, odd])
+    assert e.value.code == capi.HF_ERR_INVALID_ARGUMENT
+    pin = PinnedArray(a.input_frame_bytes, np.uint8)
+    with pytest.raises(capi.HopperFlowError) as e:
+        a.updateFrameAsync(pin)
+    assert e.value.code == capi.HF_ERR_STATE
+    f = synth.Scene(180, 320, False, 3).frame(0)
+    for _ in range(3):
+        c.updateFrame(f)          # c was named in two failed creates: still an ordinary, working context
+    c.calculateOpticalFlow(); c.sync()
+    assert c.m_frameCount == 3 and (c.readBlurredFlow(1) == 0).all()     # identical frames: zero flow
+    ba.close()
+    FlowBatch([c, a]).close()     # and free to join a batch once the other one is gone
+    pin.free()
+    for x in (a, b, c, odd):
+        x.close()

@@ -24,18 +24,19 @@ def test_every_declared_symbol_is_exported_and_bound(native_lib):
     assert not (set(syms) - set(capi.SIGNATURES)), f"not bound in capi.py: {sorted(set(syms) - set(capi.SIGNATURES))}"
     for s in syms:
         assert getattr(native_lib, s) is not None
-    assert native_lib.hf_abi_version() == 1
+    assert native_lib.hf_abi_version() == 2   # round 2: batch period / frame-update calls, hf_filter_*, stream-topology flags removed
 
 
 def test_struct_layouts_match_the_header(native_lib, tmp_path):
     """sizeof of the C structs as compiled by gcc == the ctypes mirrors."""
     from hopperrender_amd import capi
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include "hopperflow.h"\nint main(){printf("%zu %zu %zu %zu\\n", sizeof(hf_config), sizeof(hf_params), sizeof(hf_stats), sizeof(hf_profile));return 0;}\n')
+    src.write_text('#include <stdio.h>\n#include "hopperflow.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(hf_config), sizeof(hf_params), sizeof(hf_stats), sizeof(hf_profile), sizeof(hf_filter_config), sizeof(hf_filter_state));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
-    assert sizes == [ctypes.sizeof(capi.HfConfig), ctypes.sizeof(capi.HfParams), ctypes.sizeof(capi.HfStats), ctypes.sizeof(capi.HfProfile)]
+    assert sizes == [ctypes.sizeof(capi.HfConfig), ctypes.sizeof(capi.HfParams), ctypes.sizeof(capi.HfStats), ctypes.sizeof(capi.HfProfile),
+                     ctypes.sizeof(capi.HfFilterConfig), ctypes.sizeof(capi.HfFilterState)]
 
 
 def test_no_device_fails_loudly_not_silently(native_lib):

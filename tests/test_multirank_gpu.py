@@ -1,0 +1,49 @@
+"""GPU: bench.py's multi-rank path (one process per rank under torch.distributed.run, barrier + MAX/SUM reductions of
+the timing, pair streams sharded with no data-path collective) executed for real.  The box has ONE GPU, so the two ranks
+share it and the reductions run over gloo (HF_BENCH_BACKEND=gloo); on an 8-GPU node the driver uses nccl (= RCCL)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def run_bench(extra, world):
+    env = dict(os.environ, HF_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    args = ["--steps", "2", "--warmup", "1", "--periods-per-step", "4", "--workload", "sdr1080_24to60", "--no-cpu-baseline",
+            "--no-reference", "--no-host-io"] + extra
+    if world == 1:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + args
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world)] + args
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]          # rank 0 prints ONE line
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_on_one_gpu():
+    one = run_bench([], 1)
+    two = run_bench([], 2)
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert two["config"]["output_frames_total"] == 2 * one["config"]["output_frames_total"]   # SUM over ranks; weak scaling
+    assert two["value"] > 0 and two["scaling"] == "weak" and two["config"]["parallelism"].startswith("pair-sharded x2")
+    assert "cpu_baseline" not in two and "host_io" not in two                                  # rank-0-at-N=1 only
+    assert two["roofline"]["bound"] == "hbm" and 0 < two["roofline"]["frac"] < 1
+    # the ranks shared one GPU: per-rank rate about halves, the aggregate stays in the same range
+    assert two["value"] > 0.4 * one["value"]

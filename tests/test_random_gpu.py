@@ -47,15 +47,17 @@ def test_random_configuration_matches_oracle(native_lib, seed):
     g = oracle.make_geom(hdr, H, W, k["si"], k["so"], k["max_res"])
     cls = OpticalFlowCalcHDR if hdr else OpticalFlowCalcSDR
     c = cls(H, W, k["si"], k["so"], k["delta"], k["nb"], k["black"], k["white"], k["max_res"], iterations=k["iters"],
-            blur_radius=k["blur"], search_radius=k["R"], flags=(capi.HF_FLAG_ASYNC if seed % 2 else 0) | (capi.HF_FLAG_DEFER_PREP if seed % 3 == 1 else 0))
+            blur_radius=k["blur"], search_radius=k["R"], flags=(capi.HF_FLAG_ASYNC if seed % 2 else 0) | (capi.HF_FLAG_DUAL_STREAM if seed % 6 == 1 else 0))
     for x in f[:3]:
         c.updateFrame(x)
     c.calculateOpticalFlow()
     c.sync()
     off_a, blur_a, tot_a, oob_a = oracle.calculate_optical_flow(f[1], f[2], g, k["R"], k["iters"], k["delta"], k["nb"], k["blur"])
-    if oob_a == 0:   # (offsets that leave the reference's defined range only arise with huge scalars; skip those)
-        assert (c.readOffsets() == off_a).all(), k
-        assert c.m_totalFrameDelta == tot_a, k
+    # oob_a > 0: some sample position left the range the reference defines (its single reflection indexes outside the
+    # frame, calcDeltaSumsKernelSDR.h:86-95 -- only with huge scalars / tiny frames).  The oracle and the HIP path both
+    # clamp there, so they still have to agree with each other; only the comparison with the reference is off.
+    assert (c.readOffsets() == off_a).all(), (k, oob_a)
+    assert c.m_totalFrameDelta == tot_a, (k, oob_a)
     assert (c.readBlurredFlow(1) == oracle.blur_flow(c.readOffsets(), g, k["blur"])).all(), k
     c.updateFrame(f[3])
     c.calculateOpticalFlow()
@@ -103,9 +105,9 @@ def test_tiny_frames_match_oracle(native_lib, hdr, H, W):
             c.updateFrame(x)
         c.calculateOpticalFlow()
         off, blur, tot, oob = oracle.calculate_optical_flow(f[1], f[2], g, R)
-        if oob == 0:
-            assert (c.readOffsets() == off).all(), (R, "offsets")
-            assert c.m_totalFrameDelta == tot
+        # oob > 0 (offsets larger than these tiny frames): undefined in the reference, clamped identically by oracle and HIP
+        assert (c.readOffsets() == off).all(), (R, "offsets", oob)
+        assert c.m_totalFrameDelta == tot
         assert (c.readBlurredFlow(1) == oracle.blur_flow(c.readOffsets(), g, 4)).all(), (R, "blur")
         c.updateFrame(f[3]); c.calculateOpticalFlow()
         flow = c.readBlurredFlow(0)
