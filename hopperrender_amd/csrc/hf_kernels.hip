@@ -409,13 +409,8 @@ template <> struct StoreVec<8> { using type = uint2; };
 #define HF_WARP_NT_STORE 1   // streaming stores of the output frames.  (Non-temporal LOADS of frame N-2, whose last use this is,
                              // were much slower: 76 vs 52 us -- the outputs of a period re-read its rows through L2.)
 #endif
-#ifndef HF_WARP_PIPELINE
-#define HF_WARP_PIPELINE 0   // 1: request the source runs of output ti + 1 before blending output ti (two register sets).
-                             // Was worth 68 -> 53 us before the dword-aligned loads; since then the plain loop with its
-                             // higher occupancy (51 vs 91 VGPRs) is as fast or faster: 48.7 vs 49.9 us hot, 65.7 vs 67.2 us cold
-#endif
 template <typename E, int GROUP, int ROWS, int MODE, int CZ, int VB, bool DW>
-__device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a, int cy0, int cx0) {
+__device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a, int cy0, int cx0, int ti0, int ti1) {
     using T = ElemTraits<E>;
     using SV = typename StoreVec<VB>::type;
     constexpr int VEC = VB / sizeof(E);
@@ -426,7 +421,7 @@ __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a,
     const int nrows = min(ROWS, dim_y - cy0);
     const Levels lv = make_levels(a.black, a.white);
     if (cx0 + VEC > W) {  // ragged right edge
-        for (int ti = 0; ti < a.n_out; ti++) {
+        for (int ti = ti0; ti < ti1; ti++) {
             WarpArgs at = a;
             at.s12 = a.s12v[ti]; at.s21 = a.s21v[ti]; at.out = a.outv[ti];
             E* __restrict__ o = (E*)at.out + (size_t)CZ * H * So + (size_t)cy0 * So + cx0;
@@ -630,26 +625,14 @@ __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a,
 #endif
     }
   };
-#if HF_WARP_PIPELINE
-  // (requesting the runs of two outputs ahead, or of all outputs up front, measured no faster: 52.8 / 53.8 us vs 49.9 us)
-  Src S0, S1;   // two register sets: no copies between the stages of the pipeline
-  issue(0, S0);
-  for (int ti = 0; ti < a.n_out; ti += 2) {
-    const bool more = ti + 1 < a.n_out;
-    if (more) issue(ti + 1, S1);
-    finish(ti, S0);
-    if (more) {
-      if (ti + 2 < a.n_out) issue(ti + 2, S0);
-      finish(ti + 1, S1);
-    }
-  }
-#else
-  for (int ti = 0; ti < a.n_out; ti++) {
+  // (software pipelining -- requesting the runs of output ti + 1, of two outputs ahead, or of all outputs before blending
+  //  output ti -- measured no faster since the dword-aligned loads: 49.9 / 52.8 / 53.8 us against 48.7 us for the plain
+  //  loop with its higher occupancy)
+  for (int ti = ti0; ti < ti1; ti++) {
     Src cur;
     issue(ti, cur);
     finish(ti, cur);
   }
-#endif
 }
 
 // Thread = VEC consecutive elements x ROWS consecutive rows that share one flow-cell row (ROWS
@@ -660,34 +643,51 @@ __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a,
 #endif
 // VB = bytes of output per thread and row: 16, or 8 for small frames (<= 1080p 8-bit), where 16-byte threads
 // leave too few waves to hide the per-wave latency chain (one round of fat waves: 9.4 us for 9.3 MB).
+// Wave tile = kWarpTX lanes x kWarpTY row groups: (16 x VEC) elements wide, (4 x ROWS) rows high -- at 2160p HDR 128 pixels
+// x 8 rows = 16 flow cells of one cell row.  (Round 1 used 64 lanes along x: 7.5 tiles per 3840-pixel row, of which the
+// first and the last contain lanes whose runs reach into the mirror zone of warpFrameKernelSDR.h:12-20, so 27 % of all
+// waves executed the per-element edge path next to the run path -- that, not the interior code, was most of the
+// 1,940 VALU instructions per wave.  With 128-pixel tiles 2 of 30 tiles per row are edge tiles.)
+constexpr int kWarpTX = 16, kWarpTY = 4;
 template <typename E, int GROUP, int ROWS, int MODE, int VB, bool DW>
-__global__ __launch_bounds__(64 * HF_WARP_WAVES) void warp_fast_kernel(const Geom g, const WarpBatchArgs batch, int y_groups) {
+__global__ __launch_bounds__(64 * HF_WARP_WAVES) void warp_fast_kernel(const Geom g, const WarpBatchArgs batch, int y_groups, int out_chunk, int n_chunks) {
     constexpr int VEC = VB / sizeof(E);
-    // row group: luma groups first, then chroma; one row group per wave => the plane test is a scalar branch
-    // Work decomposition: a wave tile = 64 lanes x VEC elements of one row group; tiles are numbered
-    // row-major (consecutive tiles = consecutive memory), a workgroup takes 4 consecutive tiles, and
-    // workgroups are dealt to the XCDs in contiguous bands: linear block id b runs on XCD b % 8
-    // (MI355X_MICROARCH.md "Workgroup dispatch"), so block b works on band (b % 8).  Measured on the
-    // 2160p HDR blend: 20.7 us with the naive 2-D grid (every XCD walks a 1 KB wide column stripe)
-    // -> 19.0 us banded.  Placement only affects speed.  Units are ordered (member, tile): with a batch every XCD
-    // works on whole members, i.e. each source frame is pulled into ONE L2.
-    const int wpr = (g.W + 64 * VEC - 1) / (64 * VEC);            // wave tiles per row group
-    const int n_tiles = wpr * (y_groups + ((g.H >> 1) + ROWS - 1) / ROWS);
+    // Work decomposition: tiles are numbered row-major (luma tile rows first, then chroma: the plane test is a scalar
+    // branch), a workgroup takes 4 consecutive tiles, and workgroups are dealt to the XCDs in contiguous bands: linear
+    // block id b runs on XCD b % 8 (MI355X_MICROARCH.md "Workgroup dispatch"), so block b works on band (b % 8).
+    // Measured on the 2160p HDR blend: 20.7 us with the naive 2-D grid (every XCD walks a column stripe) -> 19.0 us
+    // banded.  Placement only affects speed.  Units are ordered (member, tile block, chunk): with a batch every XCD works
+    // on whole members, i.e. each source frame is pulled into ONE L2.
+    const int uv_groups = ((g.H >> 1) + ROWS - 1) / ROWS;
+    const int wpr = (g.W + kWarpTX * VEC - 1) / (kWarpTX * VEC);            // wave tiles per tile row
+    const int y_tiles = (y_groups + kWarpTY - 1) / kWarpTY, uv_tiles = (uv_groups + kWarpTY - 1) / kWarpTY;
+    const int n_tiles = wpr * (y_tiles + uv_tiles);
     const int n_blocks = (n_tiles + HF_WARP_WAVES - 1) / HF_WARP_WAVES;   // per member
-    const int total = n_blocks * batch.n;
+    // out_chunk = outputs of the period one thread produces.  Large frames: all of them (the sources are read from HBM once);
+    // small frames: fewer, so that a period is n_chunks times as many, shorter waves -- their sources come from L2 anyway and
+    // a 1080p period has only ~3,000 wave tiles for 1,024 SIMDs.  The chunks of a tile run next to each other on one XCD.
+    const int total = n_blocks * n_chunks * batch.n;
     const int per_band = (total + 7) >> 3;
     const int u = (blockIdx.x & 7) * per_band + (blockIdx.x >> 3);
     if (u >= total) return;
-    const int member = u / n_blocks, blk = u - member * n_blocks;
+    const int chunk = u % n_chunks, v = u / n_chunks;
+    const int member = v / n_blocks, blk = v - member * n_blocks;
     const WarpArgs& a = batch.s[member];
+    const int ti0 = chunk * out_chunk, ti1 = min(a.n_out, ti0 + out_chunk);
+    if (ti0 >= ti1) return;
     const int tile = blk * HF_WARP_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (tile >= n_tiles) return;
-    const int rg = tile / wpr;
-    const int cx0 = ((tile - rg * wpr) * 64 + (threadIdx.x & 63)) * VEC;
-    const int uv_groups = ((g.H >> 1) + ROWS - 1) / ROWS;
-    if (rg >= y_groups + uv_groups || cx0 >= g.W) return;
-    if (rg >= y_groups) warp_fast_body<E, GROUP, ROWS, MODE, 1, VB, DW>(g, a, (rg - y_groups) * ROWS, cx0);
-    else warp_fast_body<E, GROUP, ROWS, MODE, 0, VB, DW>(g, a, rg * ROWS, cx0);
+    const int trow = tile / wpr, tcol = tile - trow * wpr;
+    const int lane = threadIdx.x & 63;
+    const int cx0 = (tcol * kWarpTX + (lane & (kWarpTX - 1))) * VEC;
+    if (cx0 >= g.W) return;
+    if (trow >= y_tiles) {
+        const int rg = (trow - y_tiles) * kWarpTY + (lane / kWarpTX);
+        if (rg < uv_groups) warp_fast_body<E, GROUP, ROWS, MODE, 1, VB, DW>(g, a, rg * ROWS, cx0, ti0, ti1);
+    } else {
+        const int rg = trow * kWarpTY + (lane / kWarpTX);
+        if (rg < y_groups) warp_fast_body<E, GROUP, ROWS, MODE, 0, VB, DW>(g, a, rg * ROWS, cx0, ti0, ti1);
+    }
 }
 
 template <typename E, int VEC, bool ALIGNED>
@@ -765,15 +765,22 @@ static bool launch_warp_fast(const Geom& g, const WarpBatchArgs& b, hipStream_t 
                          // (re-measured with the final kernel, fused period HBM-cold: 2 rows 51.1 us, 4 rows 59.3 us -- halving the
                          // per-element scalar work does not pay for halving the number of waves)
     const int y_groups = (g.H + rows - 1) / rows, uv_groups = ((g.H >> 1) + rows - 1) / rows;
-    const int wpr = (g.W + 64 * VEC - 1) / (64 * VEC);
-    const int n_blocks = (wpr * (y_groups + uv_groups) + HF_WARP_WAVES - 1) / HF_WARP_WAVES;
-    const dim3 fg(((n_blocks * b.n + 7) / 8) * 8);
+    const int wpr = (g.W + kWarpTX * VEC - 1) / (kWarpTX * VEC);
+    const int n_blocks = (wpr * ((y_groups + kWarpTY - 1) / kWarpTY + (uv_groups + kWarpTY - 1) / kWarpTY) + HF_WARP_WAVES - 1) / HF_WARP_WAVES;
+    int max_out = 1;
+    for (int m = 0; m < b.n; m++) max_out = b.s[m].n_out > max_out ? b.s[m].n_out : max_out;
+    // outputs per thread: everything for large frames; one for frames up to 1080p (measured, fused 5-output period, us:
+    // 1080p SDR 23.6 / 21.9 / 20.3 / 18.9 and 1080p HDR 19.0 / 19.1 with 6 / 3 / 2 / 1 outputs per thread; 2160p HDR
+    // 45.9 / 46.6 hot, 50.8 / 52.1 HBM-cold with 6 / 1)
+    const int out_chunk = (size_t)g.W * g.H * sizeof(E) <= (size_t)1920 * 1088 * 2 ? 1 : kMaxWarpOutputs;
+    const int n_chunks = (max_out + out_chunk - 1) / out_chunk;
+    const dim3 fg(((n_blocks * n_chunks * b.n + 7) / 8) * 8);
 #define HF_WARP_FAST(G, D)                                                                   \
     do {                                                                                     \
         /* ev0/ev1 (may be null): timestamps of the dispatch itself, like rocprof's kernel trace */ \
-        if (mode == 0) hipExtLaunchKernelGGL((warp_fast_kernel<E, G, 2, 0, VB, D>), fg, dim3(64 * HF_WARP_WAVES), 0, stream, ev0, ev1, 0, g, b, y_groups);      \
-        else if (mode == 1) hipExtLaunchKernelGGL((warp_fast_kernel<E, G, 2, 1, VB, D>), fg, dim3(64 * HF_WARP_WAVES), 0, stream, ev0, ev1, 0, g, b, y_groups); \
-        else hipExtLaunchKernelGGL((warp_fast_kernel<E, G, 2, 2, VB, D>), fg, dim3(64 * HF_WARP_WAVES), 0, stream, ev0, ev1, 0, g, b, y_groups);                  \
+        if (mode == 0) hipExtLaunchKernelGGL((warp_fast_kernel<E, G, 2, 0, VB, D>), fg, dim3(64 * HF_WARP_WAVES), 0, stream, ev0, ev1, 0, g, b, y_groups, out_chunk, n_chunks);      \
+        else if (mode == 1) hipExtLaunchKernelGGL((warp_fast_kernel<E, G, 2, 1, VB, D>), fg, dim3(64 * HF_WARP_WAVES), 0, stream, ev0, ev1, 0, g, b, y_groups, out_chunk, n_chunks); \
+        else hipExtLaunchKernelGGL((warp_fast_kernel<E, G, 2, 2, VB, D>), fg, dim3(64 * HF_WARP_WAVES), 0, stream, ev0, ev1, 0, g, b, y_groups, out_chunk, n_chunks);                  \
     } while (0)
 #define HF_WARP_GROUP(D)                                  \
     do {                                                  \
@@ -791,7 +798,7 @@ static bool launch_warp_fast(const Geom& g, const WarpBatchArgs& b, hipStream_t 
 // frames up to 1080p 8-bit: 8 bytes per thread (twice the waves); larger frames: 16 bytes per thread
 template <typename E>
 static bool launch_warp_fast_any(const Geom& g, const WarpBatchArgs& b, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
-    const bool small = (size_t)g.W * g.H * sizeof(E) <= (size_t)1920 * 1088;
+    const bool small = (size_t)g.W * g.H * sizeof(E) <= (size_t)1920 * 1088;   // (1080p SDR, 5-output period: 18.9 us with 8-byte threads, 26.8 us with 16-byte ones)
     if (small && launch_warp_fast<E, 8>(g, b, stream, ev0, ev1)) return true;
     return launch_warp_fast<E, 16>(g, b, stream, ev0, ev1);
 }
