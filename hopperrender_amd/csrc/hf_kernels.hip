@@ -381,6 +381,50 @@ __device__ __forceinline__ Run<E, GROUP> load_run_uv_dw(const unsigned char* __r
     return r;
 }
 
+// The same runs through BUFFER loads: resource descriptor (plane base, size) in SGPRs, a 32-bit byte offset per lane -- no
+// 64-bit address arithmetic on the vector ALU (the flat-pointer form spent v_mad_i64_i32 + v_lshl_add_u64 pairs on every
+// run), reads past the plane return 0 instead of faulting.  `off` = byte offset of the run's first element (luma) / of
+// the even element e (chroma); dword-aligned plane base required.
+typedef unsigned buf_v2 __attribute__((ext_vector_type(2)));
+typedef unsigned buf_v4 __attribute__((ext_vector_type(4)));
+template <int NDW>
+__device__ __forceinline__ void buffer_load_dwords(uint32_t* d, __amdgpu_buffer_rsrc_t rsrc, unsigned off) {
+    static_assert(NDW == 1 || NDW == 2 || NDW == 4, "dword, dwordx2 or dwordx4");
+    if constexpr (NDW == 4) {
+        const buf_v4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    } else if constexpr (NDW == 2) {
+        const buf_v2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0);
+        d[0] = v.x; d[1] = v.y;
+    } else {
+        d[0] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0);
+    }
+}
+template <typename E, int G, int CZ>
+__device__ __forceinline__ Run<E, G> get_run_buf(__amdgpu_buffer_rsrc_t rsrc, unsigned off, unsigned odd) {
+    constexpr int NDW = G * (int)sizeof(E) / 4;
+    const unsigned sh = (off & 3u) * 8u, base = off & ~3u;
+    uint32_t w[NDW + 1];
+    buffer_load_dwords<NDW>(w, rsrc, base);
+    w[NDW] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, base + 4u * NDW, 0, 0);
+    uint32_t o[NDW];
+    if constexpr (CZ == 0) {
+#pragma unroll
+        for (int j = 0; j < NDW; j++) o[j] = __builtin_amdgcn_alignbit(w[j + 1], w[j], sh);
+    } else {
+        uint32_t L[NDW + 1];
+#pragma unroll
+        for (int j = 0; j < NDW; j++) L[j] = __builtin_amdgcn_alignbit(w[j + 1], w[j], sh);
+        L[NDW] = w[NDW] >> sh;
+        const uint32_t sel = sizeof(E) == 2 ? (odd ? 0x07060100u : 0x03020100u) : (odd ? 0x05020300u : 0x03020100u);
+#pragma unroll
+        for (int j = 0; j < NDW; j++) o[j] = __builtin_amdgcn_perm(L[j + 1], L[j], sel);
+    }
+    Run<E, G> r;
+    __builtin_memcpy(r.v, o, sizeof(o));
+    return r;
+}
+
 // mirrorCoordinate without branches (same values as mirror_warp): low side max(p, 1 - p), high side min(., 2d - 4 - p)
 __device__ __forceinline__ int mirror_warp_bl(int pos, int dim) {
     const int r = min(max(pos, 1 - pos), 2 * dim - 4 - pos);
@@ -434,6 +478,12 @@ __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a,
     const E* __restrict__ B = (const E*)a.frame21 + (size_t)CZ * H * Si;
     const int ly = CZ ? ((cy0 >> rs) << 1) : (cy0 >> rs);    // same for all ROWS rows
     constexpr bool need_a = MODE != 1, need_b = MODE != 0;
+    // interior waves fetch their runs through buffer loads (32-bit offsets into the plane)
+    constexpr bool BUF = DW && GROUP * sizeof(E) >= 4;
+    const unsigned pitch_b = (unsigned)Si * (unsigned)sizeof(E);
+    const unsigned plane_bytes = (unsigned)dim_y * pitch_b;
+    const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)plane_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (int)plane_bytes, 0x00020000);
 
     // flow of the thread's cells: looked up once, shared by every output of the period
     int ox12[NG], oy12[NG], ox21[NG], oy21[NG];
@@ -495,6 +545,45 @@ __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a,
         if (need_b) y_inside = y_inside && cy_lo + dyb[k] >= 1 && cy_hi + dyb[k] <= dim_y - 2;
     }
     const bool all_y_inside = __builtin_amdgcn_ballot_w64(!y_inside) == 0;
+    if constexpr (BUF) if (all_y_inside && __builtin_amdgcn_ballot_w64(!interior) == 0) {
+        // the common case, wave-uniform: every run of every lane lies where mirrorCoordinate is the identity in x and y
+        const bool one_run = NG > 1 && __builtin_amdgcn_ballot_w64(!merged) == 0;
+        const unsigned row1 = (cy0 + 1 < dim_y) ? pitch_b : 0u;     // ROWS == 2; a row past the plane end re-reads the last row (not stored)
+        static_assert(ROWS == 2, "row1");
+        if (one_run) {
+            const unsigned oa = __umul24((unsigned)(cy0 + dya[0]), pitch_b) + (unsigned)(CZ ? (xa[0] & ~1) : xa[0]) * (unsigned)sizeof(E);
+            const unsigned ob = __umul24((unsigned)(cy0 + dyb[0]), pitch_b) + (unsigned)(CZ ? (xb[0] & ~1) : xb[0]) * (unsigned)sizeof(E);
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) {
+                if (need_a) {
+                    const Run<E, VEC> w = get_run_buf<E, VEC, CZ>(rsrcA, oa + (r ? row1 : 0u), (unsigned)xa[0] & 1u);
+#pragma unroll
+                    for (int k = 0; k < NG; k++)
+#pragma unroll
+                        for (int i = 0; i < GROUP; i++) S.ra[r][k].v[i] = w.v[k * GROUP + i];
+                }
+                if (need_b) {
+                    const Run<E, VEC> w = get_run_buf<E, VEC, CZ>(rsrcB, ob + (r ? row1 : 0u), (unsigned)xb[0] & 1u);
+#pragma unroll
+                    for (int k = 0; k < NG; k++)
+#pragma unroll
+                        for (int i = 0; i < GROUP; i++) S.rb[r][k].v[i] = w.v[k * GROUP + i];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NG; k++) {
+                const unsigned oa = __umul24((unsigned)(cy0 + dya[k]), pitch_b) + (unsigned)(CZ ? (xa[k] & ~1) : xa[k]) * (unsigned)sizeof(E);
+                const unsigned ob = __umul24((unsigned)(cy0 + dyb[k]), pitch_b) + (unsigned)(CZ ? (xb[k] & ~1) : xb[k]) * (unsigned)sizeof(E);
+#pragma unroll
+                for (int r = 0; r < ROWS; r++) {
+                    if (need_a) S.ra[r][k] = get_run_buf<E, GROUP, CZ>(rsrcA, oa + (r ? row1 : 0u), (unsigned)xa[k] & 1u);
+                    if (need_b) S.rb[r][k] = get_run_buf<E, GROUP, CZ>(rsrcB, ob + (r ? row1 : 0u), (unsigned)xb[k] & 1u);
+                }
+            }
+        }
+        return;
+    }
     auto row_of = [&](const int p) { return all_y_inside ? p : mirror_warp_bl(p, dim_y); };
     if (NG > 1 && __builtin_amdgcn_ballot_w64(!(interior && merged)) == 0) {
 #pragma unroll
