@@ -160,3 +160,36 @@ def test_deliver_in_the_library_equals_the_step_by_step_replay(native_lib, hdr):
     assert kinds_all == [k for k, _ in step.log]
     assert "copy" in kinds_all[12:] and "warp" in kinds_all     # the cut produced copies after the warm-up frames
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("cut_at", [20, 27, 14])
+def test_sharded_timeline_equals_the_sequential_run(native_lib, cut_at):
+    """hopperrender_amd/batch.py: a clip cut into contiguous chunks for 3 ranks reproduces the sequential filter output
+    for output -- including the scene-change decision, whose delta history a chunk rebuilds by replaying the flow of
+    the 12 periods before its first one (no exchange between ranks).  cut_at 27 / 14: the cut sits right at a chunk
+    border (chunks start at periods 0, 14, 27), so the decisive deltas belong to the preceding rank's periods."""
+    from hopperrender_amd import batch
+    from hopperrender_amd.calc import OpticalFlowCalcSDR
+    from hopperrender_amd.protocol import SOURCE_24, TARGET_60, FilterReplay
+    H, W, n, world, thr = 180, 320, 40, 3, 150
+    frames = cut_clip(H, W, 0, cut_at, n - cut_at, seed=5)
+    seq = OpticalFlowCalcSDR(H, W, search_radius=8)
+    replay = FilterReplay(seq, SOURCE_24, TARGET_60, scene_change_threshold=thr)
+    want = []
+    for f in frames:
+        want += [o.copy() for o in replay.deliver(f)]
+    want_kinds = [k for k, _ in replay.log]
+    assert "copy" in want_kinds[6:], "the clip must contain a detected scene change"
+    got, got_kinds = [], []
+    for rank in range(world):
+        chunk = batch.shard_timeline(n, world, rank, SOURCE_24, TARGET_60)
+        c = OpticalFlowCalcSDR(H, W, search_radius=8)
+        outs, kinds = batch.run_chunk(c, chunk, frames, scene_change_threshold=thr)
+        assert chunk.first_output == len(got)
+        got += outs; got_kinds += kinds
+        c.close()
+    assert got_kinds == want_kinds
+    assert len(got) == len(want)
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert (a == b).all(), i
+    seq.close()

@@ -72,7 +72,13 @@ def test_sharding_plans():
     chunks = [batch.shard_timeline(100, 8, r) for r in range(8)]
     assert sum(c.n_periods for c in chunks) == 100
     assert chunks[0].first_period == 0 and all(chunks[i].first_period == chunks[i - 1].first_period + chunks[i - 1].n_periods for i in range(1, 8))
-    assert chunks[3].first_frame == chunks[3].first_period - 3
+    assert chunks[3].first_frame == chunks[3].first_period - 3 - batch.DELTA_HISTORY      # ring + previous flow + delta history
+    assert batch.shard_timeline(100, 8, 3, delta_history=0).first_frame == chunks[3].first_period - 3
+    sched = BlendSchedule(SOURCE_24, TARGET_60)
+    for k in range(chunks[5].first_period):
+        for _ in range(sched.begin_source_frame()):
+            sched.next_scalar()
+    assert chunks[5].blend_at_start == sched.blend
     total = sum(len(s) for c in chunks for s in c.scalars)
     assert total == sum(len(x) for x in BlendSchedule(SOURCE_24, TARGET_60).plan(100))
     assert chunks[5].first_output == sum(len(s) for c in chunks[:5] for s in c.scalars)

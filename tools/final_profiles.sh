@@ -1,14 +1,23 @@
 #!/bin/bash
-# tools/final_profiles.sh TAG -- the measurements the round's profiles/ are made from (run on the GPU box)
-TAG=${1:-r01}
-export TMPDIR=/tmp; R=$PWD; O=$R/gpurun_out/$TAG; mkdir -p $O
-python bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -c 600 $O/bench_default.json
-python bench.py --workload sdr1080_24to60 --no-reference > $O/bench_sdr1080.json 2>/dev/null
+# tools/final_profiles.sh TAG -- the measurements the round's profiles/ are made from (run on the GPU box):
+#   default bench lines (HDR 2160p, SDR 1080p), rocprofv3 kernel stats of the same commands and of one stream alone,
+#   PMC FETCH_SIZE / WRITE_SIZE passes of the fused period warp (one launch at a time), stand-alone kernel times.
+TAG=${1:-r02}
+export TMPDIR=/tmp; R=$PWD; O=$R/gpurun_out/$TAG; rm -rf $O; mkdir -p $O
+python bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -c 400 $O/bench_default.json; echo
+python bench.py --workload sdr1080_24to60 --no-reference > $O/bench_sdr1080.json 2> $O/bench_sdr1080.err
+python tools/microbench.py > $O/microbench.txt 2>&1
+python tools/microbench.py --hdr 0 --H 1080 --W 1920 >> $O/microbench.txt 2>&1
+python tools/chain_time.py --batch 1 2 4 8 >> $O/microbench.txt 2>&1
+python tools/chain_time.py --batch 1 8 --hdr 0 --H 1080 --W 1920 >> $O/microbench.txt 2>&1
 cd /tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_default -o p -- python3 $R/bench.py --no-cpu-baseline --no-reference > $O/bench_default_under_rocprof.json 2>/dev/null
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_streams1 -o p -- python3 $R/bench.py --streams 1 --batch 1 --steps 40 --no-cpu-baseline --no-reference > /dev/null 2>&1
-for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -o p -- python3 $R/bench.py --streams 1 --batch 1 --steps 20 --warmup 5 --no-profile --no-cpu-baseline --no-reference > /dev/null 2>&1
-  echo "pmc $c rc=$?"
-done
+Q="--no-cpu-baseline --no-reference --no-host-io"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_default -o p -- python3 $R/bench.py $Q > $O/bench_default_under_rocprof.json 2>/dev/null
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_sdr1080 -o p -- python3 $R/bench.py --workload sdr1080_24to60 $Q > $O/bench_sdr1080_under_rocprof.json 2>/dev/null
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_streams1 -o p -- python3 $R/bench.py --streams 1 --batch 1 --steps 2 --periods-per-step 20 $Q > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_chain8 -o p -- python3 $R/tools/chain_time.py --batch 8 --n 50 > /dev/null 2>&1
+for wl in hdr2160_24to120 sdr1080_24to60; do for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_${wl}_$c -o p -- python3 $R/bench.py --workload $wl --streams 1 --batch 1 --steps 2 --warmup 1 --periods-per-step 12 --no-profile $Q > /dev/null 2>&1
+  echo "pmc $wl $c rc=$?"
+done; done
 ls $O

@@ -1,0 +1,72 @@
+"""tools/pmc_traffic.py -- profiles/roofline_traffic.json from rocprofv3 PMC passes (generate it, do not type it).
+
+    python tools/pmc_traffic.py <workload> <fetch_csv> <write_csv> [--out profiles/roofline_traffic.json]
+
+<fetch_csv> / <write_csv>: the *_counter_collection.csv of two separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`
+passes over the same command (bench.py --streams 1 --batch 1 --no-profile: one fused period launch at a time).
+Corrections per /opt/skills/guides/MI355X_MICROARCH.md "HBM": the counters are in KiB; on gfx950 FETCH_SIZE reports half the
+bytes of wide coalesced reads (16 B per lane) -> doubled; WRITE_SIZE is exact for 16-byte streaming stores.
+The entry describes the dominant kernel: the fused period launch with the most output frames."""
+import argparse
+import collections
+import csv
+import json
+import os
+
+
+def per_kernel(path, counter):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            acc[(r["Kernel_Name"], int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
+    return acc
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("workload"); ap.add_argument("fetch_csv"); ap.add_argument("write_csv")
+    ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "roofline_traffic.json"))
+    ap.add_argument("--kernel", default="warp_fast_kernel")
+    ap.add_argument("--units-per-launch", type=float, default=0.0, help="output frames of the launches selected (0: take it from --frames-by-write)")
+    ap.add_argument("--frame-bytes", type=int, default=0, help="bytes of one output frame: units per launch = WRITE_SIZE / frame bytes")
+    a = ap.parse_args()
+    f = {k: v for k, v in per_kernel(a.fetch_csv, "FETCH_SIZE").items() if a.kernel in k[0]}
+    w = {k: v for k, v in per_kernel(a.write_csv, "WRITE_SIZE").items() if a.kernel in k[0]}
+    if not f or not w:
+        raise SystemExit("no %s dispatches in the CSVs" % a.kernel)
+    # several launch shapes of the same kernel may appear (5- and 6-output periods share a grid): bucket by written bytes
+    name, grid = max(w, key=lambda k: sum(w[k]) / len(w[k]))
+    wv, fv = w[(name, grid)], f[(name, grid)]
+    units = None
+    if a.frame_bytes:
+        by_units = collections.defaultdict(list)
+        for x in wv:
+            by_units[round(x * 1024 / a.frame_bytes)].append(x)
+        units = max(by_units)                      # the launches with the most output frames
+        wv = by_units[units]
+    write_kib = sum(wv) / len(wv)
+    fetch_kib = sum(fv) / len(fv)
+    entry = {
+        "warp_kernel_hbm_bytes_per_launch": int(round((2 * fetch_kib + write_kib) * 1024)),
+        "units_per_launch": units if units is not None else a.units_per_launch,
+        "kernel": name, "grid_size": grid,
+        "FETCH_SIZE_KiB_mean": round(fetch_kib, 1), "WRITE_SIZE_KiB_mean": round(write_kib, 1),
+        "dispatches": {"fetch_pass": len(fv), "write_pass": len(wv)},
+        "corrections": "FETCH_SIZE x 2 (gfx950 tallies 128-byte read requests of wide coalesced loads at 64 B), KiB -> bytes; WRITE_SIZE exact",
+        "files": [os.path.relpath(a.fetch_csv), os.path.relpath(a.write_csv)],
+        "note": "FETCH_SIZE is averaged over all launches of the shape (5- and 6-output periods read the same two source frames); "
+                "WRITE_SIZE over the launches with the most output frames",
+    }
+    data = {}
+    if os.path.exists(a.out):
+        try:
+            data = json.load(open(a.out))
+        except Exception:
+            data = {}
+    data[a.workload] = entry
+    json.dump(data, open(a.out, "w"), indent=1)
+    print(json.dumps({a.workload: entry}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
