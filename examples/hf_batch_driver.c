@@ -1,5 +1,6 @@
 /* examples/hf_batch_driver.c -- a throughput driver written against the C ABI only (include/hopperflow.h):
- * two independent NV12 clips, one flow batch, device-resident frames, fused period warps.
+ * two independent NV12 clips, one hf_batch, device-resident frames: per source period ONE phase-plane launch, ONE batched
+ * refinement chain and ONE fused warp launch for both clips.
  *
  *   gcc -std=c11 -Iinclude examples/hf_batch_driver.c -Lhopperrender_amd/lib -lhopperflow -Wl,-rpath,$PWD/hopperrender_amd/lib -o hf_batch_driver
  *   ./hf_batch_driver [periods]
@@ -72,11 +73,20 @@ int main(int argc, char** argv) {
     for (int c = 0; c < CLIPS; c++)                       /* prime the ring with the first two frames */
         for (int k = 0; k < 2; k++) CHECK(hf_update_frame_device_ref(ctx[c], src[c * n_frames + k]));
 
+    int n_out[CLIPS];
+    float ts[CLIPS][HF_MAX_PERIOD_OUTPUTS];
+    void* outs[CLIPS][HF_MAX_PERIOD_OUTPUTS];
+    memset(outs, 0, sizeof(outs));
+    for (int c = 0; c < CLIPS; c++) {
+        n_out[c] = NOUT;
+        for (int i = 0; i < NOUT; i++) { ts[c][i] = t[i]; outs[c][i] = out[c][i]; }
+    }
     for (int p = 0; p < periods; p++) {
-        for (int c = 0; c < CLIPS; c++) CHECK(hf_update_frame_device_ref(ctx[c], src[c * n_frames + p + 2]));
-        CHECK(hf_batch_calculate_optical_flow(batch));    /* both clips' flow calculations in one set of launches */
-        for (int c = 0; c < CLIPS; c++)
-            CHECK(hf_interpolate_period_ex(ctx[c], NULL, NOUT, t, out[c], 2, /*update_and_flow=*/0));
+        const void* next[CLIPS];
+        for (int c = 0; c < CLIPS; c++) next[c] = src[c * n_frames + p + 2];
+        CHECK(hf_batch_update_frames_device_ref(batch, next));   /* updateFrame of both clips, one phase-plane launch */
+        CHECK(hf_batch_calculate_optical_flow(batch));            /* both clips' flow calculations in one set of launches */
+        CHECK(hf_batch_interpolate_period(batch, n_out, &ts[0][0], &outs[0][0], 2));   /* all outputs of both clips: one launch */
         for (int c = 0; c < CLIPS; c++) {
             CHECK(hf_sync(ctx[c]));
             hf_stats st;

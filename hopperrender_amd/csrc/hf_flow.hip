@@ -244,42 +244,84 @@ __device__ __forceinline__ Strip<PX> load_strip(const Geom& g, const FlowStep& a
     return s;
 }
 
-// sad[cz] = sum over the strip of |dY| + |dU| + |dV| for candidate cz of `axis` (0 for cz >= R)
+// PX consecutive elements through a BUFFER load: resource (plane base + size) in SGPRs, `voff` = per-lane byte offset,
+// `soff` = wave-uniform byte offset (scalar register, costs no vector instruction).
+typedef unsigned flow_v2 __attribute__((ext_vector_type(2)));
+typedef unsigned flow_v4 __attribute__((ext_vector_type(4)));
 template <int PX>
+__device__ __forceinline__ Elems<PX> buffer_elems(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+    Elems<PX> r;
+    if constexpr (PX == 4) {
+        const flow_v4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
+        r.d[0] = v.x; r.d[1] = v.y; r.d[2] = v.z; r.d[3] = v.w;
+    } else {
+        const flow_v2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, 0);
+        r.d[0] = v.x; r.d[1] = v.y;
+    }
+    return r;
+}
+
+// sad[cz] = sum over the strip of |dY| + |dU| + |dV| for candidate cz of `axis` (0 for cz >= R).
+// The plane offset of a candidate splits into a per-LANE part (the strip's own row / column) and a per-WINDOW part (what
+// the candidate offset adds): X step  lane: row(sy + oy) * row_el + mx + cx0      window: (ph >> 1) * lwp + (c >> rs)
+//                             Y step  lane: sy * row_el + (ph0 >> 1) * lwp + mx + j0   window: c * row_el
+// with c = searched offset + rel(cz) (sx = cx0 << rs is a multiple of 2^rs, so (sx + c) >> rs = cx0 + (c >> rs) and the
+// phase is c's alone).  UNI (every lane of the wave lies in ONE window: windows >= 16): the window part is wave-uniform
+// -- it is computed on the scalar unit and rides in the load's scalar offset, so a candidate costs no address arithmetic
+// on the vector ALU at all (round 1: ~13 of the ~36 VALU instructions per candidate).  Otherwise it is per lane.
+// (The reference does this arithmetic in 16-bit, calcDeltaSumsKernelSDR.h:75-76; offsets are bounded by
+//  iterations * 64 + 64 < 2^15, so nothing ever wraps.)
+template <int PX, bool UNI>
 __device__ __forceinline__ void strip_sads(uint32_t* sad, const Geom& g, const FlowStep& a, const Strip<PX>& s,
                                            int ox, int oy, int axis) {
     const PhaseLayout& pl = a.pl;
-    const int sx = s.cx0 << g.rs, sy = s.cy << g.rs;
-    const int searched0 = axis ? oy : ox;
+    const int sy = s.cy << g.rs;
     const bool ragged = (g.lw & (PX - 1)) != 0;                       // kernel-uniform: some strip hangs over the right grid edge
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.pp1, 0, (int)pl.bytes, 0x00020000);
+    if (UNI) { ox = __builtin_amdgcn_readfirstlane(ox); oy = __builtin_amdgcn_readfirstlane(oy); }
+    const int searched0 = axis ? oy : ox;
+    const unsigned row_el = (unsigned)(pl.nph2 * pl.lwp);             // elements per full-res row
     Elems<PX> c1[16];
     uint32_t sel[16];
-    // 32-bit element offsets into the plane (a plane is < 2^31 elements), split by axis: an X step keeps the
-    // row (ny) and varies phase + column, a Y step keeps phase + column and varies the row -- the invariant half of
-    // the address is computed once per strip instead of once per candidate.
-    const int row_el = pl.nph2 * pl.lwp;                              // elements per full-res row
-    const int ny0 = mirror_clamp(sy + oy, g.H);                       // X step: the row
-    const int nx0 = sx + ox;                                          // Y step: the column
-    const int j0 = clampi(nx0 >> g.rs, -pl.mx, g.lw + pl.mx), ph0 = nx0 & (pl.nph - 1);
-    const int fix = axis ? (ph0 >> 1) * pl.lwp + pl.mx + j0 : ny0 * row_el + pl.mx;
+    if (!axis) {
+        // (the margin mx goes into the window part: it keeps that part >= 0, as a scalar buffer offset has to be)
+        const unsigned lane_off = (__umul24((unsigned)mirror_clamp(sy + oy, g.H), row_el) + (unsigned)s.cx0) * 4u;
 #pragma unroll
-    for (int cz = 0; cz < 16; cz++) {
-        if (cz < a.R && s.any) {                                  // R is uniform
-            const int cand = (int)(int16_t)(searched0 + rel_offset(cz, a.R));  // short arithmetic, :75-76
-            int off, par;
-            if (axis) {
-                const int ny = mirror_clamp(sy + cand, g.H);
-                off = ny * row_el + fix;
-                par = ph0 & 1;
-            } else {
-                const int nx = sx + cand;
-                const int j = clampi(nx >> g.rs, -pl.mx, g.lw + pl.mx);        // never clamps: |offset| <= margin by construction
-                const int ph = nx & (pl.nph - 1);
-                off = (ph >> 1) * pl.lwp + j + fix;
-                par = ph & 1;
+        for (int cz = 0; cz < 16; cz++) {
+            if (cz < a.R && s.any) {                                  // R is uniform
+                const int c = searched0 + rel_offset(cz, a.R);
+                const int ph = c & (pl.nph - 1);
+                const unsigned coff = (unsigned)((ph >> 1) * pl.lwp + (c >> g.rs) + pl.mx) * 4u;
+                c1[cz] = UNI ? buffer_elems<PX>(rsrc, lane_off + 0u, coff) : buffer_elems<PX>(rsrc, lane_off + coff, 0u);
+                sel[cz] = 0x03020c00u | (unsigned)(ph & 1);           // v_perm_b32: luma byte of this phase, 0, U, V
             }
-            c1[cz] = load_elems<PX>(a.pp1 + (unsigned)off);
-            sel[cz] = 0x03020c00u | (unsigned)par;                // v_perm_b32: luma byte of this phase, 0, U, V
+        }
+    } else {
+        const int ph0 = ox & (pl.nph - 1);
+        const unsigned col = (unsigned)((ph0 >> 1) * pl.lwp + pl.mx + s.cx0 + (ox >> g.rs));
+        const unsigned selc = 0x03020c00u | (unsigned)(ph0 & 1);
+        // rows: the reflection of calcDeltaSumsKernelSDR.h:86-95 only acts within 64 rows of the frame edge
+        const int cmin = searched0 + rel_offset(0, a.R), cmax = searched0 + rel_offset(a.R - 1, a.R);
+        const bool inside = !s.any || (sy + cmin >= 0 && sy + cmax <= g.H - 1);
+        if (__builtin_amdgcn_ballot_w64(!inside) == 0) {
+            const unsigned lane_off = (__umul24((unsigned)(sy + cmin), row_el) + col) * 4u;   // row of the lowest candidate
+#pragma unroll
+            for (int cz = 0; cz < 16; cz++) {
+                if (cz < a.R && s.any) {
+                    const unsigned coff = __umul24((unsigned)(rel_offset(cz, a.R) - rel_offset(0, a.R)), row_el) * 4u;   // >= 0, wave-uniform
+                    c1[cz] = buffer_elems<PX>(rsrc, lane_off, coff);
+                    sel[cz] = selc;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int cz = 0; cz < 16; cz++) {
+                if (cz < a.R && s.any) {
+                    const int ny = mirror_clamp(sy + searched0 + rel_offset(cz, a.R), g.H);
+                    c1[cz] = buffer_elems<PX>(rsrc, (__umul24((unsigned)ny, row_el) + col) * 4u, 0u);
+                    sel[cz] = selc;
+                }
+            }
         }
     }
 #pragma unroll
@@ -517,7 +559,7 @@ __global__ __launch_bounds__(SPLIT ? 64 : 256) void flow_level_small_kernel(cons
 #pragma unroll
     for (int axis = 0; axis < 2; axis++) {
         uint32_t sad[16];
-        strip_sads<PX>(sad, g, a, strip, off[0], off[1], axis);
+        strip_sads<PX, G == 64>(sad, g, a, strip, off[0], off[1], axis);
         int first = group_reduce<G>(sad, lane);
         if constexpr (WS == 32) {   // four waves share the window
             if ((lane & 3) == 0) s_part[axis][wave][first] = sad[0];
@@ -567,7 +609,7 @@ __global__ __launch_bounds__(64 * WPB) void flow_big_partial_kernel(const Geom g
     }
     const Strip<4> strip = load_strip<4>(g, a, cx0, cy);
     uint32_t sad[16];
-    strip_sads<4>(sad, g, a, strip, ox, oy, a.axis);
+    strip_sads<4, true>(sad, g, a, strip, ox, oy, a.axis);
     const int first = group_reduce<64>(sad, lane);
     uint32_t* dst = &a.sums[(wy * a.cur.nwx + wx) * 16];
     if constexpr (WPB == 1) {
