@@ -159,65 +159,23 @@ def reference_opencl(hdr, H, W, target, radius, neighbor, frames):
                     "back-to-back calculateOpticalFlow / warpFrames calls, no host transfers"}
 
 
-def host_io_block(cls, H, W, target, radius, neighbor, frames, dev, n_periods=24):
-    """PCIe-inclusive rates of ONE context fed from and read back into host memory (never the bench `value`):
-    the reference's blocking protocol with pageable and with pinned buffers, and the asynchronous variant
-    (hf_update_frame_async / hf_download_frame_async: pinned buffers, H2D and D2H on side streams)."""
-    import numpy as np
-    from hopperrender_amd import capi
-    from hopperrender_amd.calc import PinnedArray
-    from hopperrender_amd.protocol import SOURCE_24, BlendSchedule
-    res = {}
-    plan = BlendSchedule(SOURCE_24, target).plan(n_periods + 4)
-    for pinned in (False, True):
-        c = cls(H, W, 0, 0, 8, neighbor, 0.0, 255.0, 270, device_index=dev, search_radius=radius)
-        n_el = c.output_frame_bytes // np.dtype(c.dtype).itemsize
-        pins = []
-        if pinned:
-            pins = [PinnedArray(f.size, c.dtype) for f in frames[:4]]
-            for p, f in zip(pins, frames):
-                p.array[:] = f
-            src = [p.array for p in pins]
-            outp = PinnedArray(n_el, c.dtype); out = outp.array; pins.append(outp)
-        else:
-            src, out = frames[:4], np.empty(n_el, c.dtype)
-        for k in range(3):
-            c.updateFrame(src[k])
-        c.calculateOpticalFlow()
-        t0 = time.perf_counter(); nout = 0
-        for i in range(n_periods):
-            c.updateFrame(src[i % 4]); c.calculateOpticalFlow()
-            for t in plan[i + 3]:
-                c.warpFrames(t, 2); c.downloadFrame(out); nout += 1
-        dt = time.perf_counter() - t0
-        res["blocking_pinned" if pinned else "blocking_pageable"] = {"frames_per_s": round(nout / dt, 1), "d2h_GB_per_s": round(nout * c.output_frame_bytes / dt / 1e9, 2)}
-        c.close()
-        for p in pins:
-            p.free()
-    c = cls(H, W, 0, 0, 8, neighbor, 0.0, 255.0, 270, device_index=dev, search_radius=radius, flags=capi.HF_FLAG_ASYNC | capi.HF_FLAG_DUAL_STREAM)
-    n_el = c.output_frame_bytes // np.dtype(c.dtype).itemsize
-    ins = [PinnedArray(f.size, c.dtype) for f in frames[:4]]
-    for p, f in zip(ins, frames):
-        p.array[:] = f
-    outs = [PinnedArray(n_el, c.dtype) for _ in range(8)]
-    for k in range(3):
-        c.updateFrameAsync(ins[k])
-    c.calculateOpticalFlow(); c.sync()
-    t0 = time.perf_counter(); nout = 0
-    for i in range(n_periods):
-        c.updateFrameAsync(ins[i % 4]); c.calculateOpticalFlow()
-        for t in plan[i + 3]:
-            c.warpFrames(t, 2); c.downloadFrameAsync(outs[nout % 8]); nout += 1
-        if i % 2 == 1:
-            c.sync()     # bound the number of in-flight host buffers (8 outputs here)
-    c.sync(); dt = time.perf_counter() - t0
-    res["async_pinned_side_streams"] = {"frames_per_s": round(nout / dt, 1), "d2h_GB_per_s": round(nout * c.output_frame_bytes / dt / 1e9, 2),
-                                       "h2d_GB_per_s": round(n_periods * c.input_frame_bytes / dt / 1e9, 2)}
-    c.close()
-    for p in ins + outs:
-        p.free()
-    res["note"] = (f"one context, {n_periods} source periods, frames enter and leave through host memory (PCIe Gen5 x16); "
-                   "output frames returned to the host; never the bench `value`")
+def host_io_block(hdr, H, W, target, n_periods=24):
+    """PCIe-inclusive rates of ONE context fed from and read back into host memory (never the bench `value`): the
+    reference's blocking protocol with pageable and with pinned buffers, and the asynchronous variant
+    (hf_update_frame_async / hf_download_frame_async: pinned buffers, H2D and D2H on side streams).  Measured by
+    tools/host_io_rate.py in a CHILD process: this process still holds its pair streams, and HIP deals all streams of a
+    process onto a handful of hardware queues (the four streams of an asynchronous context would share queues with them:
+    1080p SDR 3.0 k instead of 8.6-9.0 k frames/s)."""
+    import subprocess
+    env = dict(os.environ)
+    env.pop("GPU_MAX_HW_QUEUES", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "host_io_rate.py"), "--hdr", str(hdr), "--H", str(H), "--W", str(W),
+                        "--target", str(target), "--n", str(n_periods)], capture_output=True, text=True, timeout=600, env=env)
+    if r.returncode != 0:
+        return {"error": r.stderr[-400:]}
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    res["note"] = (f"one context, {n_periods} source periods, frames enter and leave through host memory (PCIe Gen5 x16), every output "
+                   "frame returned to the host; child process; never the bench `value`")
     return res
 
 
@@ -492,7 +450,7 @@ def main():
         }
         if not a.no_host_io and world == 1:
             try:
-                out["host_io"] = host_io_block(cls, H, W, target, a.radius, a.neighbor, host_frames, dev)
+                out["host_io"] = host_io_block(hdr, H, W, target)
             except Exception as e:
                 out["host_io"] = {"error": repr(e)}
         if not a.no_cpu_baseline and world == 1:   # reported baselines: rank 0 at N = 1 only

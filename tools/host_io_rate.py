@@ -1,4 +1,4 @@
-"""tools/host_io_rate.py -- PCIe-INCLUSIVE rate of the reference's blocking protocol (never bench.py's `value`):
+"""tools/host_io_rate.py -- PCIe-INCLUSIVE rates (never bench.py's `value`; bench.py runs this as a child for its `host_io` block):
 updateFrame(host) -> calculateOpticalFlow -> per output frame warpFrames + downloadFrame(host), one context."""
 import argparse, json, os, sys, time
 import numpy as np
@@ -32,7 +32,7 @@ for pinned in (False, True):
         for t in plan[i + 3]:
             c.warpFrames(t, 2); c.downloadFrame(out); nout += 1
     dt = time.perf_counter() - t0
-    res["pinned" if pinned else "pageable"] = {"frames_per_s": round(nout / dt, 1), "GB_per_s_d2h": round(nout * c.output_frame_bytes / dt / 1e9, 2)}
+    res["blocking_pinned" if pinned else "blocking_pageable"] = {"frames_per_s": round(nout / dt, 1), "d2h_GB_per_s": round(nout * c.output_frame_bytes / dt / 1e9, 2)}
     c.close()
 # asynchronous pipeline: uploads/readbacks on side streams, pinned buffers, nothing blocks until the end
 from hopperrender_amd import capi
@@ -51,6 +51,7 @@ for i in range(a.n):
         c.warpFrames(t, 2); c.downloadFrameAsync(outs[nout % 8]); nout += 1
     if i % 2 == 1: c.sync()     # bound the number of in-flight host buffers (8 outputs here)
 c.sync(); dt = time.perf_counter() - t0
-res["async_pinned_side_streams"] = {"frames_per_s": round(nout / dt, 1), "GB_per_s_d2h": round(nout * c.output_frame_bytes / dt / 1e9, 2)}
+res["async_pinned_side_streams"] = {"frames_per_s": round(nout / dt, 1), "d2h_GB_per_s": round(nout * c.output_frame_bytes / dt / 1e9, 2),
+                                    "h2d_GB_per_s": round(a.n * c.input_frame_bytes / dt / 1e9, 2)}
 c.close()
 print(json.dumps(res))
