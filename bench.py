@@ -82,6 +82,9 @@ def parse_args():
                     help="bracket every n-th warp launch / flow chain with HIP events (event records perturb back-to-back launches)")
     ap.add_argument("--diagnose", default="", choices=["", "no-flow", "no-warp"],
                     help="NOT a benchmark: drop the flow chain or the warps from the step to see what the other part costs")
+    ap.add_argument("--pg-first", action="store_true",
+                    help="A-B: create the process group (a single-rank RCCL communicator when not launched by torchrun) BEFORE the "
+                         "batch streams, to see what the communicator's streams do to the hardware-queue layout")
     ap.add_argument("--no-profile", action="store_true", help="no per-kernel HIP events in the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference", action="store_true")
@@ -181,6 +184,7 @@ def host_io_block(hdr, H, W, target, n_periods=24):
 
 def main():
     a = parse_args()
+    result_line = ""
     import numpy as np
     import torch  # first: one HIP runtime for the whole process
     import torch.distributed as dist
@@ -203,6 +207,16 @@ def main():
                 dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
             else:
                 dist.init_process_group(backend)
+    pg_done = False
+    if a.pg_first:
+        if world > 1:
+            init_dist()
+        else:
+            import socket
+            sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", dev_index))
+            dist.all_reduce(torch.zeros(1, device="cuda"))       # forces the communicator (and its streams) into existence
+        pg_done = True
     n_gpus = world
     if a.gpus != n_gpus and rank == 0 and world > 1:
         print(f"warning: --gpus {a.gpus} but WORLD_SIZE {world}", file=sys.stderr)
@@ -323,7 +337,8 @@ def main():
             c.sync()
         torch.cuda.synchronize()
 
-    init_dist()
+    if not pg_done:
+        init_dist()
     for k in range(a.warmup):
         run_step(k)
     sync_all()
@@ -468,14 +483,23 @@ def main():
                     out["speedup_vs_reference_opencl"] = round(out["value"] / n_gpus / r["frames_per_s"], 2)
             except Exception as e:
                 out["reference_opencl"] = {"error": repr(e)}
-        print(json.dumps(out), flush=True)
+        result_line = json.dumps(out)
 
     for b in batches:
         b.close()
     for c in calcs:
         c.close()
-    if world > 1:
+    if world > 1 or a.pg_first:
         dist.destroy_process_group()
+    if rank == 0:
+        # the ONE JSON line goes out last: RCCL prints a version banner through C stdio, which would otherwise be flushed
+        # behind it at exit
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(result_line, flush=True)
 
 
 if __name__ == "__main__":
