@@ -1062,7 +1062,14 @@ int hf_batch_interpolate_period(hf_batch* b, const int* n_out, const float* t, v
     if (one_launch) {
         // every member's period in ONE launch on the batch stream (single-stream members: program order does the rest)
         hf::WarpPeriod periods[hf::kMaxFlowBatch];
-        for (int m = 0; m < n; m++) fill_period(b->members[m], n_out[m], t + m * HF_MAX_PERIOD_OUTPUTS, device_out + m * HF_MAX_PERIOD_OUTPUTS, periods[m]);
+        for (int m = 0; m < n; m++) {
+            hf_ctx* c = b->members[m];
+            fill_period(c, n_out[m], t + m * HF_MAX_PERIOD_OUTPUTS, device_out + m * HF_MAX_PERIOD_OUTPUTS, periods[m]);
+            if (!c->warp_started && c->timing()) {   // m_warpCalcTime span of the member (opticalFlowCalcSDR.cpp:36-41), as in hf_warp_frames
+                if (hipEventRecord(c->ev_warp_start, b->stream) != hipSuccess) return batch_fail(b, HF_ERR_HIP, "hipEventRecord failed");
+                c->warp_started = true;
+            }
+        }
         const int span = span_open(l, 0);
         if (hf::launch_warp_periods(l->g, n, periods, mode, b->stream, span >= 0 ? l->spans[span].b : nullptr, span >= 0 ? l->spans[span].e : nullptr)) {
             if (span >= 0) { int f = 0; for (int m = 0; m < n; m++) f += n_out[m]; l->spans[span].frames = f; }
