@@ -49,8 +49,8 @@ WORKLOADS = {
     "sdr360_24to60": (0, 360, 640, 166667, "640x360 SDR, 24->60 fps (plumbing size)"),
 }
 # per workload: (pair streams per GPU, pairs per flow batch) -- measured operating points, DESIGN.md section 5
-OPERATING_POINT = {"hdr2160_24to120": (16, 8), "hdr2160_24to60": (16, 8), "sdr1080_24to60": (24, 8), "sdr1080_24to120": (24, 8),
-                   "sdr360_24to60": (24, 8)}
+OPERATING_POINT = {"hdr2160_24to120": (32, 16), "hdr2160_24to60": (32, 16), "sdr1080_24to60": (32, 16), "sdr1080_24to120": (32, 16),
+                   "sdr360_24to60": (32, 16)}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 WARP_SYMBOL = {1: "warp_fast_kernel<unsigned short, 8, 2, 2, 16, true>", 0: "warp_fast_kernel<unsigned char, 4, 2, 2, 8, true>"}
 

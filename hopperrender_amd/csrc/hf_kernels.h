@@ -19,7 +19,7 @@ struct Geom {
     int lw, lh;          // low-res grid
 };
 
-constexpr int kMaxFlowBatch = 8;       // contexts per hf_batch (FlowBatch below)
+constexpr int kMaxFlowBatch = 16;      // contexts per hf_batch (FlowBatch below)
 constexpr int kMaxWarpOutputs = 6;     // outputs of one source period at 24 -> 120 fps (HopperRender.cpp:944-948)
 
 // Phase-plane layout of a frame (hf_flow.hip).  ONE plane of 4-byte elements, one element per grid column, per pair of

@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("hdr,H,W,n,R,mode", [(0, 360, 640, 3, 8, 2), (1, 360, 640, 8, 16, 2), (0, 1080, 1920, 4, 16, 2),
                                              (1, 2160, 3840, 2, 5, 2), (0, 274, 486, 5, 16, 2), (1, 360, 640, 4, 9, 0),
-                                             (0, 360, 640, 3, 9, 1), (0, 360, 640, 2, 7, 4), (1, 338, 600, 3, 6, 2)])
+                                             (0, 360, 640, 3, 9, 1), (0, 360, 640, 2, 7, 4), (1, 338, 600, 3, 6, 2), (0, 180, 320, 16, 9, 2), (1, 180, 320, 13, 16, 2)])
 def test_batched_period_equals_single_contexts(native_lib, hdr, H, W, n, R, mode):
     from hopperrender_amd import capi, synth
     from hopperrender_amd.calc import DeviceBuffer, FlowBatch, OpticalFlowCalcHDR, OpticalFlowCalcSDR
