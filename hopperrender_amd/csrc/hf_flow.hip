@@ -226,11 +226,12 @@ struct Strip {
     bool any;                         // at least one pixel inside the grid
 };
 
-template <int PX>
+// FULL (here and below): the whole tile lies inside the grid and R == 16 -- no validity masks, no per-candidate tests
+template <int PX, bool FULL>
 __device__ __forceinline__ Strip<PX> load_strip(const Geom& g, const FlowStep& a, int cx0, int cy) {
     Strip<PX> s;
     s.cx0 = cx0; s.cy = cy;
-    const int n = cy < g.lh ? clampi(g.lw - cx0, 0, PX) : 0;
+    const int n = FULL ? PX : (cy < g.lh ? clampi(g.lw - cx0, 0, PX) : 0);
     s.any = n > 0;
 #pragma unroll
     for (int i = 0; i < PX; i++) { s.ref[i] = 0u; s.vm[i] = i < n ? 0xFFFFFFFFu : 0u; }
@@ -271,12 +272,14 @@ __device__ __forceinline__ Elems<PX> buffer_elems(__amdgpu_buffer_rsrc_t rsrc, u
 // on the vector ALU at all (round 1: ~13 of the ~36 VALU instructions per candidate).  Otherwise it is per lane.
 // (The reference does this arithmetic in 16-bit, calcDeltaSumsKernelSDR.h:75-76; offsets are bounded by
 //  iterations * 64 + 64 < 2^15, so nothing ever wraps.)
-template <int PX, bool UNI>
+template <int PX, bool UNI, bool FULL>
 __device__ __forceinline__ void strip_sads(uint32_t* sad, const Geom& g, const FlowStep& a, const Strip<PX>& s,
                                            int ox, int oy, int axis) {
     const PhaseLayout& pl = a.pl;
     const int sy = s.cy << g.rs;
-    const bool ragged = (g.lw & (PX - 1)) != 0;                       // kernel-uniform: some strip hangs over the right grid edge
+    const bool ragged = !FULL && (g.lw & (PX - 1)) != 0;              // kernel-uniform: some strip hangs over the right grid edge
+    const int R = FULL ? 16 : a.R;
+    const bool any = FULL || s.any;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.pp1, 0, (int)pl.bytes, 0x00020000);
     if (UNI) { ox = __builtin_amdgcn_readfirstlane(ox); oy = __builtin_amdgcn_readfirstlane(oy); }
     const int searched0 = axis ? oy : ox;
@@ -288,8 +291,8 @@ __device__ __forceinline__ void strip_sads(uint32_t* sad, const Geom& g, const F
         const unsigned lane_off = (__umul24((unsigned)mirror_clamp(sy + oy, g.H), row_el) + (unsigned)s.cx0) * 4u;
 #pragma unroll
         for (int cz = 0; cz < 16; cz++) {
-            if (cz < a.R && s.any) {                                  // R is uniform
-                const int c = searched0 + rel_offset(cz, a.R);
+            if (cz < R && any) {                                  // R is uniform
+                const int c = searched0 + rel_offset(cz, R);
                 const int ph = c & (pl.nph - 1);
                 const unsigned coff = (unsigned)((ph >> 1) * pl.lwp + (c >> g.rs) + pl.mx) * 4u;
                 c1[cz] = UNI ? buffer_elems<PX>(rsrc, lane_off + 0u, coff) : buffer_elems<PX>(rsrc, lane_off + coff, 0u);
@@ -301,14 +304,14 @@ __device__ __forceinline__ void strip_sads(uint32_t* sad, const Geom& g, const F
         const unsigned col = (unsigned)((ph0 >> 1) * pl.lwp + pl.mx + s.cx0 + (ox >> g.rs));
         const unsigned selc = 0x03020c00u | (unsigned)(ph0 & 1);
         // rows: the reflection of calcDeltaSumsKernelSDR.h:86-95 only acts within 64 rows of the frame edge
-        const int cmin = searched0 + rel_offset(0, a.R), cmax = searched0 + rel_offset(a.R - 1, a.R);
-        const bool inside = !s.any || (sy + cmin >= 0 && sy + cmax <= g.H - 1);
+        const int cmin = searched0 + rel_offset(0, R), cmax = searched0 + rel_offset(R - 1, R);
+        const bool inside = !any || (sy + cmin >= 0 && sy + cmax <= g.H - 1);
         if (__builtin_amdgcn_ballot_w64(!inside) == 0) {
             const unsigned lane_off = (__umul24((unsigned)(sy + cmin), row_el) + col) * 4u;   // row of the lowest candidate
 #pragma unroll
             for (int cz = 0; cz < 16; cz++) {
-                if (cz < a.R && s.any) {
-                    const unsigned coff = __umul24((unsigned)(rel_offset(cz, a.R) - rel_offset(0, a.R)), row_el) * 4u;   // >= 0, wave-uniform
+                if (cz < R && any) {
+                    const unsigned coff = __umul24((unsigned)(rel_offset(cz, R) - rel_offset(0, R)), row_el) * 4u;   // >= 0, wave-uniform
                     c1[cz] = buffer_elems<PX>(rsrc, lane_off, coff);
                     sel[cz] = selc;
                 }
@@ -316,8 +319,8 @@ __device__ __forceinline__ void strip_sads(uint32_t* sad, const Geom& g, const F
         } else {
 #pragma unroll
             for (int cz = 0; cz < 16; cz++) {
-                if (cz < a.R && s.any) {
-                    const int ny = mirror_clamp(sy + searched0 + rel_offset(cz, a.R), g.H);
+                if (cz < R && any) {
+                    const int ny = mirror_clamp(sy + searched0 + rel_offset(cz, R), g.H);
                     c1[cz] = buffer_elems<PX>(rsrc, (__umul24((unsigned)ny, row_el) + col) * 4u, 0u);
                     sel[cz] = selc;
                 }
@@ -327,7 +330,7 @@ __device__ __forceinline__ void strip_sads(uint32_t* sad, const Geom& g, const F
 #pragma unroll
     for (int cz = 0; cz < 16; cz++) {
         uint32_t t = 0u;
-        if (cz < a.R && s.any) {
+        if (cz < R && any) {
 #pragma unroll
             for (int i = 0; i < PX; i++) {
                 uint32_t v = __builtin_amdgcn_perm(c1[cz].d[i], c1[cz].d[i], sel[cz]);
@@ -398,16 +401,17 @@ __device__ __forceinline__ int group_reduce(uint32_t* sad, int lane) {
 
 // argmin over all candidates of the group; every lane of the group returns the same winner.
 // `captured` (optional) receives the full cost sum of candidate cap_cz.
-template <int G>
+template <int G, bool FULL>
 __device__ __forceinline__ int group_argmin(const uint32_t* tot, int first, const FlowStep& a, int searched0,
                                             const int* nb, uint32_t npix, int cap_cz, bool want_cap, uint32_t& captured) {
+    const int R = FULL ? 16 : a.R;
     Best b{0xFFFFFFFFu, 16};
     uint32_t cap = 0;
 #pragma unroll
     for (int k = 0; k < Owned<G>::n; k++) {
         const int cz = first + k;
-        if (cz < a.R) {
-            const int cand = (int)(int16_t)(searched0 + rel_offset(cz, a.R));
+        if (cz < R) {
+            const int cand = (int)(int16_t)(searched0 + rel_offset(cz, R));
             const uint32_t sum = (tot[k] << a.delta_scalar) + npix * window_bias(cand, a.use_neighbors, nb, a.neighbor_scalar);
             best_min(b, sum, cz);
             if (cz == cap_cz) cap = sum;
@@ -527,21 +531,17 @@ template <> struct Map<2> {    // 2 lanes = one 2x2 window; wave = 8x4 windows; 
 // SPLIT (windows <= 16, where a window never spans waves): the four waves of a tile are four one-wave workgroups
 // (TileId::wave).  A 480x270 grid has only 135 tiles for 256 CUs; split, every CU's L1 takes a share of the
 // candidate rows' cache lines (a Y step pulls ~16 x 8 row segments per wave, 32 useful bytes per 128-byte line).
-template <int WS, bool SPLIT>
-__global__ __launch_bounds__(SPLIT ? 64 : 256) void flow_level_small_kernel(const Geom g, const FlowBatch batch) {
+template <int WS, bool SPLIT, bool FULL>
+__device__ __forceinline__ void flow_level_small_body(const Geom& g, const FlowStep& a, const TileId& tile, uint32_t (*s_part)[4][16]) {
     using M = Map<WS>;
-    const TileId tile = decode_tile((g.lw + M::TW - 1) / M::TW, (g.lh + M::TH - 1) / M::TH, SPLIT ? 4 : 1, batch.n);
-    if (!tile.valid) return;
-    const FlowStep& a = batch.s[tile.pair];
     constexpr int PX = M::PX, G = M::G;
-    static_assert(!SPLIT || WS <= 16, "a 32x32 window is shared by the four waves of a workgroup");
-    __shared__ uint32_t s_part[SPLIT ? 1 : 2][SPLIT ? 1 : 4][16];
+    const int R = FULL ? 16 : a.R;
     const int tid = SPLIT ? (int)(tile.wave * 64 + threadIdx.x) : (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;
     int lx, ly;
     M::at(tid, lx, ly);
     const int cx0 = tile.tx * M::TW + lx, cy = tile.ty * M::TH + ly;
     const int wx = cx0 >> a.cur.log2w, wy = cy >> a.cur.log2w;
-    const bool win_in = (wx << a.cur.log2w) < g.lw && (wy << a.cur.log2w) < g.lh;   // whole lane group agrees
+    const bool win_in = FULL || ((wx << a.cur.log2w) < g.lw && (wy << a.cur.log2w) < g.lh);   // whole lane group agrees
 
     WinConst wc{};
     if (win_in) wc = load_win_const(g, a, wx, wy, false);
@@ -551,24 +551,24 @@ __global__ __launch_bounds__(SPLIT ? 64 : 256) void flow_level_small_kernel(cons
         const int v = resolve_pending(g, a, tx0, ty0, lane, leader);
         if (a.pend.axis) wc.oy = v; else wc.ox = v;
     }
-    const Strip<PX> strip = load_strip<PX>(g, a, cx0, cy);
-    const int cap_cz = (a.R >> 1) - 1;
+    const Strip<PX> strip = load_strip<PX, FULL>(g, a, cx0, cy);
+    const int cap_cz = (R >> 1) - 1;
     uint32_t captured = 0;
     int off[2] = {wc.ox, wc.oy};
 
 #pragma unroll
     for (int axis = 0; axis < 2; axis++) {
         uint32_t sad[16];
-        strip_sads<PX, G == 64>(sad, g, a, strip, off[0], off[1], axis);
+        strip_sads<PX, G == 64, FULL>(sad, g, a, strip, off[0], off[1], axis);
         int first = group_reduce<G>(sad, lane);
         if constexpr (WS == 32) {   // four waves share the window
             if ((lane & 3) == 0) s_part[axis][wave][first] = sad[0];
             __syncthreads();
             sad[0] = s_part[axis][0][first] + s_part[axis][1][first] + s_part[axis][2][first] + s_part[axis][3][first];
         }
-        const int best = group_argmin<G>(sad, first, a, off[axis], axis ? wc.nby : wc.nbx, wc.npix, cap_cz,
-                                         axis == 0 && a.capture_delta, captured);
-        off[axis] = (int)(int16_t)(off[axis] + rel_offset(best, a.R));   // adjustOffsetArrayKernelSDR.h:13-19
+        const int best = group_argmin<G, FULL>(sad, first, a, off[axis], axis ? wc.nby : wc.nbx, wc.npix, cap_cz,
+                                               axis == 0 && a.capture_delta, captured);
+        off[axis] = (int)(int16_t)(off[axis] + rel_offset(best, R));   // adjustOffsetArrayKernelSDR.h:13-19
     }
 
     const bool leader = WS == 32 ? tid == 0 : (lane & (G - 1)) == 0;
@@ -579,17 +579,31 @@ __global__ __launch_bounds__(SPLIT ? 64 : 256) void flow_level_small_kernel(cons
     }
 }
 
+template <int WS, bool SPLIT>
+__global__ __launch_bounds__(SPLIT ? 64 : 256) void flow_level_small_kernel(const Geom g, const FlowBatch batch) {
+    using M = Map<WS>;
+    const TileId tile = decode_tile((g.lw + M::TW - 1) / M::TW, (g.lh + M::TH - 1) / M::TH, SPLIT ? 4 : 1, batch.n);
+    if (!tile.valid) return;
+    const FlowStep& a = batch.s[tile.pair];
+    static_assert(!SPLIT || WS <= 16, "a 32x32 window is shared by the four waves of a workgroup");
+    __shared__ uint32_t s_part[SPLIT ? 1 : 2][4][16];
+    // Workgroup-uniform choice: tiles that lie inside the grid with the full search radius (all but the last tile row /
+    // column once the governor has settled at 16) run a body without validity masks and per-candidate tests -- a level
+    // launch is mostly instruction issue (vector + scalar), not loads: without ANY memory access it still takes 60-70 %
+    // of its time (what-if builds).
+    const bool full = a.R == 16 && (tile.tx + 1) * M::TW <= g.lw && (tile.ty + 1) * M::TH <= g.lh;
+    if (full) flow_level_small_body<WS, SPLIT, true>(g, a, tile, s_part);
+    else flow_level_small_body<WS, SPLIT, false>(g, a, tile, s_part);
+}
+
 // Windows > 32, one axis: raw SAD sums of a 32 x (8 * WPB) tile -> one atomic per candidate.
 // WPB = waves per workgroup.  Fewer waves per workgroup = more workgroups for the 256 CUs (a 480x270 grid has 135
 // 32x32 tiles) at the price of more atomics on the same R addresses of each window.
-template <int WPB>
-__global__ __launch_bounds__(64 * WPB) void flow_big_partial_kernel(const Geom g, const FlowBatch batch) {
-    const TileId tile = decode_tile((g.lw + 63) / 64, (g.lh + 4 * WPB - 1) / (4 * WPB), 1, batch.n);
-    if (!tile.valid) return;
-    const FlowStep& a = batch.s[tile.pair];
-    __shared__ uint32_t s_part[WPB][16];
+template <int WPB, bool FULL>
+__device__ __forceinline__ void flow_big_partial_body(const Geom& g, const FlowStep& a, const TileId& tile, uint32_t (*s_part)[16]) {
+    const int R = FULL ? 16 : a.R;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    // wave = 64 grid pixels x 4 rows: the 16 lanes the texture addresser handles together read 64 contiguous bytes of ONE
+    // wave = 64 grid pixels x 4 rows: the 16 lanes the texture addresser handles together read 256 contiguous bytes of ONE
     // phase row (a 16-lane group that spans several rows costs one L1 tag lookup per row and 64-byte block)
     const int lx = (tid & 15) * 4, ly = tid >> 4;
     const int tx0 = tile.tx * 64, ty0 = tile.ty * (4 * WPB);   // 64 x 4 WPB divides every window > 32: the tile lies in one window
@@ -607,23 +621,34 @@ __global__ __launch_bounds__(64 * WPB) void flow_big_partial_kernel(const Geom g
     } else if (a.axis == 1) {
         ox = a.cur.tx[wy * a.cur.nwx + wx];
     }
-    const Strip<4> strip = load_strip<4>(g, a, cx0, cy);
+    const Strip<4> strip = load_strip<4, FULL>(g, a, cx0, cy);
     uint32_t sad[16];
-    strip_sads<4, true>(sad, g, a, strip, ox, oy, a.axis);
+    strip_sads<4, true, FULL>(sad, g, a, strip, ox, oy, a.axis);
     const int first = group_reduce<64>(sad, lane);
     uint32_t* dst = &a.sums[(wy * a.cur.nwx + wx) * 16];
     if constexpr (WPB == 1) {
-        if ((lane & 3) == 0 && first < a.R) atomicAdd(dst + first, sad[0]);
+        if ((lane & 3) == 0 && first < R) atomicAdd(dst + first, sad[0]);
     } else {
         if ((lane & 3) == 0) s_part[wave][first] = sad[0];
         __syncthreads();
-        if (tid < a.R) {
+        if (tid < R) {
             uint32_t t = 0;
 #pragma unroll
             for (int w = 0; w < WPB; w++) t += s_part[w][tid];
             atomicAdd(dst + tid, t);
         }
     }
+}
+
+template <int WPB>
+__global__ __launch_bounds__(64 * WPB) void flow_big_partial_kernel(const Geom g, const FlowBatch batch) {
+    const TileId tile = decode_tile((g.lw + 63) / 64, (g.lh + 4 * WPB - 1) / (4 * WPB), 1, batch.n);
+    if (!tile.valid) return;
+    const FlowStep& a = batch.s[tile.pair];
+    __shared__ uint32_t s_part[WPB][16];
+    const bool full = a.R == 16 && (tile.tx + 1) * 64 <= g.lw && (tile.ty + 1) * (4 * WPB) <= g.lh;   // see flow_level_small_kernel
+    if (full) flow_big_partial_body<WPB, true>(g, a, tile, s_part);
+    else flow_big_partial_body<WPB, false>(g, a, tile, s_part);
 }
 
 // Windows > 32, one axis: 16 lanes per window finish the sums, pick the winner, update the table.
