@@ -55,6 +55,53 @@ def test_batched_period_equals_single_contexts(native_lib, hdr, H, W, n, R, mode
         c.close()
 
 
+@pytest.mark.parametrize("hdr,H,W,n,R,mode", [(1, 2160, 3840, 8, 16, 2), (1, 2160, 3840, 16, 9, 2), (0, 2160, 3840, 6, 16, 2), (1, 2154, 3832, 8, 12, 2),
+                                             (1, 2160, 3840, 8, 16, 0), (0, 2160, 3840, 8, 11, 1), (1, 1080, 1920, 12, 16, 2), (0, 1082, 1924, 16, 16, 2),
+                                             (1, 2160, 3840, 3, 16, 2)])
+def test_large_batched_periods_equal_single_contexts(native_lib, hdr, H, W, n, R, mode):
+    """Batched periods at the sizes the bench runs (up to 16 members of 2160p / 1080p frames in one launch: the unit decoding
+    (member, tile block, chunk) of warp_fast_kernel and the XCD banding only get large here).  A member's outputs must equal
+    those of a single context, which is checked against the oracle and the golden vectors elsewhere.  Includes frames
+    whose planes end inside a wave tile (2154 rows = 269 tiles + 2 rows, 1077 chroma rows; 1924 columns)."""
+    from hopperrender_amd import capi, synth
+    from hopperrender_amd.calc import DeviceBuffer, FlowBatch, OpticalFlowCalcHDR, OpticalFlowCalcSDR
+    from hopperrender_amd.protocol import SOURCE_24, TARGET_120, BlendSchedule
+    cls = OpticalFlowCalcHDR if hdr else OpticalFlowCalcSDR
+    scenes = [synth.Scene(H, W, bool(hdr), 700 + 13 * i) for i in range(2)]
+    frames = [[sc.frame(k) for k in range(4)] for sc in scenes]
+    dev = [[DeviceBuffer(f.nbytes) for f in fs] for fs in frames]
+    for i in range(2):
+        for k in range(4):
+            dev[i][k].upload(frames[i][k])
+    src = lambda i, k: dev[i % 2][(k + i // 2) % 4]          # member i: scene i % 2, started i // 2 frames in
+    singles = [cls(H, W, search_radius=R, flags=capi.HF_FLAG_ASYNC) for _ in range(n)]
+    members = [cls(H, W, search_radius=R, flags=capi.HF_FLAG_ASYNC) for _ in range(n)]
+    batch = FlowBatch(members)
+    plans = [BlendSchedule(SOURCE_24, TARGET_120).plan(10 + i)[i:] for i in range(n)]
+    outs_s = [DeviceBuffer(singles[0].output_frame_bytes) for _ in range(6)]
+    outs_b = [[DeviceBuffer(singles[0].output_frame_bytes) for _ in range(6)] for _ in range(n)]
+    dt = np.uint16 if hdr else np.uint8
+    for k in range(4):
+        for i in range(n):
+            singles[i].updateFrameDeviceRef(src(i, k).ptr)
+        batch.updateFramesDeviceRef([src(i, k).ptr for i in range(n)])
+        if k < 2:
+            continue
+        for i in range(n):
+            singles[i].calculateOpticalFlow()
+        batch.calculateOpticalFlow()
+        ts = [plans[i][k] for i in range(n)]
+        batch.interpolatePeriod(ts, [[b.ptr for b in outs_b[i]] for i in range(n)], mode)
+        for i in range(n):
+            singles[i].interpolateOnly(ts[i], [b.ptr for b in outs_s], mode)
+            singles[i].sync(); members[i].sync()
+            for j in range(len(ts[i])):
+                assert (outs_s[j].download(dt) == outs_b[i][j].download(dt)).all(), (k, i, j)
+    batch.close()
+    for c in singles + members:
+        c.close()
+
+
 def test_batched_period_matches_oracle(native_lib):
     """... and through the oracle the reference: one batched period at 180p against the CPU restatement."""
     from hopperrender_amd import capi, synth
