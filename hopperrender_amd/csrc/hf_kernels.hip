@@ -727,9 +727,13 @@ __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a,
 // Thread = VEC consecutive elements x ROWS consecutive rows that share one flow-cell row (ROWS
 // divides 2^rs).  Flow lookups and displacement maths are done once per GROUP and reused for the
 // ROWS rows; all 2 * ROWS source runs are requested before any is consumed.
-#ifndef HF_WARP_WAVES
-#define HF_WARP_WAVES 4   // waves (wave tiles) per workgroup
-#endif
+// Waves (= consecutive wave tiles of a tile row) per workgroup, chosen per launch: 4, or 16 for the batched periods of large
+// frames.  Measured on MI355X, 2160p HDR pipeline (32 pair streams = 2 batches of 16), k frames/s: 67.0 / 67.6 / 68.9 / 68.7 /
+// 67.8 / 68.8 / 70.0 with 4 / 5 / 6 / 8 / 10 / 15 / 16 waves (+2.6 % with one batch stream); a single period is 46 us with 4
+// and 52 us with 16 (760 workgroups for 256 CUs), and the short one-output waves of frames up to 1080p lose 8 % with 16.
+constexpr int kWarpWavesSmall = 4, kWarpWavesLarge = 16;
+// (only the one-flow-cell-per-thread instances are compiled for 1,024-thread workgroups = at most 128 VGPRs: the others need more)
+constexpr int warp_max_waves(size_t elem, int group, int vb) { return vb == 16 && group * (int)elem == 16 ? kWarpWavesLarge : kWarpWavesSmall; }
 // VB = bytes of output per thread and row: 16, or 8 for small frames (<= 1080p 8-bit), where 16-byte threads
 // leave too few waves to hide the per-wave latency chain (one round of fat waves: 9.4 us for 9.3 MB).
 // Wave tile = kWarpTX lanes x kWarpTY row groups: (16 x VEC) elements wide, (4 x ROWS) rows high -- at 2160p HDR 128 pixels
@@ -739,10 +743,10 @@ __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a,
 // 1,940 VALU instructions per wave.  With 128-pixel tiles 2 of 30 tiles per row are edge tiles.)
 constexpr int kWarpTX = 16, kWarpTY = 4;
 template <typename E, int GROUP, int ROWS, int MODE, int VB, bool DW>
-__global__ __launch_bounds__(64 * HF_WARP_WAVES) void warp_fast_kernel(const Geom g, const WarpBatchArgs batch, int y_groups, int out_chunk, int n_chunks) {
+__global__ __launch_bounds__(64 * warp_max_waves(sizeof(E), GROUP, VB)) void warp_fast_kernel(const Geom g, const WarpBatchArgs batch, int y_groups, int out_chunk, int n_chunks) {
     constexpr int VEC = VB / sizeof(E);
     // Work decomposition: tiles are numbered row-major (luma tile rows first, then chroma: the plane test is a scalar
-    // branch), a workgroup takes 4 consecutive tiles, and workgroups are dealt to the XCDs in contiguous bands: linear
+    // branch), a workgroup takes 4 or 16 consecutive tiles, and workgroups are dealt to the XCDs in contiguous bands: linear
     // block id b runs on XCD b % 8 (MI355X_MICROARCH.md "Workgroup dispatch"), so block b works on band (b % 8).
     // Measured on the 2160p HDR blend: 20.7 us with the naive 2-D grid (every XCD walks a column stripe) -> 19.0 us
     // banded.  Placement only affects speed.  Units are ordered (member, tile block, chunk): with a batch every XCD works
@@ -751,7 +755,8 @@ __global__ __launch_bounds__(64 * HF_WARP_WAVES) void warp_fast_kernel(const Geo
     const int wpr = (g.W + kWarpTX * VEC - 1) / (kWarpTX * VEC);            // wave tiles per tile row
     const int y_tiles = (y_groups + kWarpTY - 1) / kWarpTY, uv_tiles = (uv_groups + kWarpTY - 1) / kWarpTY;
     const int n_tiles = wpr * (y_tiles + uv_tiles);
-    const int n_blocks = (n_tiles + HF_WARP_WAVES - 1) / HF_WARP_WAVES;   // per member
+    const int wpb = (int)(blockDim.x >> 6);                                 // waves per workgroup (launch_warp_fast)
+    const int n_blocks = (n_tiles + wpb - 1) / wpb;                         // per member
     // out_chunk = outputs of the period one thread produces.  Large frames: all of them (the sources are read from HBM once);
     // small frames: fewer, so that a period is n_chunks times as many, shorter waves -- their sources come from L2 anyway and
     // a 1080p period has only ~3,000 wave tiles for 1,024 SIMDs.  The chunks of a tile run next to each other on one XCD.
@@ -764,7 +769,7 @@ __global__ __launch_bounds__(64 * HF_WARP_WAVES) void warp_fast_kernel(const Geo
     const WarpArgs& a = batch.s[member];
     const int ti0 = chunk * out_chunk, ti1 = min(a.n_out, ti0 + out_chunk);
     if (ti0 >= ti1) return;
-    const int tile = blk * HF_WARP_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile = blk * wpb + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (tile >= n_tiles) return;
     const int trow = tile / wpr, tcol = tile - trow * wpr;
     const int lane = threadIdx.x & 63;
@@ -855,7 +860,7 @@ static bool launch_warp_fast(const Geom& g, const WarpBatchArgs& b, hipStream_t 
                          // per-element scalar work does not pay for halving the number of waves)
     const int y_groups = (g.H + rows - 1) / rows, uv_groups = ((g.H >> 1) + rows - 1) / rows;
     const int wpr = (g.W + kWarpTX * VEC - 1) / (kWarpTX * VEC);
-    const int n_blocks = (wpr * ((y_groups + kWarpTY - 1) / kWarpTY + (uv_groups + kWarpTY - 1) / kWarpTY) + HF_WARP_WAVES - 1) / HF_WARP_WAVES;
+    const int n_tiles = wpr * ((y_groups + kWarpTY - 1) / kWarpTY + (uv_groups + kWarpTY - 1) / kWarpTY);
     int max_out = 1;
     for (int m = 0; m < b.n; m++) max_out = b.s[m].n_out > max_out ? b.s[m].n_out : max_out;
     // outputs per thread: everything for large frames; one for frames up to 1080p (measured, fused 5-output period, us:
@@ -863,13 +868,16 @@ static bool launch_warp_fast(const Geom& g, const WarpBatchArgs& b, hipStream_t 
     // 45.9 / 46.6 hot, 50.8 / 52.1 HBM-cold with 6 / 1)
     const int out_chunk = (size_t)g.W * g.H * sizeof(E) <= (size_t)1920 * 1088 * 2 ? 1 : kMaxWarpOutputs;
     const int n_chunks = (max_out + out_chunk - 1) / out_chunk;
-    const dim3 fg(((n_blocks * n_chunks * b.n + 7) / 8) * 8);
+    // large workgroups only where the launch keeps every CU supplied with them (>= 4 rounds of 8,192 resident waves)
+    const int wpb = out_chunk > 1 && (long)n_tiles * n_chunks * b.n >= 4 * 8192 ? warp_max_waves(sizeof(E), group, VB) : kWarpWavesSmall;
+    const int n_blocks = (n_tiles + wpb - 1) / wpb;
+    const dim3 fg(((n_blocks * n_chunks * b.n + 7) / 8) * 8), fb(64 * wpb);
 #define HF_WARP_FAST(G, D)                                                                   \
     do {                                                                                     \
         /* ev0/ev1 (may be null): timestamps of the dispatch itself, like rocprof's kernel trace */ \
-        if (mode == 0) hipExtLaunchKernelGGL((warp_fast_kernel<E, G, 2, 0, VB, D>), fg, dim3(64 * HF_WARP_WAVES), 0, stream, ev0, ev1, 0, g, b, y_groups, out_chunk, n_chunks);      \
-        else if (mode == 1) hipExtLaunchKernelGGL((warp_fast_kernel<E, G, 2, 1, VB, D>), fg, dim3(64 * HF_WARP_WAVES), 0, stream, ev0, ev1, 0, g, b, y_groups, out_chunk, n_chunks); \
-        else hipExtLaunchKernelGGL((warp_fast_kernel<E, G, 2, 2, VB, D>), fg, dim3(64 * HF_WARP_WAVES), 0, stream, ev0, ev1, 0, g, b, y_groups, out_chunk, n_chunks);                  \
+        if (mode == 0) hipExtLaunchKernelGGL((warp_fast_kernel<E, G, 2, 0, VB, D>), fg, fb, 0, stream, ev0, ev1, 0, g, b, y_groups, out_chunk, n_chunks);      \
+        else if (mode == 1) hipExtLaunchKernelGGL((warp_fast_kernel<E, G, 2, 1, VB, D>), fg, fb, 0, stream, ev0, ev1, 0, g, b, y_groups, out_chunk, n_chunks); \
+        else hipExtLaunchKernelGGL((warp_fast_kernel<E, G, 2, 2, VB, D>), fg, fb, 0, stream, ev0, ev1, 0, g, b, y_groups, out_chunk, n_chunks);                  \
     } while (0)
 #define HF_WARP_GROUP(D)                                  \
     do {                                                  \
