@@ -281,7 +281,7 @@ class PinnedArray:
 
 
 class FlowBatch:
-    """hf_batch: calculateOpticalFlow() of up to 16 contexts (independent frame pairs, same geometry and parameters)
+    """hf_batch: calculateOpticalFlow() of up to 32 contexts (independent frame pairs, same geometry and parameters)
     as one set of launches.  While the batch exists its members issue on one stream; close() it before them."""
 
     def __init__(self, members):

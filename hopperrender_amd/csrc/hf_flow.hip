@@ -470,6 +470,44 @@ __device__ __forceinline__ int resolve_pending(const Geom& g, const FlowStep& a,
 // step (measured with rocprofv3 FETCH_SIZE: 6.7 MB for a launch whose footprint is ~2 MB, 129 MB per 2160p chain).
 // So unit u = (id % 8) * per_xcd + id / 8: XCD k works on the k-th contiguous eighth of the units, ordered
 // (pair, tile row, tile column, wave) -- a band of one pair's grid, or whole pairs of a batch.
+// Kernel-argument form of a FlowBatch.  A launch carries at most 4 KB of arguments and a FlowStep is 248 bytes, but the
+// members of a batch differ only in their 13 buffer pointers: the launch gets ONE FlowStep (member 0's) plus the pointers
+// of every member (104 bytes each: 32 members = 3.3 KB), and a workgroup rebuilds its member's FlowStep in scalar registers.
+struct FlowPtrs {
+    const uint32_t *pp1, *pp2;
+    int16_t *cur_tx, *cur_ty, *prev_tx, *prev_ty;
+    uint32_t *sums, *total_delta;
+    int16_t *pend_tx, *pend_ty, *pend_prev_tx, *pend_prev_ty;
+    const uint32_t* pend_sums;
+};
+struct FlowBatchArgs {
+    int n;
+    FlowStep common;
+    FlowPtrs m[kMaxFlowBatch];
+};
+static_assert(sizeof(FlowBatchArgs) + sizeof(Geom) <= 4096, "kernel arguments of a batched chain launch");
+static FlowBatchArgs pack_batch(const FlowBatch& b) {
+    FlowBatchArgs k;
+    k.n = b.n;
+    k.common = b.s[0];
+    for (int i = 0; i < b.n; i++) {
+        const FlowStep& f = b.s[i];
+        k.m[i] = FlowPtrs{f.pp1, f.pp2, f.cur.tx, f.cur.ty, f.prev.tx, f.prev.ty, f.sums, f.total_delta,
+                          f.pend.lvl.tx, f.pend.lvl.ty, f.pend.lvl_prev.tx, f.pend.lvl_prev.ty, f.pend.sums};
+    }
+    return k;
+}
+__device__ __forceinline__ FlowStep member_step(const FlowBatchArgs& k, int i) {
+    FlowStep a = k.common;
+    const FlowPtrs& p = k.m[i];
+    a.pp1 = p.pp1; a.pp2 = p.pp2;
+    a.cur.tx = p.cur_tx; a.cur.ty = p.cur_ty; a.prev.tx = p.prev_tx; a.prev.ty = p.prev_ty;
+    a.sums = p.sums; a.total_delta = p.total_delta;
+    a.pend.lvl.tx = p.pend_tx; a.pend.lvl.ty = p.pend_ty; a.pend.lvl_prev.tx = p.pend_prev_tx; a.pend.lvl_prev.ty = p.pend_prev_ty;
+    a.pend.sums = p.pend_sums;
+    return a;
+}
+
 struct TileId { int pair, tx, ty, wave; bool valid; };
 __device__ __forceinline__ TileId decode_tile(int tiles_x, int tiles_y, int waves_per_tile, int n_pairs) {
     const int total = tiles_x * tiles_y * waves_per_tile * n_pairs;
@@ -580,11 +618,11 @@ __device__ __forceinline__ void flow_level_small_body(const Geom& g, const FlowS
 }
 
 template <int WS, bool SPLIT>
-__global__ __launch_bounds__(SPLIT ? 64 : 256) void flow_level_small_kernel(const Geom g, const FlowBatch batch) {
+__global__ __launch_bounds__(SPLIT ? 64 : 256) void flow_level_small_kernel(const Geom g, const FlowBatchArgs batch) {
     using M = Map<WS>;
     const TileId tile = decode_tile((g.lw + M::TW - 1) / M::TW, (g.lh + M::TH - 1) / M::TH, SPLIT ? 4 : 1, batch.n);
     if (!tile.valid) return;
-    const FlowStep& a = batch.s[tile.pair];
+    const FlowStep a = member_step(batch, tile.pair);
     static_assert(!SPLIT || WS <= 16, "a 32x32 window is shared by the four waves of a workgroup");
     __shared__ uint32_t s_part[SPLIT ? 1 : 2][4][16];
     // Workgroup-uniform choice: tiles that lie inside the grid with the full search radius (all but the last tile row /
@@ -641,10 +679,10 @@ __device__ __forceinline__ void flow_big_partial_body(const Geom& g, const FlowS
 }
 
 template <int WPB>
-__global__ __launch_bounds__(64 * WPB) void flow_big_partial_kernel(const Geom g, const FlowBatch batch) {
+__global__ __launch_bounds__(64 * WPB) void flow_big_partial_kernel(const Geom g, const FlowBatchArgs batch) {
     const TileId tile = decode_tile((g.lw + 63) / 64, (g.lh + 4 * WPB - 1) / (4 * WPB), 1, batch.n);
     if (!tile.valid) return;
-    const FlowStep& a = batch.s[tile.pair];
+    const FlowStep a = member_step(batch, tile.pair);
     __shared__ uint32_t s_part[WPB][16];
     const bool full = a.R == 16 && (tile.tx + 1) * 64 <= g.lw && (tile.ty + 1) * (4 * WPB) <= g.lh;   // see flow_level_small_kernel
     if (full) flow_big_partial_body<WPB, true>(g, a, tile, s_part);
@@ -652,8 +690,8 @@ __global__ __launch_bounds__(64 * WPB) void flow_big_partial_kernel(const Geom g
 }
 
 // Windows > 32, one axis: 16 lanes per window finish the sums, pick the winner, update the table.
-__global__ __launch_bounds__(256) void flow_big_argmin_kernel(const Geom g, const FlowBatch batch) {
-    const FlowStep& a = batch.s[blockIdx.y];
+__global__ __launch_bounds__(256) void flow_big_argmin_kernel(const Geom g, const FlowBatchArgs batch) {
+    const FlowStep a = member_step(batch, (int)blockIdx.y);
     const int lane16 = threadIdx.x & 15;
     const int nwin = a.cur.nwx * a.cur.nwy;
     for (int w = blockIdx.x * 16 + (threadIdx.x >> 4); w < nwin; w += gridDim.x * 16) {
@@ -736,29 +774,30 @@ void launch_prep_frame(const Geom& g, const PhaseLayout& pl, const void* frame, 
 }
 
 void launch_flow_level_small(const Geom& g, const FlowBatch& b, hipStream_t stream) {
+    const FlowBatchArgs kb = pack_batch(b);
     const int ws = b.s[0].cur.window;
     const int tw = ws == 2 ? 16 : 32;
     const int tiles_x = (g.lw + tw - 1) / tw, tiles_y = (g.lh + 31) / 32;
     // windows <= 16 never span waves: one-wave workgroups (SPLIT), see flow_level_small_kernel
     const dim3 grd(xcd_grid(tiles_x, tiles_y, 1, b.n)), sgrd(xcd_grid(tiles_x, tiles_y, 4, b.n));
     switch (ws) {
-        case 32: flow_level_small_kernel<32, false><<<grd, 256, 0, stream>>>(g, b); break;
-        case 16: flow_level_small_kernel<16, true><<<sgrd, 64, 0, stream>>>(g, b); break;
-        case 8: flow_level_small_kernel<8, true><<<sgrd, 64, 0, stream>>>(g, b); break;
-        case 4: flow_level_small_kernel<4, true><<<sgrd, 64, 0, stream>>>(g, b); break;
-        default: flow_level_small_kernel<2, true><<<sgrd, 64, 0, stream>>>(g, b); break;
+        case 32: flow_level_small_kernel<32, false><<<grd, 256, 0, stream>>>(g, kb); break;
+        case 16: flow_level_small_kernel<16, true><<<sgrd, 64, 0, stream>>>(g, kb); break;
+        case 8: flow_level_small_kernel<8, true><<<sgrd, 64, 0, stream>>>(g, kb); break;
+        case 4: flow_level_small_kernel<4, true><<<sgrd, 64, 0, stream>>>(g, kb); break;
+        default: flow_level_small_kernel<2, true><<<sgrd, 64, 0, stream>>>(g, kb); break;
     }
 }
 
 constexpr int kBigWavesPerBlock = 4;   // measured on MI355X (2160p HDR chain): 4 waves per workgroup 108.2 us, 2: 109.0 us, 1: 111.9 us (more atomics)
 void launch_flow_big_partial(const Geom& g, const FlowBatch& b, hipStream_t stream) {
     const dim3 grd(xcd_grid((g.lw + 63) / 64, (g.lh + 4 * kBigWavesPerBlock - 1) / (4 * kBigWavesPerBlock), 1, b.n));
-    flow_big_partial_kernel<kBigWavesPerBlock><<<grd, 64 * kBigWavesPerBlock, 0, stream>>>(g, b);
+    flow_big_partial_kernel<kBigWavesPerBlock><<<grd, 64 * kBigWavesPerBlock, 0, stream>>>(g, pack_batch(b));
 }
 
 void launch_flow_big_argmin(const Geom& g, const FlowBatch& b, hipStream_t stream) {
     const int nwin = b.s[0].cur.nwx * b.s[0].cur.nwy;
-    flow_big_argmin_kernel<<<dim3((nwin + 15) / 16, b.n), 256, 0, stream>>>(g, b);
+    flow_big_argmin_kernel<<<dim3((nwin + 15) / 16, b.n), 256, 0, stream>>>(g, pack_batch(b));
 }
 
 void launch_expand_offsets(const Geom& g, const FlowLevel& last, int16_t* out, hipStream_t stream) {

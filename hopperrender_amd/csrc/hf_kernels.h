@@ -19,7 +19,8 @@ struct Geom {
     int lw, lh;          // low-res grid
 };
 
-constexpr int kMaxFlowBatch = 16;      // contexts per hf_batch (FlowBatch below)
+constexpr int kMaxFlowBatch = 32;      // contexts per hf_batch (FlowBatch below)
+constexpr int kMaxWarpBatch = 16;      // members per fused warp launch (its per-member arguments are 160 bytes; a launch carries 4 KB)
 constexpr int kMaxWarpOutputs = 6;     // outputs of one source period at 24 -> 120 fps (HopperRender.cpp:944-948)
 
 // Phase-plane layout of a frame (hf_flow.hip).  ONE plane of 4-byte elements, one element per grid column, per pair of

@@ -226,7 +226,7 @@ struct WarpArgs {
 // selects the member, so a batch of 8 pairs is one bandwidth-bound launch instead of 8 serialised ones.
 struct WarpBatchArgs {
     int n;
-    WarpArgs s[kMaxFlowBatch];
+    WarpArgs s[kMaxWarpBatch];
 };
 
 // One output element of warpFrameKernel (all modes).
@@ -927,19 +927,25 @@ void launch_warp(const Geom& g, const void* frame12, const void* frame21, const 
 
 bool launch_warp_periods(const Geom& g, int n, const WarpPeriod* periods, int mode, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
     if (n < 1 || n > kMaxFlowBatch) return false;
-    WarpBatchArgs b;
-    b.n = n;
-    for (int m = 0; m < n; m++) {
-        const WarpPeriod& p = periods[m];
-        if (p.n_out < 1 || p.n_out > kMaxWarpOutputs) return false;
-        WarpArgs& a = b.s[m];
-        a.frame12 = p.frame12; a.frame21 = p.frame21; a.flow = p.flow; a.flow_xy = p.flow_xy; a.out = p.outs[0];
-        a.mode = mode; a.black = p.black; a.white = p.white;
-        a.n_out = p.n_out;
-        for (int i = 0; i < p.n_out; i++) { a.s12v[i] = p.ts[i]; a.s21v[i] = 1.0f - p.ts[i]; a.outv[i] = p.outs[i]; }
-        a.s12 = a.s12v[0]; a.s21 = a.s21v[0];
+    // at most kMaxWarpBatch members per launch (kernel-argument space): a batch of 32 is two launches
+    for (int first = 0; first < n; first += kMaxWarpBatch) {
+        WarpBatchArgs b;
+        b.n = n - first < kMaxWarpBatch ? n - first : kMaxWarpBatch;
+        for (int m = 0; m < b.n; m++) {
+            const WarpPeriod& p = periods[first + m];
+            if (p.n_out < 1 || p.n_out > kMaxWarpOutputs) return false;
+            WarpArgs& a = b.s[m];
+            a.frame12 = p.frame12; a.frame21 = p.frame21; a.flow = p.flow; a.flow_xy = p.flow_xy; a.out = p.outs[0];
+            a.mode = mode; a.black = p.black; a.white = p.white;
+            a.n_out = p.n_out;
+            for (int i = 0; i < p.n_out; i++) { a.s12v[i] = p.ts[i]; a.s21v[i] = 1.0f - p.ts[i]; a.outv[i] = p.outs[i]; }
+            a.s12 = a.s12v[0]; a.s21 = a.s21v[0];
+        }
+        hipEvent_t e0 = first == 0 ? ev0 : nullptr, e1 = first + kMaxWarpBatch >= n ? ev1 : nullptr;
+        const bool ok = g.hdr ? launch_warp_fast_any<uint16_t>(g, b, stream, e0, e1) : launch_warp_fast_any<uint8_t>(g, b, stream, e0, e1);
+        if (!ok) return false;   // (the caller renders every output again, one launch each: same frames)
     }
-    return g.hdr ? launch_warp_fast_any<uint16_t>(g, b, stream, ev0, ev1) : launch_warp_fast_any<uint8_t>(g, b, stream, ev0, ev1);
+    return true;
 }
 
 template <typename E>

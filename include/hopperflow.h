@@ -164,7 +164,7 @@ int hf_interpolate_period_ex(hf_ctx* ctx, const void* device_frame, int n_out, c
 /* ---- Batched flow calculation (throughput drivers) -------------------------------------------------------------
  * The reference computes one pair at a time (opticalFlowCalcSDR.cpp:44-139: 66 enqueues per call).  Its flow grid is
  * at most 480x270, so one refinement chain is a sequence of small latency-bound launches that cannot fill 256 CUs.
- * A driver that converts INDEPENDENT frame pairs groups up to 16 contexts of identical
+ * A driver that converts INDEPENDENT frame pairs groups up to 32 contexts of identical
  * geometry/parameters into a batch: hf_batch_calculate_optical_flow() runs the calculateOpticalFlow() of every
  * member as ONE set of launches (each kernel handles all pairs).  Results per member are bit-identical to
  * hf_calculate_optical_flow(member).

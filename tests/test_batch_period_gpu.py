@@ -9,7 +9,8 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("hdr,H,W,n,R,mode", [(0, 360, 640, 3, 8, 2), (1, 360, 640, 8, 16, 2), (0, 1080, 1920, 4, 16, 2),
                                              (1, 2160, 3840, 2, 5, 2), (0, 274, 486, 5, 16, 2), (1, 360, 640, 4, 9, 0),
-                                             (0, 360, 640, 3, 9, 1), (0, 360, 640, 2, 7, 4), (1, 338, 600, 3, 6, 2), (0, 180, 320, 16, 9, 2), (1, 180, 320, 13, 16, 2)])
+                                             (0, 360, 640, 3, 9, 1), (0, 360, 640, 2, 7, 4), (1, 338, 600, 3, 6, 2), (0, 180, 320, 16, 9, 2), (1, 180, 320, 13, 16, 2),
+                                             (0, 180, 320, 32, 16, 2), (1, 270, 480, 27, 11, 2)])
 def test_batched_period_equals_single_contexts(native_lib, hdr, H, W, n, R, mode):
     from hopperrender_amd import capi, synth
     from hopperrender_amd.calc import DeviceBuffer, FlowBatch, OpticalFlowCalcHDR, OpticalFlowCalcSDR
@@ -57,7 +58,7 @@ def test_batched_period_equals_single_contexts(native_lib, hdr, H, W, n, R, mode
 
 @pytest.mark.parametrize("hdr,H,W,n,R,mode", [(1, 2160, 3840, 8, 16, 2), (1, 2160, 3840, 16, 9, 2), (0, 2160, 3840, 6, 16, 2), (1, 2154, 3832, 8, 12, 2),
                                              (1, 2160, 3840, 8, 16, 0), (0, 2160, 3840, 8, 11, 1), (1, 1080, 1920, 12, 16, 2), (0, 1082, 1924, 16, 16, 2),
-                                             (1, 2160, 3840, 3, 16, 2)])
+                                             (1, 2160, 3840, 3, 16, 2), (1, 2160, 3840, 32, 16, 2), (0, 1080, 1920, 32, 16, 2)])
 def test_large_batched_periods_equal_single_contexts(native_lib, hdr, H, W, n, R, mode):
     """Batched periods at the sizes the bench runs (up to 16 members of 2160p / 1080p frames in one launch: the unit decoding
     (member, tile block, chunk) of warp_fast_kernel and the XCD banding only get large here).  A member's outputs must equal
@@ -151,6 +152,13 @@ def test_batch_state_errors(native_lib):
     with pytest.raises(capi.HopperFlowError) as e:
         FlowBatch([c, odd])
     assert e.value.code == capi.HF_ERR_INVALID_ARGUMENT
+    many = [OpticalFlowCalcSDR(180, 320, flags=capi.HF_FLAG_ASYNC) for _ in range(33)]
+    with pytest.raises(capi.HopperFlowError) as e:
+        FlowBatch(many)          # a launch carries the buffer pointers of at most 32 members
+    assert e.value.code == capi.HF_ERR_INVALID_ARGUMENT and "at most 32" in str(e.value)
+    FlowBatch(many[:32]).close()
+    for x in many:
+        x.close()
     pin = PinnedArray(a.input_frame_bytes, np.uint8)
     with pytest.raises(capi.HopperFlowError) as e:
         a.updateFrameAsync(pin)
