@@ -171,7 +171,7 @@ int hf_interpolate_period_ex(hf_ctx* ctx, const void* device_frame, int n_out, c
  *   - members: HF_FLAG_ASYNC contexts without async host I/O, all single-stream or all HF_FLAG_DUAL_STREAM, same device, frame geometry, iterations, blur radius; at call time the same search
  *     radius / delta / neighbor scalar.  DUAL_STREAM members issue their warps on up to 3 streams the batch shares
  *     out round robin (they overlap the batched chain; measured slower than single-stream batches).
- *   - while the batch exists all members issue on ONE stream (the first member's): their hf_update_frame_device*,
+ *   - while the batch exists all members issue on ONE stream (the batch's own): their hf_update_frame_device*,
  *     hf_interpolate_period_ex(..., update_and_flow = 0), hf_sync ... calls keep working and stay in program order
  *     with the batched chain.  Destroy the batch before its members. */
 typedef struct hf_batch hf_batch;
