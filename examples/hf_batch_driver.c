@@ -84,9 +84,9 @@ int main(int argc, char** argv) {
     for (int p = 0; p < periods; p++) {
         const void* next[CLIPS];
         for (int c = 0; c < CLIPS; c++) next[c] = src[c * n_frames + p + 2];
-        CHECK(hf_batch_update_frames_device_ref(batch, next));   /* updateFrame of both clips, one phase-plane launch */
-        CHECK(hf_batch_calculate_optical_flow(batch));            /* both clips' flow calculations in one set of launches */
-        CHECK(hf_batch_interpolate_period(batch, n_out, &ts[0][0], &outs[0][0], 2));   /* all outputs of both clips: one launch */
+        /* the whole source period of both clips in ONE call: updateFrame of both (one phase-plane launch), both flow
+         * calculations in one set of launches, all outputs of both clips in one fused warp launch */
+        CHECK(hf_batch_run_period(batch, next, 1, n_out, &ts[0][0], (void* const*)&outs[0][0], 2));
         for (int c = 0; c < CLIPS; c++) {
             CHECK(hf_sync(ctx[c]));
             hf_stats st;

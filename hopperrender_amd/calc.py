@@ -49,7 +49,7 @@ class OpticalFlowCalc:
                             deltaScalar, neighborScalar, blackLevel, whiteLevel, maxCalcRes, device_index, iterations,
                             blur_radius, search_radius, flags)
         capi.check(self._lib.hf_create(C.byref(cfg), C.byref(self._ctx)))
-        self.device_index = device_index
+        self.device_index = self._lib.hf_get_device(self._ctx)   # device_index = -1: the first suitable device
         st = self._stats()
         self.m_frameWidth, self.m_frameHeight = st.frame_width, st.frame_height
         self.m_inputStride, self.m_outputStride = st.input_stride, st.output_stride
@@ -317,6 +317,31 @@ class FlowBatch:
                 t[i * K + k] = float(x)
                 outs[i * K + k] = int(out_ptrs[i][k])
         self._check(self._lib.hf_batch_interpolate_period(self._b, counts, t, outs, int(mode)))
+
+    def preparePeriod(self, dev_ptrs, scalars, out_ptrs, mode=BlendedFrame, calculate_flow=True):
+        """The arguments of one hf_batch_run_period call, marshalled once (a driver's schedule is known ahead of time);
+        dev_ptrs / scalars may be None to skip the update / the warps."""
+        n, K = len(self.members), capi.HF_MAX_PERIOD_OUTPUTS
+        frames = (C.c_void_p * n)(*[int(p) for p in dev_ptrs]) if dev_ptrs is not None else None
+        counts = t = outs = None
+        if scalars is not None:
+            counts = (C.c_int * n)(*[len(ts) for ts in scalars])
+            t = (C.c_float * (n * K))()
+            outs = (C.c_void_p * (n * K))()
+            for i, ts in enumerate(scalars):
+                for k, x in enumerate(ts):
+                    t[i * K + k] = float(x)
+                    outs[i * K + k] = int(out_ptrs[i][k])
+        return (frames, 1 if calculate_flow else 0, counts, t, outs, int(mode))
+
+    def runPeriod(self, prepared):
+        """updateFramesDeviceRef + calculateOpticalFlow + interpolatePeriod of one source period in ONE native call."""
+        rc = self._lib.hf_batch_run_period(self._b, *prepared)
+        if rc != 0:
+            self._check(rc)
+
+    def sync(self):
+        self._check(self._lib.hf_batch_sync(self._b))
 
     def __len__(self):
         return self._lib.hf_batch_size(self._b)

@@ -15,6 +15,7 @@ HF_FLAG_NO_LAZY_ARGMIN = 0x8
 HF_FLAG_DUAL_STREAM = 0x40
 HF_FLAG_NO_FUSED_WARP = 0x80
 HF_FLAG_NO_TIMING = 0x200
+HF_FLAG_BATCH_NORMAL_PRIORITY = 0x800
 HF_MAX_PERIOD_OUTPUTS = 6
 
 (HF_OK, HF_ERR_INVALID_ARGUMENT, HF_ERR_NO_DEVICE, HF_ERR_OUT_OF_MEMORY, HF_ERR_HIP, HF_ERR_STATE) = (0, -1, -2, -3, -4, -5)
@@ -29,6 +30,11 @@ class HfConfig(C.Structure):
                 ("flags", C.c_uint32)]
 
 
+class HfDeviceCaps(C.Structure):
+    _fields_ = [("vram_bytes", C.c_uint64), ("lds_bytes_per_workgroup", C.c_uint64), ("max_threads_per_workgroup", C.c_int32),
+                ("wavefront_size", C.c_int32)]
+
+
 class HfParams(C.Structure):
     _fields_ = [("delta_scalar", C.c_int32), ("neighbor_scalar", C.c_int32), ("black_level", C.c_float),
                 ("white_level", C.c_float), ("search_radius", C.c_int32), ("frame_count", C.c_uint32)]
@@ -40,7 +46,7 @@ class HfStats(C.Structure):
                 ("res_scalar", C.c_int32), ("low_width", C.c_int32), ("low_height", C.c_int32),
                 ("frame_width", C.c_int32), ("frame_height", C.c_int32), ("input_stride", C.c_int32),
                 ("output_stride", C.c_int32), ("iterations", C.c_int32), ("initial_window", C.c_int32),
-                ("input_frame_bytes", C.c_uint64), ("output_frame_bytes", C.c_uint64)]
+                ("input_frame_bytes", C.c_uint64), ("output_frame_bytes", C.c_uint64), ("phase_plane_bytes", C.c_uint64)]
 
 
 class HfProfile(C.Structure):
@@ -69,6 +75,8 @@ SIGNATURES = {
     "hf_destroy": (None, [_vp]),
     "hf_last_error": (C.c_char_p, [_vp]),
     "hf_abi_version": (_i, []),
+    "hf_select_device": (_i, [C.POINTER(HfDeviceCaps), _i, C.c_uint64, C.c_char_p, C.c_size_t]),
+    "hf_get_device": (_i, [_vp]),
     "hf_update_frame": (_i, [_vp, _vp]),
     "hf_calculate_optical_flow": (_i, [_vp]),
     "hf_warp_frames": (_i, [_vp, _f, _i]),
@@ -88,6 +96,8 @@ SIGNATURES = {
     "hf_batch_calculate_optical_flow": (_i, [_vp]),
     "hf_batch_update_frames_device_ref": (_i, [_vp, C.POINTER(_vp)]),
     "hf_batch_interpolate_period": (_i, [_vp, C.POINTER(_i), C.POINTER(C.c_float), C.POINTER(_vp), _i]),
+    "hf_batch_run_period": (_i, [_vp, C.POINTER(_vp), _i, C.POINTER(_i), C.POINTER(C.c_float), C.POINTER(_vp), _i]),
+    "hf_batch_sync": (_i, [_vp]),
     "hf_batch_size": (_i, [_vp]),
     "hf_batch_last_error": (C.c_char_p, [_vp]),
     "hf_download_frame_device": (_i, [_vp, _vp]),

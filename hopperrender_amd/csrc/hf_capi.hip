@@ -455,6 +455,32 @@ int hf_device_count(void) {
     return n;
 }
 
+// detectDevices' selection rule on a capability table (opticalFlowCalc.cpp:67-93): the first entry with enough memory, >= 2 KB
+// of LDS per workgroup and 16 x 16 workgroups -- plus, for this build's kernels, 64-wide wavefronts.
+int hf_select_device(const hf_device_caps* caps, int n, uint64_t required_vram_bytes, char* why_not, size_t why_not_size) {
+    if (why_not && why_not_size) why_not[0] = 0;
+    if (!caps || n < 1) return -1;
+    for (int d = 0; d < n; d++)
+        if (caps[d].vram_bytes >= required_vram_bytes && caps[d].lds_bytes_per_workgroup >= 2048 && caps[d].max_threads_per_workgroup >= 256 &&
+            caps[d].wavefront_size == 64)
+            return d;
+    if (why_not && why_not_size) {   // the reference reports the LAST device it looked at (:98-108)
+        const hf_device_caps& k = caps[n - 1];
+        size_t o = 0;
+        auto add = [&](const char* fmt, auto... v) { if (o < why_not_size) { const int w = snprintf(why_not + o, why_not_size - o, fmt, v...); if (w > 0) o += (size_t)w; } };
+        if (k.vram_bytes < required_vram_bytes)
+            add("Not enough VRAM available! Required: %llu MB, Available: %llu MB. ", (unsigned long long)(required_vram_bytes / 1024 / 1024), (unsigned long long)(k.vram_bytes / 1024 / 1024));
+        if (k.lds_bytes_per_workgroup < 2048)
+            add("Not enough shared memory available! Required: 2048 bytes, Available: %llu bytes. ", (unsigned long long)k.lds_bytes_per_workgroup);
+        if (k.max_threads_per_workgroup < 256)
+            add("Not enough work group sizes available! Required: 16, 16, 1 (256 threads), Available: %d threads. ", k.max_threads_per_workgroup);
+        if (k.wavefront_size != 64) add("Wavefront size %d, the kernels need 64. ", k.wavefront_size);
+    }
+    return -1;
+}
+
+int hf_get_device(const hf_ctx* c) { return c ? c->device : -1; }
+
 int hf_create(const hf_config* cfg, hf_ctx** out_ctx) {
     if (!cfg || !out_ctx) return fail(nullptr, HF_ERR_INVALID_ARGUMENT, "hf_create: null argument");
     *out_ctx = nullptr;
@@ -466,23 +492,13 @@ int hf_create(const hf_config* cfg, hf_ctx** out_ctx) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(nullptr, HF_ERR_NO_DEVICE, "Error in function detectDevices: no HIP device available");
-    if (cfg->device_index < 0 || cfg->device_index >= ndev)
+    if (cfg->device_index < -1 || cfg->device_index >= ndev)
         return fail(nullptr, HF_ERR_NO_DEVICE, "Error in function detectDevices: device %d of %d", cfg->device_index, ndev);
-    {   // detectDevices (opticalFlowCalc.cpp:48-55,88-89): the device must offer the memory, LDS and workgroup size the
-        // calculator needs.  The reference prices 9 H S_in + 3 H S_out (HDR worst case) + offset / sum arrays; this build
-        // keeps 3 frames + 3 phase planes + 1 output frame + small tables, priced exactly below once the geometry is known.
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, cfg->device_index) != hipSuccess)
-            return fail(nullptr, HF_ERR_NO_DEVICE, "Error in function detectDevices: cannot query device %d", cfg->device_index);
-        if (prop.maxThreadsPerBlock < 256 || prop.sharedMemPerBlock < 2048 || prop.warpSize != 64)
-            return fail(nullptr, HF_ERR_NO_DEVICE, "Error in function detectDevices: device %d (%s) lacks 256-thread workgroups, 2 KB of LDS or 64-wide wavefronts",
-                        cfg->device_index, prop.name);
-    }
 
     hf_ctx* c = new (std::nothrow) hf_ctx();
     if (!c) return fail(nullptr, HF_ERR_OUT_OF_MEMORY, "hf_create: host allocation failed");
     c->cfg = *cfg;
-    c->device = cfg->device_index;
+    c->device = cfg->device_index >= 0 ? cfg->device_index : 0;   // (-1: settled by detectDevices below)
     hf::Geom& g = c->g;
     g.hdr = cfg->is_hdr ? 1 : 0;
     g.H = cfg->frame_height;
@@ -534,17 +550,41 @@ int hf_create(const hf_config* cfg, hf_ctx** out_ctx) {
     c->sums_bytes = (size_t)kMaxSteps * c->sums_stride * sizeof(uint32_t);
     int rc = HF_OK;
     auto bail = [&](int code) { std::string e = c->err; hf_destroy(c); g_create_error = e; return code; };
-    if ((rc = set_device(c))) return bail(rc);
-    {   // detectDevices, memory half (opticalFlowCalc.cpp:39-43,88: requiredVRAM vs CL_DEVICE_GLOBAL_MEM_SIZE)
-        const size_t required = 3 * c->in_bytes + 3 * c->pl.bytes + c->out_bytes + c->tables_bytes + c->sums_bytes +
-                                2 * c->plane_elems * sizeof(int16_t) * 3 + 2 * c->plane_elems * sizeof(uint32_t);
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < required) {
-            fail(c, HF_ERR_NO_DEVICE, "Error in function detectDevices: not enough VRAM available! Required: %zu MB, Available: %zu MB",
-                 required / 1024 / 1024, free_b / 1024 / 1024);
+    {   // detectDevices (opticalFlowCalc.cpp:45-109): the device must offer the memory, LDS and workgroup size the calculator
+        // needs.  The reference prices 9 H S_in + 3 H S_out (HDR worst case) + offset / sum arrays against the device's TOTAL
+        // memory and takes the FIRST device that qualifies; this build keeps 3 frames + 3 phase planes + 1 output frame + small
+        // tables, priced exactly, and additionally requires that much memory to be FREE on the device it settles on.
+        // device_index >= 0 pins the ordinal (one process per GPU); -1 scans like the reference.
+        const uint64_t required = 3 * c->in_bytes + 3 * c->pl.bytes + c->out_bytes + c->tables_bytes + c->sums_bytes +
+                                  2 * c->plane_elems * sizeof(int16_t) * 3 + 2 * c->plane_elems * sizeof(uint32_t);
+        std::vector<hf_device_caps> caps((size_t)ndev);
+        for (int d = 0; d < ndev; d++) {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, d) != hipSuccess) { caps[(size_t)d] = hf_device_caps{}; continue; }
+            caps[(size_t)d] = hf_device_caps{(uint64_t)prop.totalGlobalMem, (uint64_t)prop.sharedMemPerBlock, prop.maxThreadsPerBlock, prop.warpSize};
+        }
+        char why[384] = "";
+        const int first = cfg->device_index >= 0 ? cfg->device_index : 0, last = cfg->device_index >= 0 ? cfg->device_index + 1 : ndev;
+        int chosen = -1;
+        for (int start = first; start < last && chosen < 0;) {
+            const int rel = hf_select_device(caps.data() + start, last - start, required, why, sizeof(why));
+            if (rel < 0) break;
+            const int d = start + rel;
+            size_t free_b = 0, total_b = 0;
+            if (hipSetDevice(d) == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b >= required) { chosen = d; break; }
+            snprintf(why, sizeof(why), "Not enough VRAM available! Required: %llu MB, Available: %llu MB", (unsigned long long)(required / 1024 / 1024),
+                     (unsigned long long)(free_b / 1024 / 1024));
+            start = d + 1;   // suitable on paper but occupied: move on, as the reference's loop does for an unsuitable device
+        }
+        if (chosen < 0) {
+            fail(c, HF_ERR_NO_DEVICE, "Error in function detectDevices: no suitable HIP GPU found among device%s %d..%d! %s", last - first > 1 ? "s" : "",
+                 first, last - 1, why);
             return bail(HF_ERR_NO_DEVICE);
         }
+        c->device = chosen;
+        c->cfg.device_index = chosen;
     }
+    if ((rc = set_device(c))) return bail(rc);
 #define HF_TRY(call) do { hipError_t _e = (call); if (_e != hipSuccess) { \
         fail(c, _e == hipErrorOutOfMemory ? HF_ERR_OUT_OF_MEMORY : HF_ERR_HIP, "HIP error %d (%s) in %s", (int)_e, hipGetErrorString(_e), #call); \
         return bail(_e == hipErrorOutOfMemory ? HF_ERR_OUT_OF_MEMORY : HF_ERR_HIP); } } while (0)
@@ -826,12 +866,18 @@ int hf_batch_create(hf_ctx* const* members, int n, hf_batch** out) {
     // GPU_MAX_HW_QUEUES of them sit on different hardware queues whatever was created before.  (With the leader's stream, two
     // batches whose leaders were 32 streams apart shared ONE queue and ran strictly one after the other: 64 x 32 at 103 k
     // instead of 115 k frames/s; a normal-priority stream of the batch's own did the same at 48 x 24.)
+    // Side effect (include/hopperflow.h): the priority is real -- batch work is scheduled ahead of the normal-priority streams
+    // of the process.  HF_FLAG_BATCH_NORMAL_PRIORITY on the leader opts out (and gives up the private queue pool).
     {
         int prio_low = 0, prio_high = 0;
-        (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
-        if (hipStreamCreateWithPriority(&b->stream, hipStreamNonBlocking, prio_high) != hipSuccess) {
-            delete b;
-            return batch_fail(nullptr, HF_ERR_HIP, "hf_batch_create: cannot create the batch stream");
+        const bool want_high = !(l->cfg.flags & HF_FLAG_BATCH_NORMAL_PRIORITY) && hipDeviceGetStreamPriorityRange(&prio_low, &prio_high) == hipSuccess;
+        if (!want_high || hipStreamCreateWithPriority(&b->stream, hipStreamNonBlocking, prio_high) != hipSuccess) {
+            (void)hipGetLastError();
+            b->stream = nullptr;
+            if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) {
+                delete b;
+                return batch_fail(nullptr, HF_ERR_HIP, "hf_batch_create: cannot create the batch stream");
+            }
         }
     }
     if (l->dual()) {
@@ -894,14 +940,16 @@ int hf_batch_update_frames_device_ref(hf_batch* b, const void* const* device_fra
     if (hipSetDevice(l->device) != hipSuccess) return batch_fail(b, HF_ERR_HIP, "hipSetDevice failed");
     hf::PrepBatch pb{};
     pb.n = n;
+    // first pass: everything that can fail, before any member's ring is touched (a failure leaves every member as it was)
     for (int i = 0; i < n; i++) {
         hf_ctx* m = b->members[i];
         if (!device_frames[i]) return batch_fail(b, HF_ERR_INVALID_ARGUMENT, "hf_batch_update_frames_device_ref: null frame");
         if (int rc = leave_warp_stream(m)) return batch_fail(b, rc, m->err);
-        if (m->timing()) {
-            if (hipEventRecord(m->ev_upload, b->stream) != hipSuccess) return batch_fail(b, HF_ERR_HIP, "hipEventRecord failed");
-            m->upload_recorded = true;
-        }
+        if (m->timing() && hipEventRecord(m->ev_upload, b->stream) != hipSuccess) return batch_fail(b, HF_ERR_HIP, "hipEventRecord failed");
+    }
+    for (int i = 0; i < n; i++) {
+        hf_ctx* m = b->members[i];
+        if (m->timing()) m->upload_recorded = true;
         m->ring[0] = const_cast<void*>(device_frames[i]);   // the ring references the caller's frame (hf_update_frame_device_ref)
         pb.frame[i] = m->ring[0];
         pb.pp[i] = m->pp[0];
@@ -1066,8 +1114,14 @@ int hf_batch_interpolate_period(hf_batch* b, const int* n_out, const float* t, v
     hf_ctx* l = b->members[0];
     const int n = (int)b->members.size();
     if (hipSetDevice(l->device) != hipSuccess) return batch_fail(b, HF_ERR_HIP, "hipSetDevice failed");
-    bool one_launch = !l->dual() && !(l->cfg.flags & HF_FLAG_NO_FUSED_WARP);
+    bool one_launch = !l->dual();
     for (int m = 0; m < n; m++) {
+        hf_ctx* c = b->members[m];
+        if (!c) return batch_fail(b, HF_ERR_INVALID_ARGUMENT, "null context");
+        // batch members have no asynchronous host I/O (hf_batch_create / hf_*_async enforce it), so there is no output-ring slot to
+        // guard and no side stream to notify here -- the one-launch path relies on that
+        if (c->io_in) return batch_fail(b, HF_ERR_STATE, "hf_batch_interpolate_period: a member uses asynchronous host I/O");
+        one_launch = one_launch && !(c->cfg.flags & HF_FLAG_NO_FUSED_WARP);
         if (n_out[m] < 0 || n_out[m] > HF_MAX_PERIOD_OUTPUTS) return batch_fail(b, HF_ERR_INVALID_ARGUMENT, "hf_batch_interpolate_period: n_out outside [0, 6]");
         for (int i = 0; i < n_out[m]; i++)
             if (t[m * HF_MAX_PERIOD_OUTPUTS + i] > 1.0f)
@@ -1096,6 +1150,22 @@ int hf_batch_interpolate_period(hf_batch* b, const int* n_out, const float* t, v
     for (int m = 0; m < n; m++)   // not eligible (diagnostic modes, odd shapes, dual-stream members): member by member
         if (int rc = hf_interpolate_period_ex(b->members[m], nullptr, n_out[m], t + m * HF_MAX_PERIOD_OUTPUTS, device_out + m * HF_MAX_PERIOD_OUTPUTS, mode, 0))
             return batch_fail(b, rc, b->members[m]->err);
+    return HF_OK;
+}
+
+int hf_batch_run_period(hf_batch* b, const void* const* device_frames, int calculate_flow, const int* n_out, const float* t,
+                        void* const* device_out, int mode) {
+    if (!b) return batch_fail(nullptr, HF_ERR_INVALID_ARGUMENT, "null batch");
+    if (device_frames) if (int rc = hf_batch_update_frames_device_ref(b, device_frames)) return rc;
+    if (calculate_flow) if (int rc = hf_batch_calculate_optical_flow(b)) return rc;
+    if (n_out) if (int rc = hf_batch_interpolate_period(b, n_out, t, device_out, mode)) return rc;
+    return HF_OK;
+}
+
+int hf_batch_sync(hf_batch* b) {
+    if (!b) return batch_fail(nullptr, HF_ERR_INVALID_ARGUMENT, "null batch");
+    for (hf_ctx* m : b->members)
+        if (int rc = hf_sync(m)) return batch_fail(b, rc, m->err);
     return HF_OK;
 }
 
@@ -1172,6 +1242,7 @@ int hf_get_stats(hf_ctx* c, hf_stats* out) {
     out->initial_window = c->initial_window;
     out->input_frame_bytes = c->in_bytes;
     out->output_frame_bytes = c->out_bytes;
+    out->phase_plane_bytes = c->pl.bytes;
     return HF_OK;
 }
 

@@ -184,8 +184,8 @@ int hf_filter_get_state(const hf_filter* f, hf_filter_state* out) {
 int hf_filter_deliver(hf_filter* f, hf_ctx* ctx, const void* host_in, void* const* host_out, int max_out, int* n_out, int32_t* kinds) {
     if (!f || !ctx || !host_in || !host_out || !n_out) return HF_ERR_INVALID_ARGUMENT;
     *n_out = 0;
-    const int n = hf_filter_begin_source_frame(f);                            // :944-948
-    if (n > max_out) return HF_ERR_INVALID_ARGUMENT;
+    const int n = hf_filter_begin_source_frame(f);                            // :944-948 (a pure function of the state: calling it twice is harmless)
+    if (n > max_out) { *n_out = n; return HF_ERR_INVALID_ARGUMENT; }          // nothing else has happened yet; *n_out = buffers needed
     hf_params p{};
     hf_stats st{};
     int rc = hf_get_params(ctx, &p);

@@ -834,8 +834,9 @@ void launch_pack_flow(const Geom& g, const int16_t* flow, uint32_t* packed, hipS
 
 // Fast-path launch for VB bytes per thread and row (all members of `b` in one launch).  Returns false when the
 // shape of any member does not qualify.
+// Does the fast kernel with VB bytes per thread and row apply to every member of `b`?  dw: dword-aligned source loads possible.
 template <typename E, int VB>
-static bool launch_warp_fast(const Geom& g, const WarpBatchArgs& b, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+static bool warp_fast_shape(const Geom& g, const WarpBatchArgs& b, bool& dw) {
     constexpr int VEC = VB / sizeof(E);
     const int cell = 1 << g.rs;
     const int group = cell < VEC ? cell : VEC;
@@ -843,7 +844,7 @@ static bool launch_warp_fast(const Geom& g, const WarpBatchArgs& b, hipStream_t 
     bool fast = mode >= 0 && mode <= 2 && (g.in_stride % 2) == 0 && (g.out_stride % VEC) == 0 &&
                 g.W >= 2 * VEC && group * (int)sizeof(E) >= 4 && VEC % group == 0 && VEC / group <= 4;
     // dword-aligned source loads (load_run_dw) need dword-aligned frames and rows that end on a dword
-    bool dw = ((size_t)g.in_stride * sizeof(E)) % 4 == 0 && ((size_t)g.W * sizeof(E)) % 4 == 0 && ((size_t)g.H * g.in_stride * sizeof(E)) % 4 == 0;
+    dw = ((size_t)g.in_stride * sizeof(E)) % 4 == 0 && ((size_t)g.W * sizeof(E)) % 4 == 0 && ((size_t)g.H * g.in_stride * sizeof(E)) % 4 == 0;
     for (int m = 0; m < b.n && fast; m++) {
         const WarpArgs& a = b.s[m];
         // blend shortcuts of the fast kernel need 0 <= t <= 1 and levels that cannot produce NaN;
@@ -854,7 +855,21 @@ static bool launch_warp_fast(const Geom& g, const WarpBatchArgs& b, hipStream_t 
             fast = fast && a.s12v[i] >= 0.0f && a.s12v[i] <= 1.0f && (((uintptr_t)a.outv[i]) & (VB - 1)) == 0;
         dw = dw && (((uintptr_t)a.frame12 | (uintptr_t)a.frame21) & 3) == 0;
     }
-    if (!fast) return false;
+    return fast;
+}
+template <typename E>
+static constexpr bool warp_small_frame(const Geom& g) {   // frames up to 1080p 8-bit: 8 bytes per thread (twice the waves)
+    return (size_t)g.W * g.H * sizeof(E) <= (size_t)1920 * 1088;
+}
+
+template <typename E, int VB>
+static bool launch_warp_fast(const Geom& g, const WarpBatchArgs& b, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+    constexpr int VEC = VB / sizeof(E);
+    const int cell = 1 << g.rs;
+    const int group = cell < VEC ? cell : VEC;
+    const int mode = b.s[0].mode;
+    bool dw = false;
+    if (!warp_fast_shape<E, VB>(g, b, dw)) return false;
     const int rows = 2;  // rows per thread (divides the 2^rs rows of a flow cell); measured on MI355X, 2160p HDR blend: 1 row 25.9 us, 2 rows 24.3 us, 4 rows 30.2 us
                          // (re-measured with the final kernel, fused period HBM-cold: 2 rows 51.1 us, 4 rows 59.3 us -- halving the
                          // per-element scalar work does not pay for halving the number of waves)
@@ -898,7 +913,7 @@ static bool launch_warp_fast(const Geom& g, const WarpBatchArgs& b, hipStream_t 
 // frames up to 1080p 8-bit: 8 bytes per thread (twice the waves); larger frames: 16 bytes per thread
 template <typename E>
 static bool launch_warp_fast_any(const Geom& g, const WarpBatchArgs& b, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
-    const bool small = (size_t)g.W * g.H * sizeof(E) <= (size_t)1920 * 1088;   // (1080p SDR, 5-output period: 18.9 us with 8-byte threads, 26.8 us with 16-byte ones)
+    const bool small = warp_small_frame<E>(g);   // (1080p SDR, 5-output period: 18.9 us with 8-byte threads, 26.8 us with 16-byte ones)
     if (small && launch_warp_fast<E, 8>(g, b, stream, ev0, ev1)) return true;   // (also in a batch of 16: 114.3 k frames/s against 100.2 k with 16-byte threads)
     return launch_warp_fast<E, 16>(g, b, stream, ev0, ev1);
 }
@@ -925,25 +940,42 @@ void launch_warp(const Geom& g, const void* frame12, const void* frame21, const 
     else launch_warp_t<uint8_t>(g, a, stream, ev0, ev1);
 }
 
+// Launch arguments of members [first, first + b.n) of a set of periods; false: a member's n_out is out of range.
+static bool fill_warp_batch(const WarpPeriod* periods, int n, int first, int mode, WarpBatchArgs& b) {
+    b.n = n - first < kMaxWarpBatch ? n - first : kMaxWarpBatch;
+    for (int m = 0; m < b.n; m++) {
+        const WarpPeriod& p = periods[first + m];
+        if (p.n_out < 1 || p.n_out > kMaxWarpOutputs) return false;
+        WarpArgs& a = b.s[m];
+        a.frame12 = p.frame12; a.frame21 = p.frame21; a.flow = p.flow; a.flow_xy = p.flow_xy; a.out = p.outs[0];
+        a.mode = mode; a.black = p.black; a.white = p.white;
+        a.n_out = p.n_out;
+        for (int i = 0; i < p.n_out; i++) { a.s12v[i] = p.ts[i]; a.s21v[i] = 1.0f - p.ts[i]; a.outv[i] = p.outs[i]; }
+        a.s12 = a.s12v[0]; a.s21 = a.s21v[0];
+    }
+    return true;
+}
+template <typename E>
+static bool warp_fast_any_shape(const Geom& g, const WarpBatchArgs& b) {
+    bool dw = false;
+    return (warp_small_frame<E>(g) && warp_fast_shape<E, 8>(g, b, dw)) || warp_fast_shape<E, 16>(g, b, dw);
+}
+
 bool launch_warp_periods(const Geom& g, int n, const WarpPeriod* periods, int mode, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
     if (n < 1 || n > kMaxFlowBatch) return false;
-    // at most kMaxWarpBatch members per launch (kernel-argument space): a batch of 32 is two launches
+    // at most kMaxWarpBatch members per launch (kernel-argument space): a batch of 32 is two launches.  ALL of them are
+    // checked before the first one goes out, so a set of periods is either rendered by these launches or not touched at all
     for (int first = 0; first < n; first += kMaxWarpBatch) {
         WarpBatchArgs b;
-        b.n = n - first < kMaxWarpBatch ? n - first : kMaxWarpBatch;
-        for (int m = 0; m < b.n; m++) {
-            const WarpPeriod& p = periods[first + m];
-            if (p.n_out < 1 || p.n_out > kMaxWarpOutputs) return false;
-            WarpArgs& a = b.s[m];
-            a.frame12 = p.frame12; a.frame21 = p.frame21; a.flow = p.flow; a.flow_xy = p.flow_xy; a.out = p.outs[0];
-            a.mode = mode; a.black = p.black; a.white = p.white;
-            a.n_out = p.n_out;
-            for (int i = 0; i < p.n_out; i++) { a.s12v[i] = p.ts[i]; a.s21v[i] = 1.0f - p.ts[i]; a.outv[i] = p.outs[i]; }
-            a.s12 = a.s12v[0]; a.s21 = a.s21v[0];
-        }
+        if (!fill_warp_batch(periods, n, first, mode, b)) return false;
+        if (!(g.hdr ? warp_fast_any_shape<uint16_t>(g, b) : warp_fast_any_shape<uint8_t>(g, b))) return false;
+    }
+    for (int first = 0; first < n; first += kMaxWarpBatch) {
+        WarpBatchArgs b;
+        fill_warp_batch(periods, n, first, mode, b);
         hipEvent_t e0 = first == 0 ? ev0 : nullptr, e1 = first + kMaxWarpBatch >= n ? ev1 : nullptr;
         const bool ok = g.hdr ? launch_warp_fast_any<uint16_t>(g, b, stream, e0, e1) : launch_warp_fast_any<uint8_t>(g, b, stream, e0, e1);
-        if (!ok) return false;   // (the caller renders every output again, one launch each: same frames)
+        if (!ok) return false;   // (cannot happen after the check above)
     }
     return true;
 }

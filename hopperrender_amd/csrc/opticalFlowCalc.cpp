@@ -28,6 +28,7 @@ void OpticalFlowCalc::init(bool hdr, int frameHeight, int frameWidth, int inputS
     cfg.black_level = blackLevel;
     cfg.white_level = whiteLevel;
     cfg.max_calc_res = maxCalcRes;
+    cfg.device_index = -1;   // detectDevices: the first suitable device (opticalFlowCalc.cpp:67-93), not a fixed ordinal
     const int rc = hf_create(&cfg, &m_ctx);
     if (rc != HF_OK) {
         std::string msg = hf_last_error(nullptr);
@@ -44,7 +45,7 @@ void OpticalFlowCalc::init(bool hdr, int frameHeight, int frameWidth, int inputS
     pull();
     hf_stats st{};
     hf_get_stats(m_ctx, &st);
-    printf("[HopperRender] Using HIP device %d and %llu MB of VRAM\n", cfg.device_index,   // opticalFlowCalc.cpp:90
+    printf("[HopperRender] Using HIP device %d and %llu MB of VRAM\n", hf_get_device(m_ctx),   // opticalFlowCalc.cpp:90
            (unsigned long long)((3 * st.input_frame_bytes + st.output_frame_bytes) / 1024 / 1024));
 }
 

@@ -166,7 +166,9 @@ class NativeFilter:
         import numpy as np
         C = self._C
         a = np.ascontiguousarray(input_frame)
-        K = 16
+        # the number of outputs of this period is a pure function of the filter state (m_iNumIntFrames, :944-948; a slowed-down
+        # segment can ask for any number): ask first, then hand over exactly that many frame buffers
+        K = max(1, self.begin_source_frame())
         outs = [np.empty(calc.output_frame_bytes // np.dtype(calc.dtype).itemsize, dtype=calc.dtype) for _ in range(K)]
         ptrs = (C.c_void_p * K)(*[o.ctypes.data for o in outs])
         n, kinds = C.c_int(), (C.c_int32 * K)()

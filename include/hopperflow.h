@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HF_ABI_VERSION 2
+#define HF_ABI_VERSION 3
 
 typedef struct hf_ctx hf_ctx;
 
@@ -62,6 +62,8 @@ typedef enum hf_output_mode {
                                     calculateOpticalFlow produces the next flow from N-1/N into the other buffer, so the two
                                     overlap inside one context; events keep every other ordering intact */
 #define HF_FLAG_NO_FUSED_WARP 0x80 /* hf_interpolate_period: one warp launch per output frame (debug / A-B timing) */
+#define HF_FLAG_BATCH_NORMAL_PRIORITY 0x800 /* on the leader passed to hf_batch_create: give the batch a normal-priority stream
+                                                (default: highest priority, see hf_batch_create) */
 #define HF_FLAG_NO_TIMING 0x200 /* do not record the events behind m_ofcCalcTime / m_warpCalcTime (hf_stats times stay 0).
                                    Every timing event is a barrier packet on the stream: measured 5-6 us each between
                                    back-to-back kernels, ~15 us per source period in a throughput pipeline */
@@ -83,7 +85,8 @@ typedef struct hf_config {
     float white_level;      /* ctor arg 8, 0..255 */
     int32_t max_calc_res;   /* ctor arg 9, config.h:4 default 270 */
     /* --- extensions --- */
-    int32_t device_index;   /* HIP device ordinal (reference: first suitable OpenCL device) */
+    int32_t device_index;   /* HIP device ordinal, or -1 = the first suitable device like the reference's detectDevices
+                               (opticalFlowCalc.cpp:67-93); hf_get_device() tells which one it became */
     int32_t iterations;     /* NUM_ITERATIONS (config.h:6) made runtime; 0 = auto */
     int32_t blur_radius;    /* KERNEL_RADIUS (blurFlowKernelSDR.h:4) made runtime; 0 -> 4 */
     int32_t search_radius;  /* initial m_opticalFlowSearchRadius; 0 -> MIN_SEARCH_RADIUS 5 (:216) */
@@ -115,6 +118,7 @@ typedef struct hf_stats {
     int32_t initial_window;     /* first window size (opticalFlowCalcSDR.cpp:49-59) */
     uint64_t input_frame_bytes; /* bytes updateFrame reads  = bpp*(H*S_in + (H/2)*S_in)  (:20) */
     uint64_t output_frame_bytes;/* bytes downloadFrame writes = bpp*(H*S_out + (H/2)*S_out) (:33) */
+    uint64_t phase_plane_bytes; /* bytes of one phase plane (this build's re-laid copy of a frame) */
 } hf_stats;
 
 /* ---- lifecycle: constructor / destructor (opticalFlowCalcSDR.cpp:206-325, :185-204) ---- */
@@ -122,6 +126,20 @@ int hf_create(const hf_config* cfg, hf_ctx** out_ctx);
 void hf_destroy(hf_ctx* ctx);
 const char* hf_last_error(const hf_ctx* ctx);
 int hf_abi_version(void);
+
+/* detectDevices (opticalFlowCalc.cpp:45-109) as a pure function over a capability table, so that the rule can be tested
+ * without hardware: index of the FIRST entry with vram_bytes >= required_vram_bytes, >= 2048 bytes of LDS per workgroup,
+ * workgroups of 256 threads (16 x 16) and 64-wide wavefronts, or -1.  why_not (optional) receives the reference's messages
+ * for the last entry inspected (:98-108).  hf_create(device_index = -1) applies it to the HIP devices (vram = total device
+ * memory, as the reference compares CL_DEVICE_GLOBAL_MEM_SIZE) and then insists on that much FREE memory, moving on if not. */
+typedef struct hf_device_caps {
+    uint64_t vram_bytes;
+    uint64_t lds_bytes_per_workgroup;
+    int32_t max_threads_per_workgroup;
+    int32_t wavefront_size;
+} hf_device_caps;
+int hf_select_device(const hf_device_caps* caps, int n, uint64_t required_vram_bytes, char* why_not, size_t why_not_size);
+int hf_get_device(const hf_ctx* ctx);   /* the HIP ordinal the context lives on */
 
 /* ---- the five virtuals of OpticalFlowCalc (opticalFlowCalc.h:100-132) ---- */
 /* updateFrame (opticalFlowCalcSDR.cpp:19-29): upload one NV12/P010 frame, rotate the 3-frame ring, frame_count++ */
@@ -171,6 +189,12 @@ int hf_interpolate_period_ex(hf_ctx* ctx, const void* device_frame, int n_out, c
  *   - members: HF_FLAG_ASYNC contexts without async host I/O, all single-stream or all HF_FLAG_DUAL_STREAM, same device, frame geometry, iterations, blur radius; at call time the same search
  *     radius / delta / neighbor scalar.  DUAL_STREAM members issue their warps on up to 3 streams the batch shares
  *     out round robin (they overlap the batched chain; measured slower than single-stream batches).
+ *   - the batch issues on a stream of its own of the HIGHEST priority.  Not for the priority: the HIP runtime keeps one pool of
+ *     hardware queues per priority and nobody else creates such streams, so the batch streams of a process land on different
+ *     hardware queues whatever was created before them (DESIGN.md "Streams and hardware queues").  SIDE EFFECT: the priority is
+ *     real -- batch launches are scheduled ahead of every normal-priority stream of the process (other contexts' work and
+ *     asynchronous I/O, RCCL).  A host that mixes batches with latency-sensitive single contexts passes
+ *     HF_FLAG_BATCH_NORMAL_PRIORITY on the leader; if the priority range cannot be queried the batch falls back to a normal stream.
  *   - while the batch exists all members issue on ONE stream (the batch's own): their hf_update_frame_device*,
  *     hf_interpolate_period_ex(..., update_and_flow = 0), hf_sync ... calls keep working and stay in program order
  *     with the batched chain.  Destroy the batch before its members. */
@@ -187,6 +211,13 @@ int hf_batch_update_frames_device_ref(hf_batch* batch, const void* const* device
  * selects the member's internal output frame. */
 #define HF_MAX_PERIOD_OUTPUTS 6
 int hf_batch_interpolate_period(hf_batch* batch, const int* n_out, const float* t, void* const* device_out, int mode);
+/* One source period of the whole batch in ONE call (what a throughput driver issues per period -- three calls' worth of
+ * argument marshalling matter when a period is ~70 us of GPU time): hf_batch_update_frames_device_ref(device_frames) unless
+ * device_frames == NULL, hf_batch_calculate_optical_flow() if calculate_flow, hf_batch_interpolate_period(n_out, t,
+ * device_out, mode) unless n_out == NULL.  Same results and same error behaviour as the three calls. */
+int hf_batch_run_period(hf_batch* batch, const void* const* device_frames, int calculate_flow, const int* n_out, const float* t,
+                        void* const* device_out, int mode);
+int hf_batch_sync(hf_batch* batch);   /* hf_sync() of every member */
 int hf_batch_size(const hf_batch* batch);
 const char* hf_batch_last_error(const hf_batch* batch);   /* batch == NULL: error of the last failed hf_batch_create (per thread) */
 
@@ -268,7 +299,10 @@ int hf_filter_push_frame_delta(hf_filter* filter, uint32_t frame_count, uint32_t
 int hf_filter_detect_scene_change(hf_filter* filter, uint32_t frame_count);     /* :1126-1176; 1 = copyFrame instead of warpFrames */
 int hf_filter_get_state(const hf_filter* filter, hf_filter_state* out);
 /* One DeliverToRenderer (:938-1197) on a blocking context: host_out[i] receives output frame i (n = return of
- * hf_filter_begin_source_frame <= max_out), kinds[i] (optional) = 1 warp / 0 copy. */
+ * hf_filter_begin_source_frame <= max_out), kinds[i] (optional) = 1 warp / 0 copy.  The number of outputs is unbounded in
+ * principle (a slowed-down segment): call hf_filter_begin_source_frame() first to size host_out -- it only recomputes
+ * m_iNumIntFrames from the state -- or retry after HF_ERR_INVALID_ARGUMENT with the *n_out buffers it then reports (nothing else
+ * has been touched at that point). */
 int hf_filter_deliver(hf_filter* filter, hf_ctx* ctx, const void* host_in, void* const* host_out, int max_out, int* n_out, int32_t* kinds);
 
 /* ---- plain device-memory helpers so non-HIP hosts (ctypes, cgo, JNI) can stage frames ---- */

@@ -103,6 +103,72 @@ def test_large_batched_periods_equal_single_contexts(native_lib, hdr, H, W, n, R
         c.close()
 
 
+def test_run_period_is_the_three_calls(native_lib):
+    """hf_batch_run_period (one native call per batch and source period, what bench.py and examples/hf_batch_driver.c issue)
+    == hf_batch_update_frames_device_ref + hf_batch_calculate_optical_flow + hf_batch_interpolate_period, also with parts
+    skipped; hf_batch_sync == hf_sync of every member."""
+    from hopperrender_amd import capi, synth
+    from hopperrender_amd.calc import DeviceBuffer, FlowBatch, OpticalFlowCalcHDR
+    H, W, n, R = 360, 640, 5, 13
+    scenes = [synth.Scene(H, W, True, 40 + i) for i in range(n)]
+    dev = []
+    for sc in scenes:
+        row = []
+        for k in range(6):
+            f = sc.frame(k)
+            b = DeviceBuffer(f.nbytes); b.upload(f); row.append(b)
+        dev.append(row)
+    mk = lambda: [OpticalFlowCalcHDR(H, W, search_radius=R, flags=capi.HF_FLAG_ASYNC) for _ in range(n)]
+    three, one = mk(), mk()
+    b3, b1 = FlowBatch(three), FlowBatch(one)
+    ts = [[0.0, 0.25, 0.5, 0.75, 0.9][:3 + i % 3] for i in range(n)]
+    o3 = [[DeviceBuffer(three[0].output_frame_bytes) for _ in range(5)] for _ in range(n)]
+    o1 = [[DeviceBuffer(three[0].output_frame_bytes) for _ in range(5)] for _ in range(n)]
+    for k in range(6):
+        ptrs = [dev[i][k].ptr for i in range(n)]
+        b3.updateFramesDeviceRef(ptrs)
+        if k < 2:
+            b1.runPeriod(b1.preparePeriod(ptrs, None, None, calculate_flow=False))      # update only
+            continue
+        b3.calculateOpticalFlow()
+        b3.interpolatePeriod(ts, [[x.ptr for x in o3[i]] for i in range(n)], 2)
+        if k == 3:    # the same period in two calls: update + flow, then the warps alone
+            b1.runPeriod(b1.preparePeriod(ptrs, None, None))
+            b1.runPeriod(b1.preparePeriod(None, ts, [[x.ptr for x in o1[i]] for i in range(n)], 2, calculate_flow=False))
+        else:
+            b1.runPeriod(b1.preparePeriod(ptrs, ts, [[x.ptr for x in o1[i]] for i in range(n)], 2))
+        b1.sync()
+        for i in range(n):
+            three[i].sync()
+            assert one[i].m_frameCount == three[i].m_frameCount == k + 1
+            assert one[i].m_totalFrameDelta == three[i].m_totalFrameDelta
+            for j in range(len(ts[i])):
+                assert (o1[i][j].download(np.uint16) == o3[i][j].download(np.uint16)).all(), (k, i, j)
+    with pytest.raises(capi.HopperFlowError) as e:      # same error behaviour as the calls it stands for
+        b1.runPeriod(b1.preparePeriod(None, [[1.5]] * n, [[o1[i][0].ptr] for i in range(n)], 2, calculate_flow=False))
+    assert e.value.code == capi.HF_ERR_INVALID_ARGUMENT and "greater than 1.0" in str(e.value)
+    with pytest.raises(capi.HopperFlowError) as e:      # a NULL frame is caught before ANY member's ring is touched
+        b1.runPeriod(b1.preparePeriod([dev[0][0].ptr] * (n - 1) + [0], None, None, calculate_flow=False))
+    assert e.value.code == capi.HF_ERR_INVALID_ARGUMENT
+    assert all(m.m_frameCount == 6 for m in one)
+    b1.runPeriod(b1.preparePeriod(None, ts, [[x.ptr for x in o1[i]] for i in range(n)], 2, calculate_flow=False))
+    b1.sync()
+    for i in range(n):     # ... so the members still warp the same frames
+        for j in range(len(ts[i])):
+            assert (o1[i][j].download(np.uint16) == o3[i][j].download(np.uint16)).all(), ("after the failed update", i, j)
+    b3.close(); b1.close()
+    for c in three + one:
+        c.close()
+
+
+def test_first_suitable_device_on_this_box(native_lib):
+    """device_index = -1 (what the C++ drop-in passes): detectDevices settles on the first suitable HIP device."""
+    from hopperrender_amd.calc import OpticalFlowCalcSDR
+    c = OpticalFlowCalcSDR(180, 320, device_index=-1)
+    assert c.device_index == 0 and native_lib.hf_get_device(c._ctx) == 0
+    c.close()
+
+
 def test_batched_period_matches_oracle(native_lib):
     """... and through the oracle the reference: one batched period at 180p against the CPU restatement."""
     from hopperrender_amd import capi, synth

@@ -24,7 +24,7 @@ def test_every_declared_symbol_is_exported_and_bound(native_lib):
     assert not (set(syms) - set(capi.SIGNATURES)), f"not bound in capi.py: {sorted(set(syms) - set(capi.SIGNATURES))}"
     for s in syms:
         assert getattr(native_lib, s) is not None
-    assert native_lib.hf_abi_version() == 2   # round 2: batch period / frame-update calls, hf_filter_*, stream-topology flags removed
+    assert native_lib.hf_abi_version() == 3   # round 3: hf_batch_run_period / hf_batch_sync, hf_select_device / hf_get_device, device_index = -1, hf_stats.phase_plane_bytes
 
 
 def test_struct_layouts_match_the_header(native_lib, tmp_path):
@@ -37,6 +37,30 @@ def test_struct_layouts_match_the_header(native_lib, tmp_path):
     sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     assert sizes == [ctypes.sizeof(capi.HfConfig), ctypes.sizeof(capi.HfParams), ctypes.sizeof(capi.HfStats), ctypes.sizeof(capi.HfProfile),
                      ctypes.sizeof(capi.HfFilterConfig), ctypes.sizeof(capi.HfFilterState)]
+
+
+def test_first_suitable_device_rule(native_lib):
+    """detectDevices (reference opticalFlowCalc.cpp:67-109) on a fake capability table: the FIRST device with enough memory,
+    >= 2 KB of LDS and 16 x 16 workgroups wins (hf_create(device_index = -1) applies the same function to the HIP devices);
+    when none qualifies the message names what the last one lacked, in the reference's words."""
+    from hopperrender_amd import capi
+    GB = 1 << 30
+    caps = lambda rows: (capi.HfDeviceCaps * len(rows))(*[capi.HfDeviceCaps(*r) for r in rows])
+    why = ctypes.create_string_buffer(384)
+    sel = lambda rows, need: native_lib.hf_select_device(caps(rows), len(rows), need, why, len(why))
+    good, small, no_lds, tiny_wg, wave32 = (288 * GB, 65536, 1024, 64), (1 * GB, 65536, 1024, 64), (288 * GB, 1024, 1024, 64), (288 * GB, 65536, 128, 64), (288 * GB, 65536, 1024, 32)
+    assert sel([good, good], 4 * GB) == 0                          # first suitable, not "best"
+    assert sel([small, good, good], 4 * GB) == 1                   # device 0 lacks the memory: moves on (the reference's loop, :75-93)
+    assert sel([no_lds, tiny_wg, wave32, small, good], 4 * GB) == 4
+    assert sel([small], 1 * GB) == 0                               # >= , not >
+    assert sel([good, small], 4 * GB) == 0
+    assert sel([small, no_lds], 4 * GB) == -1
+    assert b"Not enough shared memory available! Required: 2048 bytes, Available: 1024 bytes" in why.value   # the LAST device inspected (:98-108)
+    assert sel([no_lds, small], 4 * GB) == -1
+    assert b"Not enough VRAM available! Required: 4096 MB, Available: 1024 MB" in why.value
+    assert sel([tiny_wg], 1) == -1 and b"work group sizes" in why.value
+    assert sel([wave32], 1) == -1 and b"Wavefront size 32" in why.value
+    assert native_lib.hf_select_device(None, 0, 1, None, 0) == -1
 
 
 def test_no_device_fails_loudly_not_silently(native_lib):

@@ -21,9 +21,9 @@ def free_port():
     return p
 
 
-def run_bench(extra, world):
+def run_bench(extra, world, workload="sdr1080_24to60"):
     env = dict(os.environ, HF_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    args = ["--steps", "2", "--warmup", "1", "--periods-per-step", "4", "--workload", "sdr1080_24to60", "--no-cpu-baseline",
+    args = ["--steps", "2", "--warmup", "1", "--periods-per-step", "4", "--workload", workload, "--no-cpu-baseline",
             "--no-reference", "--no-host-io"] + extra
     if world == 1:
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + args
@@ -47,3 +47,17 @@ def test_bench_two_ranks_on_one_gpu():
     assert two["roofline"]["bound"] == "hbm" and 0 < two["roofline"]["frac"] < 1
     # the ranks shared one GPU: per-rank rate about halves, the aggregate stays in the same range
     assert two["value"] > 0.4 * one["value"]
+
+
+def test_named_baseline_configs_4_and_5():
+    """BASELINE.json configs 4 and 5 by name: `sdr1080_64pairs` (64 independent 1080p SDR pairs in flight, split over the
+    ranks: strong scaling) and `hdr2160_nb10_blur32` (neighbour scalar 10, blurFlow radius 32)."""
+    one = run_bench([], 1, "sdr1080_64pairs")
+    assert one["config"]["pair_streams_per_gpu"] == 64 and one["config"]["flow_batch"] == 32 and one["scaling"] == "strong"
+    two = run_bench([], 2, "sdr1080_64pairs")
+    assert two["config"]["pair_streams_per_gpu"] == 32 and two["config"]["pair_streams_total"] == 64
+    assert two["config"]["output_frames_total"] == one["config"]["output_frames_total"]        # the job is the same 64 pairs
+    five = run_bench([], 1, "hdr2160_nb10_blur32")
+    assert five["config"]["neighbor_scalar"] == 10 and five["config"]["blur_radius"] == 32 and five["value"] > 0
+    assert five["config"]["host_calls_per_batch_and_period"] == 1
+    assert 0 < five["roofline"]["frac"] < 1 and five["roofline"]["frac_algorithmic"] > five["roofline"]["frac"]

@@ -83,6 +83,8 @@ def test_eager_and_graph_paths_agree(native_lib):
     (1, 360, 640, 0, 0, 16, 0, 16),    # blur radius extension (BASELINE config 5)
     (0, 270, 480, 0, 0, 13, 0, 32),
     (0, 1090, 1922, 1984, 1936, 16, 0, 4),  # ragged 1080p-class, rs=3
+    (0, 1080, 1920, 0, 0, 16, 0, 4),        # BASELINE config 2 geometry
+    (1, 2160, 3840, 0, 0, 16, 0, 4),        # BASELINE config 3 geometry
 ])
 def test_flow_matches_oracle_on_seeded_inputs(native_lib, hdr, H, W, si, so, R, it, blur):
     from hopperrender_amd import synth
@@ -101,11 +103,16 @@ def test_flow_matches_oracle_on_seeded_inputs(native_lib, hdr, H, W, si, so, R, 
     assert (c.readBlurredFlow(1) == blur_o).all()
     assert c.m_totalFrameDelta == tot_o
     c.calculateOpticalFlow()
+    flow = c.readBlurredFlow(0)
     for t in (0.0, 0.37, 1.0):
-        for mode in (0, 1, 2, 4, 5, 6):
+        for mode in (0, 1, 2, 3, 4, 5, 6):
             c.warpFrames(t, mode)
             out = c.downloadFrame()
-            ref = oracle.warp_frames(f[0], f[1], c.readBlurredFlow(0), g, t, mode)
+            ref = oracle.warp_frames(f[0], f[1], flow, g, t, mode)
+            if mode == 3:   # diagnostic HSV visualisation: atan2 / fmod of the device vs libm, <= 2 LSB of 8 bits
+                d = np.abs(out.astype(np.int64) - ref.astype(np.int64))
+                assert d.max() <= (2 * 256 if hdr else 2), f"warp t={t} mode=3: max diff {d.max()}"
+                continue
             assert (out == ref).all(), f"warp t={t} mode={mode}"
     c.copyFrame()
     assert (c.downloadFrame() == oracle.copy_frame(f[0], g)).all()

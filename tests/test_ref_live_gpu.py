@@ -24,7 +24,7 @@ def test_hip_matches_live_reference(native_lib, hdr, H, W, si, so, R, delta, nb,
         pytest.skip("oracle/_ref (the compiled reference) or an OpenCL GPU is not available")
     sc = synth.Scene(H, W, bool(hdr), seed, in_stride=si)
     f = [sc.frame(k) for k in range(4)]
-    tvals = [0.0, 0.1998, 0.5994, 0.999]
+    tvals = [0.0, 0.1998, 0.3996, 0.5994, 0.999]
     s = oracle.RefSession(hdr, H, W, si, so, delta, nb, 0.0, 255.0, max_res)
     s.radius(R)
     for x in f[:3]:
@@ -53,7 +53,45 @@ def test_hip_matches_live_reference(native_lib, hdr, H, W, si, so, R, delta, nb,
             assert (c.downloadFrame() == ref[f"w{m}_{t}"]).all(), f"mode {m} t {t}"
     c.copyFrame()
     assert (c.downloadFrame() == ref["copy"]).all()
+    # the same five outputs as ONE fused period launch (hf_interpolate_period_ex): at 2160p every thread produces all of
+    # them (the launch shape bench.py times), judged here by the live reference (warpFrameKernelHDR.h:116-184)
+    from hopperrender_amd import capi
+    from hopperrender_amd.calc import DeviceBuffer, FlowBatch
+    dt = np.uint16 if hdr else np.uint8
+    outs = [DeviceBuffer(c.output_frame_bytes) for _ in tvals]
+    zeros = np.zeros(c.output_frame_bytes, np.uint8)
+    for b in outs:
+        b.upload(zeros)            # the padding behind each row (output stride > width) is never written: zero as in the reference's buffer
+    for m in (2, 0, 1):
+        c.interpolateOnly(tvals, [b.ptr for b in outs], m)
+        c.sync()
+        for j, t in enumerate(tvals):
+            assert (outs[j].download(dt) == ref[f"w{m}_{t}"]).all(), f"fused period, mode {m} t {t}"
     c.close()
+    if H * W <= 1920 * 1080 and si == 0:
+        # frames up to 1080p produce all outputs per thread only inside a batch of >= 11 members: 12 members, same frames
+        n = 12
+        cls = OpticalFlowCalcHDR if hdr else OpticalFlowCalcSDR
+        members = [cls(H, W, si, so, delta, nb, 0.0, 255.0, max_res, search_radius=R, flags=capi.HF_FLAG_ASYNC) for _ in range(n)]
+        batch = FlowBatch(members)
+        dev = []
+        for x in f:
+            b = DeviceBuffer(x.nbytes); b.upload(x); dev.append(b)
+        for k in range(4):
+            batch.updateFramesDeviceRef([dev[k].ptr] * n)
+            if k >= 2:
+                batch.calculateOpticalFlow()
+        mouts = [[DeviceBuffer(len(zeros)) for _ in tvals] for _ in range(n)]
+        plans = [tvals[i % 5:] + tvals[:i % 5] for i in range(n)]
+        batch.interpolatePeriod(plans, [[b.ptr for b in mo] for mo in mouts], 2)
+        for i, mbr in enumerate(members):
+            mbr.sync()
+            assert mbr.m_totalFrameDelta == js[1]["total_frame_delta"]
+            for j, t in enumerate(plans[i]):
+                assert (mouts[i][j].download(dt) == ref[f"w2_{t}"]).all(), f"batched fused period, member {i} t {t}"
+        batch.close()
+        for mbr in members:
+            mbr.close()
 
 
 @pytest.mark.parametrize("hdr,H,W", [(0, 4, 4), (1, 4, 4), (0, 6, 10)])
