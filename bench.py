@@ -169,7 +169,7 @@ def reference_opencl(hdr, H, W, target, radius, neighbor, frames):
                     "back-to-back calculateOpticalFlow / warpFrames calls, no host transfers"}
 
 
-def host_io_block(hdr, H, W, target, n_periods=24):
+def host_io_block(hdr, H, W, target, n_periods=24, device=0, async_only=False):
     """PCIe-inclusive rates of ONE context fed from and read back into host memory (never the bench `value`): the
     reference's blocking protocol with pageable and with pinned buffers, and the asynchronous variant
     (hf_update_frame_async / hf_download_frame_async: pinned buffers, H2D and D2H on side streams).  Measured by
@@ -180,7 +180,8 @@ def host_io_block(hdr, H, W, target, n_periods=24):
     env = dict(os.environ)
     env.pop("GPU_MAX_HW_QUEUES", None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "host_io_rate.py"), "--hdr", str(hdr), "--H", str(H), "--W", str(W),
-                        "--target", str(target), "--n", str(n_periods)], capture_output=True, text=True, timeout=600, env=env)
+                        "--target", str(target), "--n", str(n_periods), "--device", str(device)] + (["--async-only"] if async_only else []),
+                       capture_output=True, text=True, timeout=600, env=env)
     if r.returncode != 0:
         return {"error": r.stderr[-400:]}
     res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
@@ -434,6 +435,19 @@ def main():
         isolated = {"warp_us": 1e3 * p["warp_ms"] / max(p["warp_launches"], 1), "fpl": p["warp_frames"] / max(p["warp_launches"], 1),
                     "flow_chain_us": 1e3 * p["flow_ms"] / max(p["flow_chains"], 1)}
 
+    # Host-I/O leg at N > 1 (the expected scaling limit is host memcpy / the PCIe root complex): EVERY rank feeds
+    # one context from pinned host memory and reads every output frame back, all ranks at the same time, each in a child process
+    # on its own GPU; rank 0 reports the aggregate.  Never part of `value`.
+    host_io_ranks = None
+    if world > 1 and not a.no_host_io:
+        dist.barrier()
+        try:
+            mine = host_io_block(hdr, H, W, target, n_periods=24, device=dev_index, async_only=True)
+        except Exception as e:
+            mine = {"error": repr(e)}
+        host_io_ranks = [None] * world
+        dist.all_gather_object(host_io_ranks, mine)
+
     if rank == 0:
         st = calcs[0].stats()
         N = st["low_width"] * st["low_height"]
@@ -525,6 +539,16 @@ def main():
             "ms_per_flow_calc_isolated": round(isolated["flow_chain_us"] / 1e3, 4) if isolated else None,
             "roofline": roof,
         }
+        if host_io_ranks is not None:
+            ok = [r["async_pinned_side_streams"] for r in host_io_ranks if r and "async_pinned_side_streams" in r]
+            out["host_io"] = {
+                "ranks_reporting": len(ok), "aggregate_frames_per_s": round(sum(r["frames_per_s"] for r in ok), 1),
+                "d2h_GB_per_s_per_gpu": round(sum(r["d2h_GB_per_s"] for r in ok) / max(len(ok), 1), 2),
+                "h2d_GB_per_s_per_gpu": round(sum(r["h2d_GB_per_s"] for r in ok) / max(len(ok), 1), 2),
+                "per_rank_frames_per_s": [r["frames_per_s"] for r in ok],
+                "errors": [r.get("error") for r in host_io_ranks if r and "error" in r],
+                "note": "every rank at the same time: one asynchronous context per GPU (child process), pinned host buffers, H2D / D2H on side "
+                        "streams, every output frame returned to the host (PCIe-inclusive; never the bench `value`)"}
         if not a.no_host_io and world == 1:
             try:
                 out["host_io"] = host_io_block(hdr, H, W, target)

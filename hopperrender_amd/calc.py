@@ -151,6 +151,17 @@ class OpticalFlowCalc:
         a = pinned.array if hasattr(pinned, "array") else pinned
         capi.check(self._lib.hf_download_frame_async(self._ctx, _ptr(a)), self._ctx)
 
+    def waitFlow(self):
+        """Asynchronous contexts: block until the last calculateOpticalFlow has finished (m_totalFrameDelta valid); side streams keep running."""
+        capi.check(self._lib.hf_wait_flow(self._ctx), self._ctx)
+
+    def downloadsIssued(self):
+        return int(self._lib.hf_downloads_issued(self._ctx))
+
+    def waitDownload(self, index):
+        """Block until the index-th downloadFrameAsync (issue order, from 0) has landed in its host buffer."""
+        capi.check(self._lib.hf_wait_download(self._ctx, int(index)), self._ctx)
+
     def downloadFrameDevice(self, dev_ptr):
         capi.check(self._lib.hf_download_frame_device(self._ctx, C.c_void_p(dev_ptr)), self._ctx)
 

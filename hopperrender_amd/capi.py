@@ -89,6 +89,9 @@ SIGNATURES = {
     "hf_update_frame_device_ref": (_i, [_vp, _vp]),
     "hf_update_frame_async": (_i, [_vp, _vp]),
     "hf_download_frame_async": (_i, [_vp, _vp]),
+    "hf_wait_flow": (_i, [_vp]),
+    "hf_downloads_issued": (C.c_uint64, [_vp]),
+    "hf_wait_download": (_i, [_vp, C.c_uint64]),
     "hf_interpolate_period": (_i, [_vp, _vp, _i, C.POINTER(C.c_float), C.POINTER(_vp), _i]),
     "hf_interpolate_period_ex": (_i, [_vp, _vp, _i, C.POINTER(C.c_float), C.POINTER(_vp), _i, _i]),
     "hf_batch_create": (_i, [C.POINTER(_vp), _i, C.POINTER(_vp)]),

@@ -100,6 +100,12 @@ struct hf_ctx {
     void* out_ring[kOutRing] = {nullptr, nullptr, nullptr};      // [0] == out_frame
     int out_idx = 0;
     bool have_last_launch = false;
+    // completion of the asynchronous readbacks, for streaming hosts (hf_wait_download): one event per download, ring of kDlRing
+    static constexpr int kDlRing = 64;
+    hipEvent_t ev_dl[kDlRing] = {};
+    uint64_t dl_issued = 0;
+    hipEvent_t ev_flow_done = nullptr;                 // behind the last chain of an asynchronous context (hf_wait_flow)
+    bool flow_done_recorded = false;
 
     int ring_phase = 0;   // number of rotations mod 3 (graph key)
     int blur_phase = 0;   // number of swaps mod 2
@@ -397,6 +403,7 @@ int io_init(hf_ctx* c) {
     HF_HIP(c, hipEventCreateWithFlags(&c->ev_out_ready, hipEventDisableTiming));
     for (auto& e : c->ev_slot_prep) HF_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& e : c->ev_d2h) HF_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto& e : c->ev_dl) HF_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     c->out_ring[0] = c->out_frame;
     for (int i = 1; i < hf_ctx::kOutRing; i++) HF_HIP(c, hipMalloc(&c->out_ring[i], c->out_bytes));
     return HF_OK;
@@ -664,6 +671,8 @@ void hf_destroy(hf_ctx* c) {
     for (hipEvent_t e : {c->ev_h2d, c->ev_last_launch, c->ev_out_ready}) if (e) hipEventDestroy(e);
     for (hipEvent_t e : c->ev_slot_prep) if (e) hipEventDestroy(e);
     for (hipEvent_t e : c->ev_d2h) if (e) hipEventDestroy(e);
+    for (hipEvent_t e : c->ev_dl) if (e) hipEventDestroy(e);
+    if (c->ev_flow_done) hipEventDestroy(c->ev_flow_done);
     for (hipEvent_t e : c->ev_flow) if (e) hipEventDestroy(e);
     if (c->ev_chain_done) hipEventDestroy(c->ev_chain_done);
     if (c->ev_warps_done) hipEventDestroy(c->ev_warps_done);
@@ -722,6 +731,8 @@ int hf_download_frame_async(hf_ctx* c, void* pinned_host_out) {
     HF_HIP(c, hipEventRecord(c->ev_out_ready, last));
     HF_HIP(c, hipStreamWaitEvent(c->io_out, c->ev_out_ready, 0));
     HF_HIP(c, hipMemcpyAsync(pinned_host_out, c->out_target, c->out_bytes, hipMemcpyDeviceToHost, c->io_out));
+    HF_HIP(c, hipEventRecord(c->ev_dl[c->dl_issued % hf_ctx::kDlRing], c->io_out));
+    c->dl_issued++;
     for (int i = 0; i < hf_ctx::kOutRing; i++)
         if (c->out_target == c->out_ring[i]) {   // internal output: the next frame goes to the next ring slot
             HF_HIP(c, hipEventRecord(c->ev_d2h[i], c->io_out));
@@ -760,6 +771,11 @@ static int after_flow_enqueued(hf_ctx* c, hipStream_t s) {
         c->flow_timing_pending = true;
     }
     c->delta_pending = c->last_iterations > 0;
+    if (c->async() && !c->batch) {   // hf_wait_flow(): the host needs m_totalFrameDelta of THIS chain before it decides warp vs copy
+        if (!c->ev_flow_done) HF_HIP(c, hipEventCreateWithFlags(&c->ev_flow_done, hipEventDisableTiming));
+        HF_HIP(c, hipEventRecord(c->ev_flow_done, s));
+        c->flow_done_recorded = true;
+    }
     if (c->dual()) {   // tag the flow buffer just written, the tag travels with the buffer through the swap below
         HF_HIP(c, hipEventRecord(c->ev_flow[0], s));
         c->ev_flow_valid[0] = true;
@@ -1206,6 +1222,30 @@ int hf_sync(hf_ctx* c) {
     HF_CHECK_CTX(c);
     if (int rc = set_device(c)) return rc;
     return sync_ctx(c);
+}
+
+int hf_wait_flow(hf_ctx* c) {
+    HF_CHECK_CTX(c);
+    if (int rc = set_device(c)) return rc;
+    if (!c->async()) return HF_OK;                       // blocking contexts have finished every call already
+    if (c->batch) return fail(c, HF_ERR_STATE, "hf_wait_flow: the context is a member of a batch (use hf_sync)");
+    if (!c->flow_done_recorded) return HF_OK;
+    HF_HIP(c, hipEventSynchronize(c->ev_flow_done));
+    if (c->delta_pending) { c->total_frame_delta = *c->h_total_delta; c->delta_pending = false; }
+    return HF_OK;
+}
+
+uint64_t hf_downloads_issued(const hf_ctx* c) { return c ? c->dl_issued : 0; }
+
+int hf_wait_download(hf_ctx* c, uint64_t index) {
+    HF_CHECK_CTX(c);
+    if (index >= c->dl_issued) return fail(c, HF_ERR_INVALID_ARGUMENT, "hf_wait_download: download %llu has not been issued (%llu so far)",
+                                           (unsigned long long)index, (unsigned long long)c->dl_issued);
+    if (c->dl_issued - index > (uint64_t)hf_ctx::kDlRing) return HF_OK;   // older than the event ring: every later one has been recorded behind it
+    if (int rc = set_device(c)) return rc;
+    // (if the ring has wrapped past `index` the event belongs to a LATER download on the same in-order stream: waiting for it is still correct)
+    HF_HIP(c, hipEventSynchronize(c->ev_dl[index % hf_ctx::kDlRing]));
+    return HF_OK;
 }
 
 int hf_get_params(const hf_ctx* c, hf_params* out) {

@@ -168,6 +168,15 @@ int hf_update_frame_device(hf_ctx* ctx, const void* device_frame);
  * not wait for the previous readback. */
 int hf_update_frame_async(hf_ctx* ctx, const void* pinned_host_frame);
 int hf_download_frame_async(hf_ctx* ctx, void* pinned_host_out);
+/* Streaming hosts (the multi-GPU driver, hopperrender_amd/hostio.py): what the host must know WITHOUT draining the side streams.
+ *   hf_wait_flow      blocks until the last hf_calculate_optical_flow of an asynchronous context has finished and makes its
+ *                     m_totalFrameDelta visible in hf_get_stats -- the filter decides warp vs copy from it (HopperRender.cpp:
+ *                     959-972,1126-1176) while uploads and readbacks keep running;
+ *   hf_wait_download  blocks until the index-th hf_download_frame_async of this context (0, 1, 2 ... in issue order;
+ *                     hf_downloads_issued() = how many there are) has landed in its host buffer. */
+int hf_wait_flow(hf_ctx* ctx);
+uint64_t hf_downloads_issued(const hf_ctx* ctx);
+int hf_wait_download(hf_ctx* ctx, uint64_t index);
 /* Zero-copy variant: the ring keeps a REFERENCE to device_frame (e.g. a decoder surface).  The caller must
  * leave the frame untouched until three further frames have been submitted (it stays in the 3-frame ring
  * as frame N, N-1 and N-2, opticalFlowCalcSDR.cpp:22-28). */

@@ -21,10 +21,10 @@ def free_port():
     return p
 
 
-def run_bench(extra, world, workload="sdr1080_24to60"):
+def run_bench(extra, world, workload="sdr1080_24to60", host_io=False):
     env = dict(os.environ, HF_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     args = ["--steps", "2", "--warmup", "1", "--periods-per-step", "4", "--workload", workload, "--no-cpu-baseline",
-            "--no-reference", "--no-host-io"] + extra
+            "--no-reference"] + ([] if host_io else ["--no-host-io"]) + extra
     if world == 1:
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + args
     else:
@@ -61,3 +61,13 @@ def test_named_baseline_configs_4_and_5():
     assert five["config"]["neighbor_scalar"] == 10 and five["config"]["blur_radius"] == 32 and five["value"] > 0
     assert five["config"]["host_calls_per_batch_and_period"] == 1
     assert 0 < five["roofline"]["frac"] < 1 and five["roofline"]["frac_algorithmic"] > five["roofline"]["frac"]
+
+
+def test_host_io_leg_at_two_ranks():
+    """bench.py at N > 1: every rank runs the asynchronous host-I/O path (pinned buffers, H2D / D2H on side streams) on its
+    GPU at the same time and rank 0 reports the aggregate -- the leg SURVEY.md 8(e) names as the expected scaling limit."""
+    two = run_bench([], 2, host_io=True)
+    h = two["host_io"]
+    assert h["ranks_reporting"] == 2 and not h["errors"]
+    assert h["aggregate_frames_per_s"] > 0 and len(h["per_rank_frames_per_s"]) == 2
+    assert h["d2h_GB_per_s_per_gpu"] > 0 and h["h2d_GB_per_s_per_gpu"] > 0

@@ -75,3 +75,37 @@ def test_missing_frame_marker():
     r = y4m.Y4MReader(io.BytesIO(b"YUV4MPEG2 W4 H4 C420\nFRAMX\n" + b"\0" * 24))
     with pytest.raises(y4m.Y4MError):
         next(r)
+
+
+def test_random_access_clip_and_worker_file_layout(tmp_path):
+    """The multi-GPU CLI's workers read source frames by index (cli._Clip) and write output frames at their final offsets:
+    raw = i x frame bytes; .y4m = header + i x (6 + frame bytes), the header being exactly what Y4MWriter emits."""
+    import io
+    from hopperrender_amd import cli, synth
+    from hopperrender_amd.y4m import Y4MWriter
+    H, W = 36, 64
+    for hdr in (False, True):
+        sc = synth.Scene(H, W, hdr, 3)
+        frames = [sc.frame(k) for k in range(5)]
+        if hdr:
+            frames = [(f >> 6) << 6 for f in frames]          # .y4m keeps the 10-bit code only
+        raw, y4m = tmp_path / f"c{int(hdr)}.bin", tmp_path / f"c{int(hdr)}.y4m"
+        with open(raw, "wb") as f:
+            for x in frames:
+                f.write(x.tobytes())
+        with open(y4m, "wb") as f:
+            w = Y4MWriter(f, W, H, 24000, 1001, hdr)
+            for x in frames:
+                w.write(x)
+        for path, kw in ((raw, dict(width=W, height=H, hdr=hdr, source_fps=None)), (y4m, dict(width=None, height=None, hdr=False, source_fps=None))):
+            clip = cli._Clip(str(path), **kw)
+            assert (clip.n_frames, clip.width, clip.height, clip.hdr) == (5, W, H, hdr)
+            buf = np.empty(clip.n_el, dtype=clip.dt)
+            for k in (3, 0, 4):
+                clip.read_into(k, buf)
+                assert (buf == frames[k]).all(), (path, k)
+        clip = cli._Clip(str(y4m), None, None, False, None)
+        ref = io.BytesIO()
+        Y4MWriter(ref, W, H, 60, 1, hdr, clip.extra)
+        assert cli._y4m_header(clip, 60.0) == ref.getvalue()
+        assert len(open(y4m, "rb").read()) == clip.data0 + 5 * (6 + clip.frame_bytes)

@@ -1,24 +1,42 @@
-"""tools/copy_profiles.py TAG -- profiles/r02_* from gpurun_out/TAG (the output of tools/final_profiles.sh TAG on the GPU box):
-bench lines, rocprofv3 kernel stats, stand-alone kernel times, the warp kernel's rows of the PMC passes; then
-profiles/roofline_traffic.json is regenerated from those rows (tools/pmc_traffic.py).  Nothing is typed by hand."""
+"""tools/copy_profiles.py TAG -- profiles/TAG_* from gpurun_out/TAG (the output of tools/final_profiles.sh TAG on the GPU box):
+bench lines, rocprofv3 kernel stats, stand-alone kernel times, the PMC passes reduced to one row per kernel and launch shape;
+then profiles/roofline_traffic.json is regenerated from those rows (tools/pmc_traffic.py: the dominant kernel's bytes per
+launch AND the whole pipeline's bytes per output frame).  Nothing is typed by hand."""
 import csv, os, shutil, subprocess, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1]; src = os.path.join(R, "gpurun_out", tag); dst = os.path.join(R, "profiles"); rnd = "r02"
+tag = sys.argv[1]; src = os.path.join(R, "gpurun_out", tag); dst = os.path.join(R, "profiles"); rnd = tag
 pairs = [("bench_default.json", "bench_default.json"), ("bench_sdr1080.json", "bench_sdr1080.json"),
+         ("bench_sdr1080_64pairs.json", "bench_sdr1080_64pairs.json"), ("bench_hdr2160_nb10_blur32.json", "bench_hdr2160_nb10_blur32.json"),
          ("bench_default_under_rocprof.json", "bench_default_under_rocprof.json"), ("bench_sdr1080_under_rocprof.json", "bench_sdr1080_under_rocprof.json"),
          ("microbench.txt", "microbench.txt"), ("stats_default/p_kernel_stats.csv", "bench_default_kernel_stats.csv"),
          ("stats_sdr1080/p_kernel_stats.csv", "bench_sdr1080_kernel_stats.csv"), ("stats_streams1/p_kernel_stats.csv", "bench_streams1_kernel_stats.csv"),
-         ("stats_chain8/p_kernel_stats.csv", "chain_batch8_kernel_stats.csv")]
+         ("stats_chain16/p_kernel_stats.csv", "chain_batch16_kernel_stats.csv")]
 for a, b in pairs:
-    shutil.copyfile(os.path.join(src, a), os.path.join(dst, f"{rnd}_{b}")); print("copied", b)
+    if os.path.exists(os.path.join(src, a)):
+        shutil.copyfile(os.path.join(src, a), os.path.join(dst, f"{rnd}_{b}")); print("copied", b)
+    else:
+        print("MISSING", a)
+frame_bytes = {"hdr2160_24to120": 3840 * 2160 * 3, "sdr1080_24to60": 1920 * 1080 * 3 // 2}   # P010 / NV12 output frame
+
+
+def reduce_rows(path, counter, keep):
+    rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter and keep(r["Kernel_Name"])]
+    return rows
+
+
 for wl in ("hdr2160_24to120", "sdr1080_24to60"):
-    files = []
-    for c in ("FETCH_SIZE", "WRITE_SIZE"):
-        rows = list(csv.DictReader(open(os.path.join(src, f"pmc_{wl}_{c}", "p_counter_collection.csv"))))
-        keep = [r for r in rows if "warp_fast_kernel" in r["Kernel_Name"] and r["Counter_Name"] == c]
-        out = os.path.join(dst, f"{rnd}_warp_period_pmc_{wl}_{c}.csv")
-        with open(out, "w", newline="") as f:
-            w = csv.DictWriter(f, fieldnames=list(rows[0].keys())); w.writeheader(); w.writerows(keep)
-        files.append(out); print("filtered", os.path.basename(out), len(keep), "rows")
-    frame_bytes = {"hdr2160_24to120": 3840 * 2160 * 3, "sdr1080_24to60": 1920 * 1080 * 3 // 2}[wl]   # P010 / NV12 output frame
-    subprocess.check_call([sys.executable, os.path.join(R, "tools", "pmc_traffic.py"), wl, files[0], files[1], "--frame-bytes", str(frame_bytes)])
+    for kind, prefix, keep, extra in (("warp_period", "pmc", lambda n: "warp_fast_kernel" in n, []),
+                                      ("pipeline", "pmcpipe", lambda n: "hf::" in n, ["--pipeline", "--batch", "16"])):
+        files = []
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            p = os.path.join(src, f"{prefix}_{wl}_{c}", "p_counter_collection.csv")
+            if not os.path.exists(p):
+                print("MISSING", p); files = []; break
+            rows = reduce_rows(p, c, keep)
+            out = os.path.join(dst, f"{rnd}_{kind}_pmc_{wl}_{c}.csv")
+            cols = ["Dispatch_Id", "Kernel_Name", "Grid_Size", "Workgroup_Size", "Counter_Name", "Counter_Value"]
+            with open(out, "w", newline="") as f:
+                w = csv.DictWriter(f, fieldnames=cols, extrasaction="ignore"); w.writeheader(); w.writerows(rows)
+            files.append(out); print("reduced", os.path.basename(out), len(rows), "rows")
+        if files:
+            subprocess.check_call([sys.executable, os.path.join(R, "tools", "pmc_traffic.py"), wl, files[0], files[1], "--frame-bytes", str(frame_bytes[wl])] + extra)

@@ -1,23 +1,32 @@
 #!/bin/bash
-# tools/final_profiles.sh TAG -- the measurements the round's profiles/ are made from (run on the GPU box):
-#   default bench lines (HDR 2160p, SDR 1080p), rocprofv3 kernel stats of the same commands and of one stream alone,
-#   PMC FETCH_SIZE / WRITE_SIZE passes of the fused period warp (one launch at a time), stand-alone kernel times.
-TAG=${1:-r02}
+# tools/final_profiles.sh TAG -- the measurements the round's profiles/ are made from (run on the GPU box, then
+# `python tools/copy_profiles.py TAG` in the build container):
+#   default bench lines (HDR 2160p, SDR 1080p, BASELINE configs 4 and 5), rocprofv3 kernel stats of the same commands and of one
+#   stream alone, PMC FETCH_SIZE / WRITE_SIZE passes of the fused period warp alone (one launch at a time) AND of the whole
+#   batched pipeline at the bench's operating point, stand-alone kernel times.
+TAG=${1:-r03}
 export TMPDIR=/tmp; R=$PWD; O=$R/gpurun_out/$TAG; rm -rf $O; mkdir -p $O
-python bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -c 400 $O/bench_default.json; echo
+python bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -c 300 $O/bench_default.json; echo
 python bench.py --workload sdr1080_24to60 --no-reference > $O/bench_sdr1080.json 2> $O/bench_sdr1080.err
+python bench.py --workload sdr1080_64pairs --no-reference --no-cpu-baseline --no-host-io > $O/bench_sdr1080_64pairs.json 2> $O/bench_cfg4.err
+python bench.py --workload hdr2160_nb10_blur32 --no-reference --no-cpu-baseline --no-host-io > $O/bench_hdr2160_nb10_blur32.json 2> $O/bench_cfg5.err
 python tools/microbench.py > $O/microbench.txt 2>&1
 python tools/microbench.py --hdr 0 --H 1080 --W 1920 >> $O/microbench.txt 2>&1
-python tools/chain_time.py --batch 1 2 4 8 >> $O/microbench.txt 2>&1
-python tools/chain_time.py --batch 1 8 --hdr 0 --H 1080 --W 1920 >> $O/microbench.txt 2>&1
+python tools/chain_time.py --batch 1 2 4 8 16 >> $O/microbench.txt 2>&1
+python tools/chain_time.py --batch 1 8 16 --hdr 0 --H 1080 --W 1920 >> $O/microbench.txt 2>&1
+python tools/warp_ab.py >> $O/microbench.txt 2>&1
 cd /tmp
 Q="--no-cpu-baseline --no-reference --no-host-io"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_default -o p -- python3 $R/bench.py $Q > $O/bench_default_under_rocprof.json 2>/dev/null
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_sdr1080 -o p -- python3 $R/bench.py --workload sdr1080_24to60 $Q > $O/bench_sdr1080_under_rocprof.json 2>/dev/null
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_streams1 -o p -- python3 $R/bench.py --streams 1 --batch 1 --steps 2 --periods-per-step 20 $Q > /dev/null 2>&1
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_chain8 -o p -- python3 $R/tools/chain_time.py --batch 8 --n 50 > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_chain16 -o p -- python3 $R/tools/chain_time.py --batch 16 --n 50 > /dev/null 2>&1
 for wl in hdr2160_24to120 sdr1080_24to60; do for c in FETCH_SIZE WRITE_SIZE; do
+  # the fused period warp alone: one member, one launch at a time
   timeout 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_${wl}_$c -o p -- python3 $R/bench.py --workload $wl --streams 1 --batch 1 --steps 2 --warmup 1 --periods-per-step 12 --no-profile $Q > /dev/null 2>&1
-  echo "pmc $wl $c rc=$?"
+  echo "pmc warp $wl $c rc=$?"
+  # the whole pipeline at the bench's operating point (2 batch streams of 16; counter collection serialises the dispatches)
+  timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmcpipe_${wl}_$c -o p -- python3 $R/bench.py --workload $wl --steps 2 --warmup 1 --periods-per-step 8 --no-profile $Q > /dev/null 2>&1
+  echo "pmc pipeline $wl $c rc=$?"
 done; done
 ls $O

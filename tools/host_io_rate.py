@@ -8,13 +8,14 @@ from hopperrender_amd.calc import OpticalFlowCalcHDR, OpticalFlowCalcSDR, Pinned
 from hopperrender_amd.protocol import SOURCE_24, TARGET_120, TARGET_60, BlendSchedule
 ap = argparse.ArgumentParser(); ap.add_argument("--hdr", type=int, default=1); ap.add_argument("--H", type=int, default=2160)
 ap.add_argument("--W", type=int, default=3840); ap.add_argument("--n", type=int, default=30); ap.add_argument("--target", type=int, default=TARGET_120)
+ap.add_argument("--device", type=int, default=0); ap.add_argument("--async-only", action="store_true", help="only the asynchronous pinned variant (multi-rank runs)")
 a = ap.parse_args()
 cls = OpticalFlowCalcHDR if a.hdr else OpticalFlowCalcSDR
 sc = synth.Scene(a.H, a.W, bool(a.hdr), 1234)
 frames = [sc.frame(k) for k in range(4)]
 res = {}
-for pinned in (False, True):
-    c = cls(a.H, a.W, 0, 0, 8, 6, 0.0, 255.0, 270, search_radius=16)
+for pinned in (() if a.async_only else (False, True)):
+    c = cls(a.H, a.W, 0, 0, 8, 6, 0.0, 255.0, 270, search_radius=16, device_index=a.device)
     n_el = c.output_frame_bytes // np.dtype(c.dtype).itemsize
     if pinned:
         ins = [PinnedArray(f.size, c.dtype) for f in frames]
@@ -36,7 +37,7 @@ for pinned in (False, True):
     c.close()
 # asynchronous pipeline: uploads/readbacks on side streams, pinned buffers, nothing blocks until the end
 from hopperrender_amd import capi
-c = cls(a.H, a.W, 0, 0, 8, 6, 0.0, 255.0, 270, search_radius=16, flags=capi.HF_FLAG_ASYNC | capi.HF_FLAG_DUAL_STREAM)
+c = cls(a.H, a.W, 0, 0, 8, 6, 0.0, 255.0, 270, search_radius=16, device_index=a.device, flags=capi.HF_FLAG_ASYNC | capi.HF_FLAG_DUAL_STREAM)
 n_el = c.output_frame_bytes // np.dtype(c.dtype).itemsize
 ins = [PinnedArray(f.size, c.dtype) for f in frames]
 for p, f in zip(ins, frames): p.array[:] = f

@@ -22,14 +22,79 @@ def per_kernel(path, counter):
     return acc
 
 
+def short(name):
+    """'void hf::(anonymous namespace)::flow_level_small_kernel<16, true>(hf::Geom, ...)' -> 'flow_level_small_kernel<16, true>'"""
+    n = name.split("(anonymous namespace)::")[-1] if "(anonymous namespace)::" in name else name.split("hf::")[-1]
+    depth = 0
+    for i, ch in enumerate(n):
+        if ch == "<": depth += 1
+        elif ch == ">": depth -= 1
+        elif ch == "(" and depth == 0:
+            return n[:i]
+    return n
+
+
+def pipeline_entry(a):
+    """HBM traffic of EVERY kernel inside the batched pipeline, per pair and source period and per output frame.
+    Inputs: PMC passes (FETCH_SIZE, WRITE_SIZE) over the default `bench.py` command (its operating point: batches of
+    `--batch` members).  Only the batched dispatches count (per kernel: the dispatches with the largest grid; priming calls
+    and the stand-alone leg behind the timed region launch one member at a time).  A batched warp dispatch = one source
+    period of `--batch` pairs; output frames = bytes it wrote / frame bytes."""
+    f_all, w_all = per_kernel(a.fetch_csv, "FETCH_SIZE"), per_kernel(a.write_csv, "WRITE_SIZE")
+
+    def batched(acc):
+        by_name = collections.defaultdict(dict)
+        for (name, grid), v in acc.items():
+            by_name[name][grid] = v
+        return {name: grids[max(grids)] for name, grids in by_name.items() if "hf::" in name}
+
+    fb, wb = batched(f_all), batched(w_all)
+    warp = [n for n in wb if a.kernel in n]
+    if not warp:
+        raise SystemExit("no %s dispatches" % a.kernel)
+    warp = max(warp, key=lambda n: sum(wb[n]))
+    periods_w, periods_f = len(wb[warp]) * a.batch, len(fb[warp]) * a.batch      # pair-periods seen by each pass
+    frames_per_pair_period = sum(wb[warp]) * 1024 / a.frame_bytes / periods_w
+    per_kernel_bytes, total = {}, 0.0
+    for name in sorted(set(fb) | set(wb)):
+        rd = 2 * sum(fb.get(name, [])) * 1024 / periods_f                          # FETCH_SIZE x 2 (gfx950 note), KiB -> bytes
+        wr = sum(wb.get(name, [])) * 1024 / periods_w
+        if rd + wr < 1:
+            continue
+        per_kernel_bytes[short(name)] = {"read": int(rd), "write": int(wr), "dispatches_per_pair_period": round(len(wb.get(name, [])) / periods_w * a.batch, 2)}
+        total += rd + wr
+    return {
+        "hbm_bytes_per_output_frame": int(total / frames_per_pair_period),
+        "hbm_bytes_per_pair_and_period": int(total),
+        "output_frames_per_pair_and_period": round(frames_per_pair_period, 3),
+        "per_kernel_bytes_per_pair_and_period": per_kernel_bytes,
+        "operating_point": "%d pairs per batch, batched dispatches only" % a.batch,
+        "pair_periods": {"fetch_pass": periods_f, "write_pass": periods_w},
+        "corrections": "FETCH_SIZE x 2 (gfx950 tallies 128-byte read requests of wide coalesced loads at 64 B; an upper bound for the narrow "
+                       "gathers of the chain kernels), KiB -> bytes; WRITE_SIZE exact; counter collection serialises the kernels, so the "
+                       "cross-stream cache effects of the free-running pipeline are not in these numbers",
+        "files": [os.path.relpath(a.fetch_csv), os.path.relpath(a.write_csv)],
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("workload"); ap.add_argument("fetch_csv"); ap.add_argument("write_csv")
+    ap.add_argument("--pipeline", action="store_true", help="the CSVs are passes over the batched pipeline: write the workload's `pipeline` entry")
+    ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "roofline_traffic.json"))
     ap.add_argument("--kernel", default="warp_fast_kernel")
     ap.add_argument("--units-per-launch", type=float, default=0.0, help="output frames of the launches selected (0: take it from --frames-by-write)")
     ap.add_argument("--frame-bytes", type=int, default=0, help="bytes of one output frame: units per launch = WRITE_SIZE / frame bytes")
     a = ap.parse_args()
+    if a.pipeline:
+        if not a.frame_bytes:
+            raise SystemExit("--pipeline needs --frame-bytes")
+        data = json.load(open(a.out)) if os.path.exists(a.out) else {}
+        data.setdefault(a.workload, {})["pipeline"] = pipeline_entry(a)
+        json.dump(data, open(a.out, "w"), indent=1)
+        print(json.dumps({a.workload: {"pipeline": data[a.workload]["pipeline"]}}, indent=1))
+        return
     f = {k: v for k, v in per_kernel(a.fetch_csv, "FETCH_SIZE").items() if a.kernel in k[0]}
     w = {k: v for k, v in per_kernel(a.write_csv, "WRITE_SIZE").items() if a.kernel in k[0]}
     if not f or not w:
@@ -63,6 +128,8 @@ def main():
             data = json.load(open(a.out))
         except Exception:
             data = {}
+    if "pipeline" in data.get(a.workload, {}):
+        entry["pipeline"] = data[a.workload]["pipeline"]
     data[a.workload] = entry
     json.dump(data, open(a.out, "w"), indent=1)
     print(json.dumps({a.workload: entry}, indent=1))
