@@ -732,190 +732,17 @@ __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a,
     }
   };
   auto finish = [&](const int ti, const Src& S) {
-#if defined(HF_WI) && HF_WI == 5   /* stopwatch: + 40 dependent VALU instructions per output (+200 per wave, + 17 %) */
-    { int pad = ti; _Pragma("unroll") for (int q = 0; q < 40; q++) asm volatile("v_add_u32 %0, %0, 1" : "+v"(pad)); asm volatile("" :: "v"(pad)); }
-#endif
-#if defined(HF_WI) && HF_WI == 6   /* stopwatch: + 40 SALU instructions per output */
-    { int pad = ti; _Pragma("unroll") for (int q = 0; q < 40; q++) asm volatile("s_add_u32 %0, %0, 1" : "+s"(pad)); asm volatile("" :: "s"(pad)); }
-#endif
     E* __restrict__ out = (E*)a.outv[ti] + (size_t)CZ * H * So + (size_t)cy0 * So + cx0;
     warp_finish<E, GROUP, ROWS, MODE, CZ, VB>(S, a.s12v[ti], a.s21v[ti], out, So, nrows, lv);
   };
   // (software pipelining -- requesting the runs of output ti + 1, of two outputs ahead, or of all outputs before blending
   //  output ti -- measured no faster since the dword-aligned loads: 49.9 / 52.8 / 53.8 us against 48.7 us for the plain
   //  loop with its higher occupancy)
-#if defined(HF_WI) && HF_WI == 1   /* stopwatch build (WRONG results): source runs fetched for the first output only */
-  Src cur;
-  issue(ti0, cur);
-  for (int ti = ti0; ti < ti1; ti++) finish(ti, cur);
-#else
   for (int ti = ti0; ti < ti1; ti++) {
     Src cur;
     issue(ti, cur);
     finish(ti, cur);
   }
-#endif
-}
-
-// ------------------------------------------------------------------------------------------
-// LDS-staged period warp
-// ------------------------------------------------------------------------------------------
-// The outputs of a source period read almost the same source rows -- the displacement only grows with the blending scalar --
-// and re-gathering them from L2 once per OUTPUT (311 MB of 16-byte runs per 2160p HDR period, through a 32 KB texture cache
-// that holds a fifth of what the resident waves touch) is what bounds the fused launch, not HBM.
-// Here a wave copies, ONCE per period, the window of each source frame that ALL outputs of its tile read into LDS with
-// direct-to-LDS buffer loads (16 bytes per lane, 1 KB per instruction, no VGPR round trip: kStageDma instructions per
-// source instead of 4 + 4 per output), then every output takes its runs from LDS (five dword reads per run + the same funnel
-// shift / byte permute as the global path).  The window is found per wave: min / max over lanes and outputs of the runs'
-// 16-byte chunks and rows (packed 16-bit butterfly), shape rows x chunks free as long as it fits kStageDma KB; tiles
-// whose runs do not fit (fast or diverging motion), touch the mirror zone or are not full take the global path below --
-// same results either way.  One flow cell per thread (GROUP == VEC), two rows per thread.
-#ifndef HF_WARP_STAGE_DMA
-#define HF_WARP_STAGE_DMA 4
-#endif
-constexpr int kStageDma = HF_WARP_STAGE_DMA;            // direct-to-LDS instructions (1 KB each) per source window
-constexpr int kStageChunks = kStageDma * 64;            // 16-byte chunks per source window
-constexpr int kStageBytesPerWave = 2 * kStageChunks * 16;
-
-typedef short short2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) {
-    short2v x, y;
-    __builtin_memcpy(&x, &a, 4); __builtin_memcpy(&y, &b, 4);
-    const short2v m = __builtin_elementwise_max(x, y);
-    uint32_t r;
-    __builtin_memcpy(&r, &m, 4);
-    return r;
-}
-__device__ __forceinline__ uint32_t pk_i16(int lo, int hi) { return ((uint32_t)lo & 0xFFFFu) | ((uint32_t)hi << 16); }
-__device__ __forceinline__ uint32_t wave_pk_max_i16(uint32_t v) {    // all 64 lanes active
-#if defined(HF_WI) && (HF_WI == 3 || HF_WI == 4)   /* stopwatch: no reduction */
-    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
-#endif
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) v = pk_max_i16(v, (uint32_t)__shfl_xor((int)v, m, 64));
-    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
-}
-
-template <typename E, int MODE, int CZ>
-__device__ __forceinline__ bool warp_staged_body(const Geom& g, const WarpArgs& a, const int cy0, const int cx0, const int ti0, const int ti1,
-                                                 unsigned char* const lds) {
-    constexpr int VEC = 16 / (int)sizeof(E), ROWS = 2, NDW = 4;
-    constexpr bool need_a = MODE != 1, need_b = MODE != 0;
-    const int H = g.H, W = g.W, Si = g.in_stride, So = g.out_stride, rs = g.rs, lw = g.lw, lh = g.lh;
-    const int dim_y = CZ ? (H >> 1) : H;
-    if (__builtin_amdgcn_ballot_w64(true) != ~0ull) return false;             // partial waves (ragged tiles): global path
-    bool ok = cy0 + ROWS <= dim_y && cx0 + VEC <= W;
-    const int ly = CZ ? ((cy0 >> rs) << 1) : (cy0 >> rs);
-    const int lx = CZ ? ((cx0 >> rs) & ~1) : (cx0 >> rs);
-    const uint32_t f12 = a.flow_xy[(size_t)ly * lw + lx];
-    const int ox12 = (int)(int16_t)(f12 & 0xFFFFu), oy12 = (int)(int16_t)(f12 >> 16);
-    const int py = clampi(ly - (oy12 >> rs), 0, lh - 1), px = clampi(lx - (ox12 >> rs), 0, lw - 1);
-    const uint32_t f21 = a.flow_xy[(size_t)py * lw + px];
-    const int ox21 = (int)(int16_t)(f21 & 0xFFFFu), oy21 = (int)(int16_t)(f21 >> 16);
-
-    // displacement of output ti: the same arithmetic as the global path (warp_fast_body::issue)
-    auto disp = [&](const int ti, int& xa, int& xb, int& dya, int& dyb) {
-        const float s12t = a.s12v[ti], s21t = a.s21v[ti];
-        xa = cx0 + (int)roundf((float)ox12 * s12t);
-        xb = cx0 - (int)roundf((float)ox21 * s21t);
-        if (CZ) { dya = (int)roundf((float)oy12 * s12t * 0.5f); dyb = -(int)roundf((float)oy21 * s21t * 0.5f); }
-        else { dya = (int)roundf((float)oy12 * s12t); dyb = -(int)roundf((float)oy21 * s21t); }
-    };
-    auto run_base = [&](const int x) { return ((unsigned)(CZ ? (x & ~1) : x) * (unsigned)sizeof(E)) & ~3u; };   // byte offset of the run's first dword in its row
-
-    // window of each source: chunks [c_lo, c_hi] x rows [y_lo, y_hi] over all outputs (per lane), then over the wave
-    int c_lo_a = 32767, c_hi_a = 0, y_lo_a = 32767, y_hi_a = 0, c_lo_b = 32767, c_hi_b = 0, y_lo_b = 32767, y_hi_b = 0;
-    for (int ti = ti0; ti < ti1; ti++) {
-        int xa, xb, dya, dyb;
-        disp(ti, xa, xb, dya, dyb);
-        if (need_a) {
-            ok = ok && xa >= 1 && xa + VEC - 1 <= W - 2 && cy0 + dya >= 1 && cy0 + ROWS - 1 + dya <= dim_y - 2;   // mirrorCoordinate is the identity
-            const int b0 = (int)run_base(xa);
-            c_lo_a = min(c_lo_a, b0 >> 4); c_hi_a = max(c_hi_a, (b0 + 4 * NDW + 3) >> 4);
-            y_lo_a = min(y_lo_a, cy0 + dya); y_hi_a = max(y_hi_a, cy0 + dya + ROWS - 1);
-        }
-        if (need_b) {
-            ok = ok && xb >= 1 && xb + VEC - 1 <= W - 2 && cy0 + dyb >= 1 && cy0 + ROWS - 1 + dyb <= dim_y - 2;
-            const int b0 = (int)run_base(xb);
-            c_lo_b = min(c_lo_b, b0 >> 4); c_hi_b = max(c_hi_b, (b0 + 4 * NDW + 3) >> 4);
-            y_lo_b = min(y_lo_b, cy0 + dyb); y_hi_b = max(y_hi_b, cy0 + dyb + ROWS - 1);
-        }
-    }
-    if (__builtin_amdgcn_ballot_w64(!ok) != 0) return false;
-    // (all values are in [0, 32767]: chunk indices < row bytes / 16, rows < plane height)
-    int cmin_a = 0, ymin_a = 0, C_a = 1, R_a = 0, cmin_b = 0, ymin_b = 0, C_b = 1, R_b = 0;
-    if (need_a) {
-        const uint32_t lo = wave_pk_max_i16(pk_i16(-c_lo_a, -y_lo_a)), hi = wave_pk_max_i16(pk_i16(c_hi_a, y_hi_a));
-        cmin_a = -(int)(int16_t)(lo & 0xFFFFu); ymin_a = -((int)lo >> 16);
-        C_a = (int)(hi & 0xFFFFu) - cmin_a + 1; R_a = ((int)hi >> 16) - ymin_a + 1;
-    }
-    if (need_b) {
-        const uint32_t lo = wave_pk_max_i16(pk_i16(-c_lo_b, -y_lo_b)), hi = wave_pk_max_i16(pk_i16(c_hi_b, y_hi_b));
-        cmin_b = -(int)(int16_t)(lo & 0xFFFFu); ymin_b = -((int)lo >> 16);
-        C_b = (int)(hi & 0xFFFFu) - cmin_b + 1; R_b = ((int)hi >> 16) - ymin_b + 1;
-    }
-    if (R_a * C_a > kStageChunks || R_b * C_b > kStageChunks) return false;   // wave-uniform
-
-    // copy the windows: chunk q = 64 i + lane of a window lies at row q / C, column q % C; its LDS address is 16 q
-    const unsigned pitch_b = (unsigned)Si * (unsigned)sizeof(E);
-    const unsigned plane_bytes = (unsigned)dim_y * pitch_b;
-    const E* __restrict__ A = (const E*)a.frame12 + (size_t)CZ * H * Si;
-    const E* __restrict__ B = (const E*)a.frame21 + (size_t)CZ * H * Si;
-    const unsigned lane = threadIdx.x & 63u;
-    typedef __attribute__((address_space(3))) void* lds_ptr;
-    auto stage = [&](const void* plane, const int cmin, const int ymin, const int C, const int R, unsigned char* const win) {
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(plane), 0, (int)plane_bytes, 0x00020000);
-        const unsigned magic = (65536u + (unsigned)C - 1u) / (unsigned)C;       // q / C == (q * magic) >> 16 for q < 256, C <= 256 (checked exhaustively, tests)
-        const unsigned origin = __umul24((unsigned)ymin, pitch_b) + (unsigned)cmin * 16u;
-        const int n = R * C;
-#pragma unroll
-        for (int i = 0; i < kStageDma; i++) {
-#if defined(HF_WI) && HF_WI == 4   /* stopwatch: no window copy at all */
-            if (false) {
-#else
-            if (i * 64 < n) {                                                   // wave-uniform
-#endif
-                const unsigned q = (unsigned)i * 64u + lane;
-                const unsigned row = (q * magic) >> 16, col = q - row * (unsigned)C;
-                // (chunks past the window's end land behind it inside this wave's LDS share; reads past the plane return 0)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(win + i * 1024), 16, origin + __umul24(row, pitch_b) + col * 16u, 0, 0, 0);
-            }
-        }
-    };
-    if (need_a) stage(A, cmin_a, ymin_a, C_a, R_a, lds);
-    if (need_b) stage(B, cmin_b, ymin_b, C_b, R_b, lds + kStageChunks * 16);
-    __builtin_amdgcn_s_waitcnt(0x0F70);                                         // vmcnt(0): the windows are in LDS (this wave wrote nothing else yet)
-    __builtin_amdgcn_wave_barrier();
-
-    const Levels lv = make_levels(a.black, a.white);
-    using Src = WarpSrc<E, VEC, ROWS, 1>;
-    auto lds_run = [&](const unsigned char* win, const int wrow, const int C, const unsigned byte_in_win, const unsigned off, const unsigned odd) {
-        const uint32_t* p = (const uint32_t*)(win + (unsigned)(wrow * C) * 16u + byte_in_win);
-        uint32_t w[NDW + 1];
-#pragma unroll
-        for (int j = 0; j <= NDW; j++) w[j] = p[j];
-        return run_from_dwords<E, VEC, CZ>(w, off, odd);
-    };
-    Src S;
-    for (int ti = ti0; ti < ti1; ti++) {
-        int xa, xb, dya, dyb;
-        disp(ti, xa, xb, dya, dyb);
-#if defined(HF_WI) && HF_WI == 2   /* stopwatch build (WRONG results): LDS runs read for the first output only */
-        if (ti == ti0) {
-#endif
-        const unsigned oa = (unsigned)(CZ ? (xa & ~1) : xa) * (unsigned)sizeof(E), ob = (unsigned)(CZ ? (xb & ~1) : xb) * (unsigned)sizeof(E);
-#pragma unroll
-        for (int r = 0; r < ROWS; r++) {
-            if (need_a) S.ra[r][0] = lds_run(lds, cy0 + r + dya - ymin_a, C_a, (oa & ~3u) - (unsigned)cmin_a * 16u, oa, (unsigned)xa & 1u);
-            if (need_b) S.rb[r][0] = lds_run(lds + kStageChunks * 16, cy0 + r + dyb - ymin_b, C_b, (ob & ~3u) - (unsigned)cmin_b * 16u, ob, (unsigned)xb & 1u);
-        }
-#if defined(HF_WI) && HF_WI == 2
-        }
-#endif
-        E* __restrict__ out = (E*)a.outv[ti] + (size_t)CZ * H * So + (size_t)cy0 * So + cx0;
-        warp_finish<E, VEC, ROWS, MODE, CZ, 16>(S, a.s12v[ti], a.s21v[ti], out, So, ROWS, lv);
-    }
-    return true;
 }
 
 // Thread = VEC consecutive elements x ROWS consecutive rows that share one flow-cell row (ROWS
@@ -936,10 +763,9 @@ constexpr int warp_max_waves(size_t elem, int group, int vb) { return vb == 16 &
 // waves executed the per-element edge path next to the run path -- that, not the interior code, was most of the
 // 1,940 VALU instructions per wave.  With 128-pixel tiles 2 of 30 tiles per row are edge tiles.)
 constexpr int kWarpTX = 16, kWarpTY = 4;
-template <typename E, int GROUP, int ROWS, int MODE, int VB, bool DW, bool STAGE = false>
+template <typename E, int GROUP, int ROWS, int MODE, int VB, bool DW>
 __global__ __launch_bounds__(64 * warp_max_waves(sizeof(E), GROUP, VB)) void warp_fast_kernel(const Geom g, const WarpBatchArgs batch, int y_groups, int out_chunk, int n_chunks) {
     constexpr int VEC = VB / sizeof(E);
-    extern __shared__ __attribute__((aligned(16))) unsigned char warp_windows[];   // STAGE: kStageBytesPerWave per wave
     // Work decomposition: tiles are numbered row-major (luma tile rows first, then chroma: the plane test is a scalar
     // branch), a workgroup takes 4 or 16 consecutive tiles, and workgroups are dealt to the XCDs in contiguous bands: linear
     // block id b runs on XCD b % 8 (MI355X_MICROARCH.md "Workgroup dispatch"), so block b works on band (b % 8).
@@ -970,19 +796,12 @@ __global__ __launch_bounds__(64 * warp_max_waves(sizeof(E), GROUP, VB)) void war
     const int lane = threadIdx.x & 63;
     const int cx0 = (tcol * kWarpTX + (lane & (kWarpTX - 1))) * VEC;
     if (cx0 >= g.W) return;
-    unsigned char* const lds = warp_windows + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * kStageBytesPerWave;
     if (trow >= y_tiles) {
         const int rg = (trow - y_tiles) * kWarpTY + (lane / kWarpTX);
-        if (rg < uv_groups) {
-            if constexpr (STAGE) if (warp_staged_body<E, MODE, 1>(g, a, rg * ROWS, cx0, ti0, ti1, lds)) return;
-            warp_fast_body<E, GROUP, ROWS, MODE, 1, VB, DW>(g, a, rg * ROWS, cx0, ti0, ti1);
-        }
+        if (rg < uv_groups) warp_fast_body<E, GROUP, ROWS, MODE, 1, VB, DW>(g, a, rg * ROWS, cx0, ti0, ti1);
     } else {
         const int rg = trow * kWarpTY + (lane / kWarpTX);
-        if (rg < y_groups) {
-            if constexpr (STAGE) if (warp_staged_body<E, MODE, 0>(g, a, rg * ROWS, cx0, ti0, ti1, lds)) return;
-            warp_fast_body<E, GROUP, ROWS, MODE, 0, VB, DW>(g, a, rg * ROWS, cx0, ti0, ti1);
-        }
+        if (rg < y_groups) warp_fast_body<E, GROUP, ROWS, MODE, 0, VB, DW>(g, a, rg * ROWS, cx0, ti0, ti1);
     }
 }
 
@@ -1089,33 +908,10 @@ static bool launch_warp_fast(const Geom& g, const WarpBatchArgs& b, hipStream_t 
     const int out_chunk = small_frame && (long)n_tiles * b.n < 4 * 8192 ? 1 : kMaxWarpOutputs;
     const int n_chunks = (max_out + out_chunk - 1) / out_chunk;
     // large workgroups only where the launch keeps every CU supplied with them (>= 4 rounds of 8,192 resident waves)
-#ifndef HF_WARP_STAGE
-#define HF_WARP_STAGE 0   // experimental (bit-exact, not yet faster): see DESIGN.md section 4
-#endif
-#ifndef HF_WARP_STAGE_WPB
-#define HF_WARP_STAGE_WPB 4
-#endif
-    // LDS-staged source windows (warp_staged_body): one flow cell per 16-byte thread, all outputs of the period per thread
-    const bool stage = HF_WARP_STAGE && VB == 16 && group == VEC && dw && out_chunk > 1 && max_out >= 2;
-    const bool large = out_chunk > 1 && (long)n_tiles * n_chunks * b.n >= 4 * 8192;
-    const int wpb = stage ? HF_WARP_STAGE_WPB : large ? warp_max_waves(sizeof(E), group, VB) : kWarpWavesSmall;
-    const size_t lds_bytes = stage ? (size_t)wpb * kStageBytesPerWave : 0;
+    // large workgroups only where the launch keeps every CU supplied with them (>= 4 rounds of 8,192 resident waves)
+    const int wpb = out_chunk > 1 && (long)n_tiles * n_chunks * b.n >= 4 * 8192 ? warp_max_waves(sizeof(E), group, VB) : kWarpWavesSmall;
     const int n_blocks = (n_tiles + wpb - 1) / wpb;
     const dim3 fg(((n_blocks * n_chunks * b.n + 7) / 8) * 8), fb(64 * wpb);
-    if constexpr (VB == 16) if (stage) {
-        constexpr int G = VEC;
-#define HF_WARP_STAGED(M)                                                                                                                        \
-        do {                                                                                                                                         \
-            auto kern = warp_fast_kernel<E, G, 2, M, 16, true, true>;                                                                                \
-            if (lds_bytes > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);     \
-            hipExtLaunchKernelGGL(kern, fg, fb, lds_bytes, stream, ev0, ev1, 0, g, b, y_groups, out_chunk, n_chunks);                                \
-        } while (0)
-        if (mode == 0) HF_WARP_STAGED(0);
-        else if (mode == 1) HF_WARP_STAGED(1);
-        else HF_WARP_STAGED(2);
-#undef HF_WARP_STAGED
-        return true;
-    }
 #define HF_WARP_FAST(G, D)                                                                   \
     do {                                                                                     \
         /* ev0/ev1 (may be null): timestamps of the dispatch itself, like rocprof's kernel trace */ \
