@@ -459,7 +459,9 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(a.workload, {})
+                # configs 4 / 5 run the same kernels on the same frame geometry as configs 2 / 3: they are priced with those PMC records
+                traffic_key = {"sdr1080_64pairs": "sdr1080_24to60", "hdr2160_nb10_blur32": "hdr2160_24to120"}.get(a.workload, a.workload)
+                traffic = json.load(open(tpath)).get(traffic_key, {})
             except Exception:
                 traffic = None
         # PHYSICAL roofline: HBM bytes the whole pipeline moves per output frame (warp + phase planes + chain, rocprofv3 PMC passes
@@ -469,7 +471,7 @@ def main():
         pipe = (traffic or {}).get("pipeline") or {}
         bytes_per_frame = pipe.get("hbm_bytes_per_output_frame")
         if bytes_per_frame:
-            basis = "measured: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over the pipeline at %s" % (pipe.get("operating_point"),)
+            basis = "measured: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over the pipeline of workload %s at %s (profiles/roofline_traffic.json)" % (traffic_key, pipe.get("operating_point"))
         else:   # no PMC record for this workload: the compulsory traffic of the launches (what they cannot avoid moving)
             k_out = (SOURCE_24 / target)
             pp_bytes = st["phase_plane_bytes"]

@@ -23,15 +23,17 @@ def per_kernel(path, counter):
 
 
 def short(name):
-    """'void hf::(anonymous namespace)::flow_level_small_kernel<16, true>(hf::Geom, ...)' -> 'flow_level_small_kernel<16, true>'"""
-    n = name.split("(anonymous namespace)::")[-1] if "(anonymous namespace)::" in name else name.split("hf::")[-1]
+    """'void hf::(anonymous namespace)::flow_level_small_kernel<16, true>(hf::Geom, hf::(anonymous namespace)::FlowBatchArgs)'
+    -> 'flow_level_small_kernel<16, true>'"""
+    n = name[5:] if name.startswith("void ") else name
     depth = 0
-    for i, ch in enumerate(n):
+    for i, ch in enumerate(n):               # cut the argument list: the first '(' outside template brackets that opens it
         if ch == "<": depth += 1
         elif ch == ">": depth -= 1
-        elif ch == "(" and depth == 0:
-            return n[:i]
-    return n
+        elif ch == "(" and depth == 0 and not n[i:].startswith("(anonymous namespace)"):
+            n = n[:i]
+            break
+    return n.replace("hf::(anonymous namespace)::", "").replace("hf::", "")
 
 
 def pipeline_entry(a):
@@ -61,7 +63,9 @@ def pipeline_entry(a):
         wr = sum(wb.get(name, [])) * 1024 / periods_w
         if rd + wr < 1:
             continue
-        per_kernel_bytes[short(name)] = {"read": int(rd), "write": int(wr), "dispatches_per_pair_period": round(len(wb.get(name, [])) / periods_w * a.batch, 2)}
+        k = short(name)
+        assert k not in per_kernel_bytes, k
+        per_kernel_bytes[k] = {"read": int(rd), "write": int(wr), "dispatches_per_pair_period": round(len(wb.get(name, [])) / periods_w * a.batch, 2)}
         total += rd + wr
     return {
         "hbm_bytes_per_output_frame": int(total / frames_per_pair_period),
