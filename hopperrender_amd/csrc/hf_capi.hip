@@ -1241,10 +1241,13 @@ int hf_wait_download(hf_ctx* c, uint64_t index) {
     HF_CHECK_CTX(c);
     if (index >= c->dl_issued) return fail(c, HF_ERR_INVALID_ARGUMENT, "hf_wait_download: download %llu has not been issued (%llu so far)",
                                            (unsigned long long)index, (unsigned long long)c->dl_issued);
-    if (c->dl_issued - index > (uint64_t)hf_ctx::kDlRing) return HF_OK;   // older than the event ring: every later one has been recorded behind it
     if (int rc = set_device(c)) return rc;
-    // (if the ring has wrapped past `index` the event belongs to a LATER download on the same in-order stream: waiting for it is still correct)
-    HF_HIP(c, hipEventSynchronize(c->ev_dl[index % hf_ctx::kDlRing]));
+    // The ring keeps the events of the last kDlRing downloads.  A slot that has been reused belongs to a LATER download of the same
+    // in-order stream, so waiting for it (or, for an index older than the whole ring, for the oldest event still kept) implies that
+    // download `index` has landed.
+    const uint64_t oldest = c->dl_issued > (uint64_t)hf_ctx::kDlRing ? c->dl_issued - (uint64_t)hf_ctx::kDlRing : 0;
+    const uint64_t wait_for = index < oldest ? oldest : index;
+    HF_HIP(c, hipEventSynchronize(c->ev_dl[wait_for % hf_ctx::kDlRing]));
     return HF_OK;
 }
 

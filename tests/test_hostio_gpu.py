@@ -143,6 +143,18 @@ def test_wait_flow_and_wait_download(native_lib):
         c.waitDownload(i)
         assert (outs[i].array == want[i]).all(), i
     c.sync()
+    # more readbacks in flight than the context keeps events for (64): waiting for an old index must still mean "it has landed"
+    many = [PinnedArray(fr[0].size, np.uint8) for _ in range(80)]
+    ts = [i / 100.0 for i in range(80)]
+    base = c.downloadsIssued()
+    for i, t in enumerate(ts):
+        c.warpFrames(t, 2); c.downloadFrameAsync(many[i])
+    assert c.downloadsIssued() == base + 80
+    for i in (0, 7, 15, 16, 63, 79):
+        c.waitDownload(base + i)
+        ref.warpFrames(ts[i], 2)
+        assert (many[i].array == ref.downloadFrame()).all(), i
+    c.sync()
     ref.close(); c.close()
-    for p in pins + outs:
+    for p in pins + outs + many:
         p.free()
