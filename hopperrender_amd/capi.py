@@ -35,6 +35,21 @@ class HfDeviceCaps(C.Structure):
                 ("wavefront_size", C.c_int32)]
 
 
+class HfTimelineChunk(C.Structure):
+    _fields_ = [("first_period", C.c_int64), ("n_periods", C.c_int64), ("first_frame", C.c_int64), ("n_frames", C.c_int64),
+                ("first_output", C.c_int64), ("n_outputs", C.c_int64), ("blend_at_start", C.c_double)]
+
+
+class HfHostioConfig(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("in_ring", C.c_int32), ("out_ring", C.c_int32), ("frame_output_mode", C.c_int32),
+                ("scene_change_threshold", C.c_int32), ("reserved", C.c_int32), ("source_frame_time", C.c_int64),
+                ("target_frame_time", C.c_int64)]
+
+
+HF_HOSTIO_FILL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_void_p)
+HF_HOSTIO_SINK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32)
+
+
 class HfParams(C.Structure):
     _fields_ = [("delta_scalar", C.c_int32), ("neighbor_scalar", C.c_int32), ("black_level", C.c_float),
                 ("white_level", C.c_float), ("search_radius", C.c_int32), ("frame_count", C.c_uint32)]
@@ -115,6 +130,12 @@ SIGNATURES = {
     "hf_set_profile_interval": (_i, [_vp, _i, _i]),
     "hf_timer_begin": (_i, [_vp]),
     "hf_timer_end": (_i, [_vp, C.POINTER(C.c_float)]),
+    "hf_shard_timeline": (_i, [C.c_int64, _i, _i, C.c_int64, C.c_int64, _i, _i, C.POINTER(HfTimelineChunk), C.POINTER(C.c_int32), C.POINTER(C.c_float), C.c_int64]),
+    "hf_hostio_create": (_i, [_vp, C.POINTER(HfHostioConfig), C.POINTER(_vp)]),
+    "hf_hostio_destroy": (None, [_vp]),
+    "hf_hostio_run": (_i, [_vp, C.POINTER(HfTimelineChunk), C.POINTER(C.c_int32), C.POINTER(C.c_float), HF_HOSTIO_FILL_FN, HF_HOSTIO_SINK_FN, _vp, C.POINTER(C.c_int32)]),
+    "hf_hostio_get_traffic": (_i, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "hf_hostio_last_error": (C.c_char_p, [_vp]),
     "hf_device_count": (_i, []),
     "hf_device_malloc": (_i, [_i, C.c_size_t, C.POINTER(_vp)]),
     "hf_device_free": (_i, [_i, _vp]),

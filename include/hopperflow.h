@@ -314,6 +314,45 @@ int hf_filter_get_state(const hf_filter* filter, hf_filter_state* out);
  * has been touched at that point). */
 int hf_filter_deliver(hf_filter* filter, hf_ctx* ctx, const void* host_in, void* const* host_out, int max_out, int* n_out, int32_t* kinds);
 
+/* ---- Streaming host-I/O driver of one rank + timeline planner (multi-GPU hosts; csrc/hf_hostio.cpp, plain host C++) --------
+ * The reference's filter feeds the calculator from host memory with blocking transfers (opticalFlowCalcSDR.cpp:19-42) on one
+ * GPU.  A throughput host converts one clip on several GPUs: rank r (= process = GPU) owns a contiguous chunk of the source
+ * timeline (hf_shard_timeline: no exchange between ranks -- the warm-up frames in front of a chunk rebuild ring, previous flow
+ * and scene-change history), and hf_hostio_run() streams it: pinned input ring -> hf_update_frame_async -> chain / warps ->
+ * hf_download_frame_async -> pinned output ring -> sink(), output frames strictly in index order, the filter's warp-vs-copy
+ * decision (hf_filter) made per period from that period's m_totalFrameDelta (one hf_wait_flow per period).  `fill` and `sink`
+ * run on the calling thread; the buffers they are handed are page-locked and only valid during the call. */
+typedef struct hf_timeline_chunk {
+    int64_t first_period, n_periods;   /* source periods (= source frames) this rank interpolates */
+    int64_t first_frame, n_frames;     /* source frames it has to be fed: the warm-up frames + its own */
+    int64_t first_output, n_outputs;   /* global index of its first output frame, number of its output frames */
+    double blend_at_start;             /* m_dBlendingScalar when its first period begins */
+} hf_timeline_chunk;
+/* n_out (optional): [n_periods] outputs per owned period; t (optional): their blending scalars, t_capacity entries at least
+ * n_outputs (call once with n_out = t = NULL to learn the sizes).  overlap = 3 and delta_history = 12 reproduce the sequential
+ * filter (delta_history 0: scene-change detection off). */
+int hf_shard_timeline(int64_t n_source_frames, int world, int rank, int64_t source_frame_time, int64_t target_frame_time, int overlap,
+                      int delta_history, hf_timeline_chunk* out, int32_t* n_out, float* t, int64_t t_capacity);
+typedef struct hf_hostio hf_hostio;
+typedef struct hf_hostio_config {
+    uint32_t struct_size;
+    int32_t in_ring, out_ring;          /* page-locked input / output frame buffers; <= 0 -> 3 / 12 (>= 3 / >= 2) */
+    int32_t frame_output_mode;          /* m_iFrameOutput, BlendedFrame = 2 */
+    int32_t scene_change_threshold;     /* < 0 -> DEFAULT_SCENE_CHANGE_THRESHOLD */
+    int32_t reserved;
+    int64_t source_frame_time, target_frame_time;   /* 100-ns units; <= 0 -> 417083 / 166667 */
+} hf_hostio_config;
+typedef int (*hf_hostio_fill_fn)(void* user, int64_t source_frame_index, void* pinned_frame);              /* 0 = ok */
+typedef int (*hf_hostio_sink_fn)(void* user, int64_t output_index_in_chunk, const void* frame, int32_t kind);   /* kind: 1 warp, 0 copy */
+/* ctx: an HF_FLAG_ASYNC (| HF_FLAG_DUAL_STREAM) context that the driver uses exclusively while it exists. */
+int hf_hostio_create(hf_ctx* ctx, const hf_hostio_config* cfg, hf_hostio** out);
+void hf_hostio_destroy(hf_hostio* io);
+/* kinds (optional): [chunk->n_outputs] 1 warp / 0 copy per output frame. */
+int hf_hostio_run(hf_hostio* io, const hf_timeline_chunk* chunk, const int32_t* n_out, const float* t, hf_hostio_fill_fn fill,
+                  hf_hostio_sink_fn sink, void* user, int32_t* kinds);
+int hf_hostio_get_traffic(const hf_hostio* io, uint64_t* bytes_in, uint64_t* bytes_out);   /* host -> device / device -> host so far */
+const char* hf_hostio_last_error(const hf_hostio* io);   /* io == NULL: last failed hf_hostio_create / hf_shard_timeline of this thread */
+
 /* ---- plain device-memory helpers so non-HIP hosts (ctypes, cgo, JNI) can stage frames ---- */
 int hf_device_count(void);
 int hf_device_malloc(int device_index, size_t bytes, void** out_dev_ptr);

@@ -110,6 +110,34 @@ def test_cli_two_gpu_workers_equal_the_sequential_cli(native_lib, tmp_path, ext,
     assert n_copies > 5          # the two start-up periods of rank 0 (HopperRender.cpp:955) + the cut period
 
 
+def test_c_example_two_workers_equal_the_sequential_cli(native_lib, tmp_path):
+    """examples/hf_interpolate_clip.c -- plain C11 against include/hopperflow.h only: hf_shard_timeline + hf_hostio_run, one worker
+    process per GPU (fork + exec before any GPU call), pread into / pwrite out of page-locked buffers -- produces the same bytes
+    as the sequential blocking CLI for a P010 clip with a hard cut (both workers on the one GPU of this box)."""
+    from hopperrender_amd import build
+    H, W, n, cut_at = 180, 320, 36, 17
+    frames = cut_clip(H, W, 1, cut_at, n - cut_at, seed=11)
+    src = tmp_path / "in.p010"
+    with open(src, "wb") as f:
+        for x in frames:
+            f.write(x.tobytes())
+    exe = tmp_path / "hf_interpolate_clip"
+    lib = os.path.dirname(build.LIB_FLOW)
+    subprocess.check_call(["gcc", "-std=c11", "-D_GNU_SOURCE", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "hf_interpolate_clip.c"), "-L", lib, "-lhopperflow", "-Wl,-rpath," + lib, "-o", str(exe)])
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "hopperrender_amd.cli", str(src), str(tmp_path / "seq.p010"), "--width", str(W), "--height", str(H), "--hdr",
+                        "--radius", "8", "--scene-threshold", "150", "--target-fps", "120"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    want = open(tmp_path / "seq.p010", "rb").read()
+    for gpus in (2, 3):
+        out = tmp_path / f"c{gpus}.p010"
+        r = subprocess.run([str(exe), str(src), str(out), str(W), str(H), "1", "120", str(gpus), "8", "150"], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        assert open(out, "rb").read() == want, r.stderr[-2000:]
+        assert f"rank {gpus - 1}/{gpus}" in r.stderr and "copies" in r.stderr
+
+
 def test_wait_flow_and_wait_download(native_lib):
     """hf_wait_flow: m_totalFrameDelta of the chain just enqueued without draining the side streams; hf_wait_download: per
     readback completion in issue order."""

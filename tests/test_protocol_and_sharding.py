@@ -118,3 +118,29 @@ dist.barrier(); dist.destroy_process_group()
     pairs = sorted(sum((g[0] for g in j["gathered"]), []))
     assert pairs == list(range(64))
     assert j["gathered"][0][1] == 0 and j["gathered"][1][1] == j["gathered"][0][2]
+
+
+def test_native_timeline_planner_equals_the_python_planner(native_lib):
+    """hf_shard_timeline (csrc/hf_hostio.cpp: what a C host plans its ranks with, the schedule taken from the native hf_filter) ==
+    batch.shard_timeline for every rank: chunk bounds, warm-up frames, first output index, outputs per period, blending scalars
+    (as the float the warp call receives), blending phase at the chunk start; the chunks tile the output index space."""
+    import ctypes as C
+    from hopperrender_amd import batch
+    from hopperrender_amd.hostio import shard_timeline_native
+    from hopperrender_amd.protocol import SOURCE_24, TARGET_60, TARGET_120
+    for n, world, target, dh in [(40, 3, TARGET_60, 12), (97, 8, TARGET_120, 12), (5, 4, TARGET_60, 12), (3, 8, TARGET_120, 0), (64, 1, 100000, 12),
+                                 (30, 2, 417083, 12), (0, 2, TARGET_60, 12)]:
+        nxt = 0
+        for rank in range(world):
+            want = batch.shard_timeline(n, world, rank, SOURCE_24, target, delta_history=dh)
+            ch, n_out, t = shard_timeline_native(n, world, rank, SOURCE_24, target, delta_history=dh)
+            assert (ch.first_period, ch.n_periods, ch.first_frame, ch.n_frames, ch.first_output) == \
+                   (want.first_period, want.n_periods, want.first_frame, want.n_frames, want.first_output), (n, world, rank)
+            assert [n_out[i] for i in range(ch.n_periods)] == [len(ts) for ts in want.scalars]
+            flat = [x for ts in want.scalars for x in ts]
+            assert ch.n_outputs == len(flat) and [t[i] for i in range(len(flat))] == [C.c_float(x).value for x in flat]
+            assert ch.blend_at_start == want.blend_at_start
+            assert ch.first_output == nxt
+            nxt += ch.n_outputs
+    with __import__("pytest").raises(Exception):
+        shard_timeline_native(10, 2, 2)
