@@ -67,15 +67,15 @@ int hf_shard_timeline(int64_t n_source_frames, int world, int rank, int64_t sour
     if (int rc = hf_filter_create(&fc, &f)) return hio_fail(nullptr, rc, "hf_shard_timeline: hf_filter_create failed");
     const int64_t base = n_source_frames / world, rem = n_source_frames % world;
     const int64_t start = rank * base + (rank < rem ? rank : rem), count = base + (rank < rem ? 1 : 0);
-    std::memset(out, 0, sizeof(*out));
-    out->first_period = start;
-    out->n_periods = count;
-    out->first_frame = start - overlap - delta_history > 0 ? start - overlap - delta_history : 0;
-    out->n_frames = start + count - out->first_frame;
+    hf_timeline_chunk ch{};                                  // (*out is only written on success)
+    ch.first_period = start;
+    ch.n_periods = count;
+    ch.first_frame = start - overlap - delta_history > 0 ? start - overlap - delta_history : 0;
+    ch.n_frames = start + count - ch.first_frame;
     int64_t outputs_before = 0, mine = 0;
     int rc = HF_OK;
     for (int64_t k = 0; k < start + count; k++) {
-        if (k == start) out->blend_at_start = hf_filter_blending_scalar(f);
+        if (k == start) ch.blend_at_start = hf_filter_blending_scalar(f);
         const int n = hf_filter_begin_source_frame(f);
         if (k >= start && n_out) n_out[k - start] = n;
         for (int i = 0; i < n; i++) {
@@ -94,8 +94,9 @@ int hf_shard_timeline(int64_t n_source_frames, int world, int rank, int64_t sour
     }
     hf_filter_destroy(f);
     if (rc) return hio_fail(nullptr, rc, "hf_shard_timeline: t_capacity too small");
-    out->first_output = outputs_before;
-    out->n_outputs = mine;
+    ch.first_output = outputs_before;
+    ch.n_outputs = mine;
+    *out = ch;
     return HF_OK;
 }
 
@@ -211,7 +212,7 @@ int hf_hostio_run(hf_hostio* h, const hf_timeline_chunk* chunk, const int32_t* n
     if (int rc = drain(issued)) return rc;
     HIO(hf_sync(c));
 #undef HIO
-    if (kinds) std::memcpy(kinds, kind_of.data(), kind_of.size() * sizeof(int32_t));
+    if (kinds && !kind_of.empty()) std::memcpy(kinds, kind_of.data(), kind_of.size() * sizeof(int32_t));
     return HF_OK;
 }
 
