@@ -139,3 +139,48 @@ def test_two_batches_of_16_match_the_reference(native_lib, name, modes):
     for bufs in outs:
         for b in bufs:
             b.free()
+
+
+@pytest.mark.parametrize("hdr,H,W,n", [(0, 2160, 3840, 1), (0, 2160, 3840, 3), (1, 1080, 1920, 12), (0, 1440, 2560, 4)])
+def test_fused_period_of_other_launch_shapes_matches_the_oracle(native_lib, hdr, H, W, n):
+    """The fused period in the launch shapes the golden files do not reach, judged by the pinned oracle at full size: 8-bit 2160p
+    (16-byte threads with TWO flow cells each: the merged-run path), 16-bit 1080p in a batch of 12 (all outputs per thread with two
+    cells per thread), 8-bit 1440p (rs = 3, 16 elements per thread)."""
+    from hopperrender_amd import capi, synth
+    from hopperrender_amd.calc import DeviceBuffer, FlowBatch, OpticalFlowCalcHDR, OpticalFlowCalcSDR
+    from oracle import oracle
+    R = 16
+    cls = OpticalFlowCalcHDR if hdr else OpticalFlowCalcSDR
+    dt = np.uint16 if hdr else np.uint8
+    g = oracle.make_geom(hdr, H, W)
+    sc = synth.Scene(H, W, bool(hdr), 4242)
+    frames = [sc.frame(k) for k in range(4)]
+    dev = _upload(frames)
+    _, flow, tot, oob = oracle.calculate_optical_flow(frames[1], frames[2], g, R)
+    assert oob == 0
+    ts = [0.0, 0.1988, 0.3996, 0.5984, 0.7992, 0.998]
+    want = {t: oracle.warp_frames(frames[1], frames[2], flow, g, np.float32(t), 2) for t in ts}
+    members = [cls(H, W, search_radius=R, flags=capi.HF_FLAG_ASYNC) for _ in range(n)]
+    outs = [[DeviceBuffer(members[0].output_frame_bytes) for _ in ts] for _ in members]
+    plans = [(ts[i % 6:] + ts[:i % 6])[:6 - (i % 2)] for i in range(n)]
+    if n == 1:
+        c = members[0]
+        for k in range(4):
+            c.updateFrameDeviceRef(dev[k].ptr)
+            if k >= 2:
+                c.calculateOpticalFlow()
+        c.interpolateOnly(plans[0], [b.ptr for b in outs[0]], 2)
+    else:
+        batch = FlowBatch(members)
+        for k in range(4):
+            batch.runPeriod(batch.preparePeriod([dev[k].ptr] * n, None, None, calculate_flow=k >= 2))
+        batch.runPeriod(batch.preparePeriod(None, plans, [[b.ptr for b in o] for o in outs], 2, calculate_flow=False))
+    for i, m in enumerate(members):
+        m.sync()
+        assert (m.readBlurredFlow(0) == flow).all(), i
+        for j, t in enumerate(plans[i]):
+            assert np.array_equal(outs[i][j].download(dt), want[t]), (i, j, t)
+    if n > 1:
+        batch.close()
+    for m in members:
+        m.close()
