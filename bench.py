@@ -58,7 +58,9 @@ OPERATING_POINT = {"hdr2160_24to120": (32, 16), "hdr2160_24to60": (32, 16), "sdr
 WORKLOAD_PARAMS = {"hdr2160_nb10_blur32": {"neighbor": 10, "blur_radius": 32}}   # overrides of --neighbor / --blur-radius
 TOTAL_PAIRS = {"sdr1080_64pairs": 64}                                            # pair streams of the whole JOB (strong-scaled over ranks)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-WARP_SYMBOL = {1: "warp_fast_kernel<unsigned short, 8, 2, 2, 16, true>", 0: "warp_fast_kernel<unsigned char, 4, 2, 2, 8, true>"}
+# the dominant kernel of the batched pipeline: 2160p HDR (one flow cell per 16-byte thread) runs the LDS-staged period warp
+# (one window per workgroup of 4 wave tiles), 1080p SDR the global-path kernel
+WARP_SYMBOL = {1: "warp_wg_kernel<unsigned short, 2, 4>", 0: "warp_fast_kernel<unsigned char, 4, 2, 2, 8, true>"}
 
 
 def parse_args():
@@ -415,25 +417,42 @@ def main():
             for k in prof:
                 prof[k] += p[k]
 
-    # Context for the roofline figure, OUTSIDE the timed region: the dominant kernel alone on the GPU (one stream,
-    # one member's fused period launch at a time, source frames rotating so that they come from HBM).
+    # Context for the roofline figure, OUTSIDE the timed region: the dominant kernel alone on the GPU -- one batch of 4 members (the
+    # smallest launch that takes the same kernel as the pipeline's 16-member launches), one fused period launch at a time, source
+    # frames rotating so that they come from HBM -- and the flow chain of one pair alone.
     isolated = None
     if rank == 0 and not a.no_profile:
         for b in batches:
             b.close()
         batches = []
+        nb = min(4, len(calcs))
         c = calcs[0]
-        c.setProfileInterval(1, 1)
-        c.resetProfile()
-        for i in range(24):
+        for x in calcs[:nb]:
+            x.setProfileInterval(1, 1)
+            x.resetProfile()
+        for i in range(12):                            # the chain of ONE pair alone
             c.updateFrameDeviceRef(pools[0][i % a.pool].ptr)
             c.calculateOpticalFlow()
-            c.sync()                                   # chain alone ...
-            c.interpolateOnly(plans[0][i % len(plans[0])], out_ptrs[0], 2)
-            c.sync()                                   # ... then the warps of the period alone
-        p = c.profile()
-        isolated = {"warp_us": 1e3 * p["warp_ms"] / max(p["warp_launches"], 1), "fpl": p["warp_frames"] / max(p["warp_launches"], 1),
-                    "flow_chain_us": 1e3 * p["flow_ms"] / max(p["flow_chains"], 1)}
+            c.sync()
+        flow_us = 1e3 * c.profile()["flow_ms"] / max(c.profile()["flow_chains"], 1)
+        small = FlowBatch(calcs[:nb]) if nb > 1 else None
+        for x in calcs[:nb]:
+            x.resetProfile()
+        for i in range(24):
+            ts = [plans[s][i % len(plans[s])] for s in range(nb)]
+            if small:
+                small.runPeriod(small.preparePeriod([pools[s][(i + s) % a.pool].ptr for s in range(nb)], None, None))
+                small.sync()                           # phase planes + chain alone ...
+                small.runPeriod(small.preparePeriod(None, ts, out_ptrs[:nb], 2, calculate_flow=False))
+                small.sync()                           # ... then the fused warp launch of the 4 members alone
+            else:
+                c.updateFrameDeviceRef(pools[0][i % a.pool].ptr); c.calculateOpticalFlow(); c.sync()
+                c.interpolateOnly(ts[0], out_ptrs[0], 2); c.sync()
+        p = c.profile()                                # the leader's profile carries the batch's warp launches
+        if small:
+            small.close()
+        isolated = {"warp_us": 1e3 * p["warp_ms"] / max(p["warp_launches"], 1) / nb, "fpl": p["warp_frames"] / max(p["warp_launches"], 1) / nb,
+                    "launch_us": 1e3 * p["warp_ms"] / max(p["warp_launches"], 1), "flow_chain_us": flow_us, "members": nb}
 
     # Host-I/O leg at N > 1 (the expected scaling limit is host memcpy / the PCIe root complex): EVERY rank feeds
     # one context from pinned host memory and reads every output frame back, all ranks at the same time, each in a child process
@@ -500,13 +519,22 @@ def main():
                         "while it runs, so this is neither a kernel roofline nor a pipeline one"}
         if isolated:
             alg = b_out * isolated["fpl"] / (isolated["warp_us"] * 1e-6) / 1e9
-            iso = {"avg_launch_us": round(isolated["warp_us"], 2), "output_frames_per_launch": round(isolated["fpl"], 3),
+            iso = {"avg_launch_us": round(isolated["launch_us"], 2), "us_per_member": round(isolated["warp_us"], 2),
+                   "output_frames_per_member": round(isolated["fpl"], 3),
                    "algorithmic_GBps": round(alg, 1), "algorithmic_frac": round(alg / HBM_PEAK_GBS, 4),
-                   "note": "the same kernel alone on the GPU (one member's fused period per launch, sources from HBM), after the timed "
+                   "members_per_launch": isolated["members"],
+                   "note": "the same kernel alone on the GPU (a 4-member launch of fused periods at a time, per member, sources from HBM), after the timed "
                            "region.  'algorithmic' credits 3F + 4N per output frame although the fused launch reads the two source "
                            "frames once for all its outputs; 'real' prices the bytes the PMC counters saw"}
-            if traffic and traffic.get("warp_kernel_hbm_bytes_per_launch") and abs(traffic.get("units_per_launch", 0) - isolated["fpl"]) < 0.75:
-                real = traffic["warp_kernel_hbm_bytes_per_launch"] / (isolated["warp_us"] * 1e-6) / 1e9
+            # bytes one member's period moves through this kernel: from the PMC pass over the pipeline (the kernel the pipeline runs) or,
+            # failing that, from the pass over single-member launches
+            per_k = (pipe.get("per_kernel_bytes_per_pair_and_period") or {})
+            warp_bytes = next((v["read"] + v["write"] for k, v in per_k.items() if k.startswith("warp_")), None)
+            if warp_bytes is None and traffic and abs(traffic.get("units_per_launch", 0) - isolated["fpl"]) < 0.75:
+                warp_bytes = traffic.get("warp_kernel_hbm_bytes_per_launch")
+            if warp_bytes:
+                iso["hbm_bytes_per_member"] = int(warp_bytes)
+                real = warp_bytes / (isolated["warp_us"] * 1e-6) / 1e9
                 iso["real_GBps"] = round(real, 1)
                 iso["real_frac"] = round(real / HBM_PEAK_GBS, 4)
             roof["kernel_isolated"] = iso

@@ -805,6 +805,224 @@ __global__ __launch_bounds__(64 * warp_max_waves(sizeof(E), GROUP, VB)) void war
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// LDS-staged period warp, one window per WORKGROUP
+// ------------------------------------------------------------------------------------------
+// The outputs of a source period read almost the same source rows -- the displacement only grows with the blending scalar.
+// Here the NW waves of a workgroup take NW vertically stacked 128 x 8 wave tiles (one tile column, 8 NW rows of one plane) and
+// copy, ONCE per period, the window of each source frame that all their outputs read into LDS with direct-to-LDS buffer loads
+// (16 bytes per lane, 1 KB per instruction, no VGPR round trip); every output then takes its runs from LDS (five dword reads
+// per run + the same funnel shift / byte permute as the global path).  One window per workgroup instead of one per wave: the
+// windows of vertically neighbouring tiles overlap by the vertical displacement range, so the copy fetches 1.15-1.2 x the tile
+// (per wave: 1.55 x).  The window is found per workgroup (per-wave min / max over lanes and outputs of the runs' 16-byte chunks
+// and rows -- packed 16-bit DPP butterfly -- combined through LDS); workgroups whose runs do not fit the LDS budget (fast or
+// diverging motion), touch the mirror zone or contain a partial wave take the global path (warp_fast_body): same results.
+#ifndef HF_WARP_WG
+#define HF_WARP_WG 4   // waves (= vertically stacked wave tiles) per workgroup; 0 = off.  Measured, 2160p HDR pipeline (2 batch streams of
+                       // 16), k frames/s: 68.8-70.0 off, 71.9-72.5 / 72.9-73.4 / 73.9-74.1 / 66.7-67.8 / 61.3 with 2 / 3 / 4 / 6 / 16 waves
+#endif
+#ifndef HF_WARP_WG_CPW
+#define HF_WARP_WG_CPW 192
+#endif
+constexpr int wg_chunks(int nw) { return nw >= 16 ? nw * 160 : nw * HF_WARP_WG_CPW; }   // 16-byte chunks per source window (12 KB for 4 waves)
+
+typedef short short2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) {
+    short2v x, y;
+    __builtin_memcpy(&x, &a, 4); __builtin_memcpy(&y, &b, 4);
+    const short2v m = __builtin_elementwise_max(x, y);
+    uint32_t r;
+    __builtin_memcpy(&r, &m, 4);
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_i16(int lo, int hi) { return ((uint32_t)lo & 0xFFFFu) | ((uint32_t)hi << 16); }
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_mov(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true); }
+// max of both 16-bit halves over the wave (all 64 lanes active): xor butterfly inside every 16-lane row on the DPP path
+// (quad_perm 1032 / 2301, row_half_mirror, row_mirror), then the four rows on the scalar unit
+__device__ __forceinline__ uint32_t wave_pk_max_i16(uint32_t v) {
+    v = pk_max_i16(v, dpp_mov<0xB1>(v));
+    v = pk_max_i16(v, dpp_mov<0x4E>(v));
+    v = pk_max_i16(v, dpp_mov<0x141>(v));
+    v = pk_max_i16(v, dpp_mov<0x140>(v));
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), r1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 16),
+                   r2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), r3 = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+    return pk_max_i16(pk_max_i16(r0, r1), pk_max_i16(r2, r3));
+}
+
+template <typename E, int MODE, int CZ, int NW>
+__device__ __forceinline__ void warp_wg_body(const Geom& g, const WarpArgs& a, const int cy0, const int cx0, const bool lane_valid, const int wave,
+                                             unsigned char* const lds, uint32_t (*s_bounds)[4], int* s_state) {
+    constexpr int VEC = 16 / (int)sizeof(E), ROWS = 2, NDW = 4, CHUNKS = wg_chunks(NW);
+    constexpr bool need_a = MODE != 1, need_b = MODE != 0;
+    const int H = g.H, W = g.W, Si = g.in_stride, So = g.out_stride, rs = g.rs, lw = g.lw, lh = g.lh;
+    const int dim_y = CZ ? (H >> 1) : H;
+    const int n = a.n_out;
+    const unsigned lane = threadIdx.x & 63u;
+    const uint64_t valid_mask = __builtin_amdgcn_ballot_w64(lane_valid);
+    const bool present = valid_mask != 0, full = valid_mask == ~0ull;          // wave-uniform
+
+    // ---- phase A: the runs of every output (computed once, kept packed: row << 16 | byte offset in the row) and their bounds
+    uint32_t run_a[kMaxWarpOutputs], run_b[kMaxWarpOutputs], odd_ab = 0u;
+    int c_lo_a = 32767, c_hi_a = 0, y_lo_a = 32767, y_hi_a = 0, c_lo_b = 32767, c_hi_b = 0, y_lo_b = 32767, y_hi_b = 0;
+    bool ok = lane_valid && cy0 + ROWS <= dim_y && cx0 + VEC <= W && (unsigned)Si * (unsigned)sizeof(E) < 65536u;
+#pragma unroll
+    for (int j = 0; j < kMaxWarpOutputs; j++) run_a[j] = run_b[j] = 0u;
+    if (full) {
+        const int ly = CZ ? ((cy0 >> rs) << 1) : (cy0 >> rs);
+        const int lx = CZ ? ((cx0 >> rs) & ~1) : (cx0 >> rs);
+        const uint32_t f12 = a.flow_xy[(size_t)ly * lw + lx];
+        const int ox12 = (int)(int16_t)(f12 & 0xFFFFu), oy12 = (int)(int16_t)(f12 >> 16);
+        const int py = clampi(ly - (oy12 >> rs), 0, lh - 1), px = clampi(lx - (ox12 >> rs), 0, lw - 1);
+        const uint32_t f21 = a.flow_xy[(size_t)py * lw + px];
+        const int ox21 = (int)(int16_t)(f21 & 0xFFFFu), oy21 = (int)(int16_t)(f21 >> 16);
+#pragma unroll
+        for (int j = 0; j < kMaxWarpOutputs; j++) {
+            if (j < n) {   // the same arithmetic as the global path (warp_fast_body::issue)
+                const float s12t = a.s12v[j], s21t = a.s21v[j];
+                const int xa = cx0 + (int)roundf((float)ox12 * s12t), xb = cx0 - (int)roundf((float)ox21 * s21t);
+                const int dya = CZ ? (int)roundf((float)oy12 * s12t * 0.5f) : (int)roundf((float)oy12 * s12t);
+                const int dyb = CZ ? -(int)roundf((float)oy21 * s21t * 0.5f) : -(int)roundf((float)oy21 * s21t);
+                if (need_a) {
+                    ok = ok && xa >= 1 && xa + VEC - 1 <= W - 2 && cy0 + dya >= 1 && cy0 + ROWS - 1 + dya <= dim_y - 2;   // mirrorCoordinate is the identity
+                    const unsigned off = (unsigned)(CZ ? (xa & ~1) : xa) * (unsigned)sizeof(E);
+                    const int b0 = (int)(off & ~3u), y = cy0 + dya;
+                    c_lo_a = min(c_lo_a, b0 >> 4); c_hi_a = max(c_hi_a, (b0 + 4 * NDW + 3) >> 4);
+                    y_lo_a = min(y_lo_a, y); y_hi_a = max(y_hi_a, y + ROWS - 1);
+                    run_a[j] = ((uint32_t)y << 16) | off;
+                    odd_ab |= ((unsigned)xa & 1u) << j;
+                }
+                if (need_b) {
+                    ok = ok && xb >= 1 && xb + VEC - 1 <= W - 2 && cy0 + dyb >= 1 && cy0 + ROWS - 1 + dyb <= dim_y - 2;
+                    const unsigned off = (unsigned)(CZ ? (xb & ~1) : xb) * (unsigned)sizeof(E);
+                    const int b0 = (int)(off & ~3u), y = cy0 + dyb;
+                    c_lo_b = min(c_lo_b, b0 >> 4); c_hi_b = max(c_hi_b, (b0 + 4 * NDW + 3) >> 4);
+                    y_lo_b = min(y_lo_b, y); y_hi_b = max(y_hi_b, y + ROWS - 1);
+                    run_b[j] = ((uint32_t)y << 16) | off;
+                    odd_ab |= ((unsigned)xb & 1u) << (8 + j);
+                }
+            }
+        }
+    }
+    // wave state: 2 = no tile (past the plane's end), 1 = stageable, 0 = needs the global path (partial wave, edge, mirror zone)
+    const int state = !present ? 2 : (full && __builtin_amdgcn_ballot_w64(!ok) == 0) ? 1 : 0;
+    uint32_t b4[4] = {0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u};   // neutral element of the packed signed max
+    if (state == 1) {   // all values are in [0, 32767]
+        if (need_a) { b4[0] = wave_pk_max_i16(pk_i16(-c_lo_a, -y_lo_a)); b4[1] = wave_pk_max_i16(pk_i16(c_hi_a, y_hi_a)); }
+        if (need_b) { b4[2] = wave_pk_max_i16(pk_i16(-c_lo_b, -y_lo_b)); b4[3] = wave_pk_max_i16(pk_i16(c_hi_b, y_hi_b)); }
+    }
+    if (lane < 4) s_bounds[wave][lane] = b4[lane];
+    if (lane == 0) s_state[wave] = state;
+    __syncthreads();
+    bool wg_ok = true;
+    uint32_t m4[4] = {0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u};
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+        const int st = s_state[w];
+        wg_ok = wg_ok && st != 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) m4[k] = pk_max_i16(m4[k], s_bounds[w][k]);
+    }
+    int cmin_a = 0, ymin_a = 0, C_a = 1, R_a = 0, cmin_b = 0, ymin_b = 0, C_b = 1, R_b = 0;
+    if (wg_ok) {
+        const uint32_t la = (uint32_t)__builtin_amdgcn_readfirstlane((int)m4[0]), ha = (uint32_t)__builtin_amdgcn_readfirstlane((int)m4[1]);
+        const uint32_t lb = (uint32_t)__builtin_amdgcn_readfirstlane((int)m4[2]), hb = (uint32_t)__builtin_amdgcn_readfirstlane((int)m4[3]);
+        if (need_a) { cmin_a = -(int)(int16_t)(la & 0xFFFFu); ymin_a = -((int)la >> 16); C_a = (int)(int16_t)(ha & 0xFFFFu) - cmin_a + 1; R_a = ((int)ha >> 16) - ymin_a + 1; }
+        if (need_b) { cmin_b = -(int)(int16_t)(lb & 0xFFFFu); ymin_b = -((int)lb >> 16); C_b = (int)(int16_t)(hb & 0xFFFFu) - cmin_b + 1; R_b = ((int)hb >> 16) - ymin_b + 1; }
+        // (a direct-to-LDS instruction writes 64 chunks: the windows are rounded up to that)
+        wg_ok = ((R_a * C_a + 63) & ~63) <= CHUNKS && ((R_b * C_b + 63) & ~63) <= CHUNKS && C_a <= 64 && C_b <= 64;
+    }
+    wg_ok = __builtin_amdgcn_readfirstlane((int)wg_ok) != 0;
+    if (!wg_ok) {   // workgroup-uniform: no barrier follows
+        if (lane_valid) warp_fast_body<E, VEC, ROWS, MODE, CZ, 16, true>(g, a, cy0, cx0, 0, n);
+        return;
+    }
+
+    // ---- phase B: copy the windows.  Chunk q of a window lies at row q / C, column q % C; its LDS address is 16 q.
+    const unsigned pitch_b = (unsigned)Si * (unsigned)sizeof(E);
+    const unsigned plane_bytes = (unsigned)dim_y * pitch_b;
+    const E* __restrict__ A = (const E*)a.frame12 + (size_t)CZ * H * Si;
+    const E* __restrict__ B = (const E*)a.frame21 + (size_t)CZ * H * Si;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    auto stage = [&](const void* plane, const int cmin, const int ymin, const int C, const int R, unsigned char* const win) {
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(plane), 0, (int)plane_bytes, 0x00020000);
+        const unsigned magic = ((1u << 20) + (unsigned)C - 1u) / (unsigned)C;   // q / C == (q * magic) >> 20 for q < 4096, C <= 64 (q * (magic C - 2^20) < 2^20)
+        const unsigned origin = __umul24((unsigned)ymin, pitch_b) + (unsigned)cmin * 16u;
+        const int nq = R * C;
+#pragma unroll
+        for (int i = 0; i < (CHUNKS + 64 * NW - 1) / (64 * NW); i++) {
+            const int q0 = (i * NW + wave) * 64;                                // wave-uniform
+            if (q0 < nq) {
+                const unsigned q = (unsigned)q0 + lane;
+                const unsigned row = (q * magic) >> 20, col = q - __umul24(row, (unsigned)C);
+                // (chunks past the window's end land behind it inside the window's LDS share; reads past the plane return 0)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(win + (size_t)q0 * 16), 16, origin + __umul24(row, pitch_b) + col * 16u, 0, 0, 0);
+            }
+        }
+    };
+    if (need_a) stage(A, cmin_a, ymin_a, C_a, R_a, lds);
+    if (need_b) stage(B, cmin_b, ymin_b, C_b, R_b, lds + CHUNKS * 16);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                                         // vmcnt(0): this wave's share of the windows is in LDS
+    __syncthreads();
+    if (state != 1) return;                                                     // a wave without a tile only helped copying
+
+    // ---- phase C: every output from LDS
+    const Levels lv = make_levels(a.black, a.white);
+    using Src = WarpSrc<E, VEC, ROWS, 1>;
+    auto lds_run = [&](const unsigned char* win, const uint32_t run, const int r, const int ymin, const int cmin, const int C, const unsigned odd) {
+        const unsigned off = run & 0xFFFFu;
+        const int wrow = (int)(run >> 16) + r - ymin;
+        const uint32_t* p = (const uint32_t*)(win + (unsigned)(__umul24((unsigned)wrow, (unsigned)C) - (unsigned)cmin) * 16u + (off & ~3u));
+        uint32_t w[NDW + 1];
+#pragma unroll
+        for (int k = 0; k <= NDW; k++) w[k] = p[k];
+        return run_from_dwords<E, VEC, CZ>(w, off, odd);
+    };
+    const size_t out_off = (size_t)CZ * H * So + (size_t)cy0 * So + cx0;
+#pragma unroll
+    for (int j = 0; j < kMaxWarpOutputs; j++) {
+        if (j < n) {
+            Src S;
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) {
+                if (need_a) S.ra[r][0] = lds_run(lds, run_a[j], r, ymin_a, cmin_a, C_a, (odd_ab >> j) & 1u);
+                if (need_b) S.rb[r][0] = lds_run(lds + CHUNKS * 16, run_b[j], r, ymin_b, cmin_b, C_b, (odd_ab >> (8 + j)) & 1u);
+            }
+            E* __restrict__ out = (E*)a.outv[j] + out_off;
+            warp_finish<E, VEC, ROWS, MODE, CZ, 16>(S, a.s12v[j], a.s21v[j], out, So, ROWS, lv);
+        }
+    }
+}
+
+template <typename E, int MODE, int NW>
+__global__ __launch_bounds__(64 * NW) void warp_wg_kernel(const Geom g, const WarpBatchArgs batch, int y_groups) {
+    constexpr int VEC = 16 / (int)sizeof(E), ROWS = 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char wg_windows[];   // 2 x wg_chunks(NW) x 16 bytes
+    __shared__ uint32_t s_bounds[NW][4];
+    __shared__ int s_state[NW];
+    const int uv_groups = ((g.H >> 1) + ROWS - 1) / ROWS;
+    const int wpr = (g.W + kWarpTX * VEC - 1) / (kWarpTX * VEC);
+    const int y_tiles = (y_groups + kWarpTY - 1) / kWarpTY, uv_tiles = (uv_groups + kWarpTY - 1) / kWarpTY;
+    const int yb = (y_tiles + NW - 1) / NW, ub = (uv_tiles + NW - 1) / NW;     // blocks of NW stacked tiles per tile column
+    const int n_blocks = wpr * (yb + ub);                                      // per member
+    const int total = n_blocks * batch.n;
+    const int per_band = (total + 7) >> 3;                                     // contiguous bands of units per XCD, as in warp_fast_kernel
+    const int u = (blockIdx.x & 7) * per_band + (blockIdx.x >> 3);
+    if (u >= total) return;
+    const int member = u / n_blocks, blk = u - member * n_blocks;
+    const WarpArgs& a = batch.s[member];
+    const bool chroma = blk >= wpr * yb;
+    const int b2 = chroma ? blk - wpr * yb : blk;
+    const int brow = b2 / wpr, tcol = b2 - brow * wpr;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int trow = brow * NW + wave;
+    const int cx0 = (tcol * kWarpTX + (lane & (kWarpTX - 1))) * VEC;
+    const int rg = trow * kWarpTY + (lane / kWarpTX);
+    const bool lane_valid = trow < (chroma ? uv_tiles : y_tiles) && cx0 < g.W && rg < (chroma ? uv_groups : y_groups);
+    if (chroma) warp_wg_body<E, MODE, 1, NW>(g, a, rg * ROWS, cx0, lane_valid, wave, wg_windows, s_bounds, s_state);
+    else warp_wg_body<E, MODE, 0, NW>(g, a, rg * ROWS, cx0, lane_valid, wave, wg_windows, s_bounds, s_state);
+}
+
 template <typename E, int VEC, bool ALIGNED>
 __global__ __launch_bounds__(256) void copy_kernel(const Geom g, const E* __restrict__ src, E* __restrict__ dst,
                                                     float black, float white) {
@@ -908,6 +1126,32 @@ static bool launch_warp_fast(const Geom& g, const WarpBatchArgs& b, hipStream_t 
     const int out_chunk = small_frame && (long)n_tiles * b.n < 4 * 8192 ? 1 : kMaxWarpOutputs;
     const int n_chunks = (max_out + out_chunk - 1) / out_chunk;
     // large workgroups only where the launch keeps every CU supplied with them (>= 4 rounds of 8,192 resident waves)
+#if HF_WARP_WG
+    // one LDS window per workgroup of HF_WARP_WG stacked wave tiles (warp_wg_kernel): one flow cell per 16-byte thread, all outputs
+    // of the period per thread, dword-aligned frames
+    // ... for launches that keep the device busy for several rounds of waves (batched periods): there the staged kernel's launch is
+    // 10 % shorter inside the pipeline (1,385 vs 1,545-1,595 us per 16 members; + 6.5 % frames/s) and as fast alone (39.5 vs 39.0 us
+    // per member); ONE member's period alone is 12 % slower that way (49.9 vs 44.3 us: two barriers and a serial prologue per
+    // workgroup with nothing to overlap them), so single launches keep the global path.
+    if constexpr (VB == 16) if (group == VEC && dw && out_chunk > 1 && max_out >= 2 && (long)n_tiles * b.n >= 4 * 8192) {
+        constexpr int NW = HF_WARP_WG;
+        const int y_tiles_ = (y_groups + kWarpTY - 1) / kWarpTY, uv_tiles_ = (uv_groups + kWarpTY - 1) / kWarpTY;
+        const int nb = wpr * ((y_tiles_ + NW - 1) / NW + (uv_tiles_ + NW - 1) / NW);
+        const dim3 wg(((nb * b.n + 7) / 8) * 8), wb(64 * NW);
+        const size_t lds_bytes = (size_t)2 * wg_chunks(NW) * 16;
+#define HF_WARP_WG_LAUNCH(M)                                                                                                                  \
+        do {                                                                                                                                      \
+            auto kern = warp_wg_kernel<E, M, NW>;                                                                                                 \
+            if (lds_bytes > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);  \
+            hipExtLaunchKernelGGL(kern, wg, wb, lds_bytes, stream, ev0, ev1, 0, g, b, y_groups);                                                  \
+        } while (0)
+        if (mode == 0) HF_WARP_WG_LAUNCH(0);
+        else if (mode == 1) HF_WARP_WG_LAUNCH(1);
+        else HF_WARP_WG_LAUNCH(2);
+#undef HF_WARP_WG_LAUNCH
+        return true;
+    }
+#endif
     // large workgroups only where the launch keeps every CU supplied with them (>= 4 rounds of 8,192 resident waves)
     const int wpb = out_chunk > 1 && (long)n_tiles * n_chunks * b.n >= 4 * 8192 ? warp_max_waves(sizeof(E), group, VB) : kWarpWavesSmall;
     const int n_blocks = (n_tiles + wpb - 1) / wpb;

@@ -184,3 +184,63 @@ def test_fused_period_of_other_launch_shapes_matches_the_oracle(native_lib, hdr,
         batch.close()
     for m in members:
         m.close()
+
+
+@pytest.mark.parametrize("flow_kind", ["uniform_small", "uniform_large", "diverging", "noise", "vertical_fast", "half_and_half"])
+def test_staged_warp_and_its_fallbacks_match_oracle_and_global_path(native_lib, flow_kind):
+    """The batched 2160p HDR period warp copies the window of each source frame that all outputs of a 128 x 32 workgroup tile read
+    into LDS (warp_wg_kernel) and falls back to the global path per workgroup when the runs do not fit the window (fast or
+    diverging motion), touch the mirror zone, or a wave is partial.  Injected flow fields force each case: members of a batch of 4
+    (staged kernel) must equal a single context (global-path kernel) bit for bit, and the oracle on one output."""
+    from hopperrender_amd import capi, synth
+    from hopperrender_amd.calc import DeviceBuffer, FlowBatch, OpticalFlowCalcHDR
+    from oracle import oracle
+    H, W, n = 2160, 3840, 4
+    g = oracle.make_geom(1, H, W)
+    lw, lh = g.lw, g.lh
+    rng = np.random.default_rng(7)
+    flow = np.zeros((2, lh, lw), np.int16)
+    if flow_kind == "uniform_small":
+        flow[0], flow[1] = 9, -5                               # every window fits: all interior workgroups staged
+    elif flow_kind == "uniform_large":
+        flow[0], flow[1] = 230, -140                           # 0.8 x 140 rows of displacement range: no window fits -> global path
+    elif flow_kind == "diverging":
+        flow[0] = np.linspace(-200, 200, lw).astype(np.int16)[None, :]          # x displacement varies by 13 pixels per tile
+        flow[1] = np.linspace(-90, 90, lh).astype(np.int16)[:, None]
+    elif flow_kind == "noise":
+        flow[:] = rng.integers(-40, 41, size=flow.shape)       # every lane of a wave differs
+    elif flow_kind == "vertical_fast":
+        flow[1] = 64                                           # 51 rows of range at t = 0.8: over the 12 KB window of a 32-row tile
+    else:
+        flow[0, :, : lw // 2], flow[1, :, : lw // 2] = 4, 2    # left half fits, right half does not: both paths in one launch
+        flow[0, :, lw // 2:], flow[1, :, lw // 2:] = -300, 200
+    sc = synth.Scene(H, W, True, 99)
+    frames = [sc.frame(k) for k in range(3)]
+    dev = _upload(frames)
+    ts = [0.0, 0.1988, 0.5, 0.7992, 0.998]
+    single = OpticalFlowCalcHDR(H, W, search_radius=5, flags=capi.HF_FLAG_ASYNC)
+    members = [OpticalFlowCalcHDR(H, W, search_radius=5, flags=capi.HF_FLAG_ASYNC) for _ in range(n)]
+    for c in [single] + members:
+        for k in range(3):
+            c.updateFrameDeviceRef(dev[k].ptr)
+        c.sync()
+        c.writeBlurredFlow(0, flow)
+    outs_s = [DeviceBuffer(single.output_frame_bytes) for _ in ts]
+    outs_b = [[DeviceBuffer(single.output_frame_bytes) for _ in ts] for _ in range(n)]
+    batch = FlowBatch(members)
+    plans = [ts[i:] + ts[:i] for i in range(n)]
+    for mode in (2, 0, 1):
+        single.interpolateOnly(ts, [b.ptr for b in outs_s], mode)
+        single.sync()
+        want = {t: outs_s[j].download(np.uint16) for j, t in enumerate(ts)}
+        if mode == 2:
+            t = ts[3]
+            assert np.array_equal(want[t], oracle.warp_frames(frames[0], frames[1], flow, g, np.float32(t), 2)), flow_kind
+        batch.interpolatePeriod(plans, [[b.ptr for b in o] for o in outs_b], mode)
+        for i, m in enumerate(members):
+            m.sync()
+            for j, t in enumerate(plans[i]):
+                assert np.array_equal(outs_b[i][j].download(np.uint16), want[t]), (flow_kind, mode, i, t)
+    batch.close()
+    for c in [single] + members:
+        c.close()

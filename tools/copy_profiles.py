@@ -25,7 +25,7 @@ def reduce_rows(path, counter, keep):
 
 
 for wl in ("hdr2160_24to120", "sdr1080_24to60"):
-    for kind, prefix, keep, extra in (("warp_period", "pmc", lambda n: "warp_fast_kernel" in n, []),
+    for kind, prefix, keep, extra in (("warp_period", "pmc", lambda n: "::warp_" in n, []),
                                       ("pipeline", "pmcpipe", lambda n: "hf::" in n, ["--pipeline", "--batch", "16"])):
         files = []
         for c in ("FETCH_SIZE", "WRITE_SIZE"):

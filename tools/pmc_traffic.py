@@ -87,7 +87,7 @@ def main():
     ap.add_argument("--pipeline", action="store_true", help="the CSVs are passes over the batched pipeline: write the workload's `pipeline` entry")
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "roofline_traffic.json"))
-    ap.add_argument("--kernel", default="warp_fast_kernel")
+    ap.add_argument("--kernel", default="::warp_", help="substring of the dominant kernel's name (warp_fast_kernel / warp_wg_kernel)")
     ap.add_argument("--units-per-launch", type=float, default=0.0, help="output frames of the launches selected (0: take it from --frames-by-write)")
     ap.add_argument("--frame-bytes", type=int, default=0, help="bytes of one output frame: units per launch = WRITE_SIZE / frame bytes")
     a = ap.parse_args()
