@@ -505,10 +505,19 @@ def main():
                 "frac_algorithmic": round(pipeline_gbs / HBM_PEAK_GBS, 4), "achieved_algorithmic": round(pipeline_gbs, 1),
                 "algorithmic_definition": "SURVEY.md 8(d): frames/s per GPU x B_out, B_out = 3F + 4N bytes per output frame",
                 "algorithmic_bytes_per_unit": b_out,
-                "traffic": (traffic or {}).get("warp_kernel_hbm_bytes_per_launch"),
-                "traffic_note": "HBM bytes of one fused period launch (one member) of the dominant kernel (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
-                                "profiles/roofline_traffic.json generated by tools/pmc_traffic.py)",
+                "traffic": None, "traffic_note": None,
                 "kernel": WARP_SYMBOL[hdr]}
+        # HBM bytes of ONE launch of the dominant kernel as the pipeline issues it (a.batch members): PMC pass over the pipeline, else
+        # the pass over single-member launches
+        per_k = (pipe.get("per_kernel_bytes_per_pair_and_period") or {})
+        warp_bytes_member = next((v["read"] + v["write"] for k, v in per_k.items() if k.startswith("warp_")), None)
+        if warp_bytes_member:
+            roof["traffic"] = int(warp_bytes_member * max(a.batch, 1))
+            roof["traffic_note"] = (f"HBM bytes of one launch of the dominant kernel = {max(a.batch, 1)} members' fused periods ({int(warp_bytes_member)} B per member; "
+                                    "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over the pipeline, profiles/roofline_traffic.json generated by tools/pmc_traffic.py)")
+        elif traffic and traffic.get("warp_kernel_hbm_bytes_per_launch"):
+            roof["traffic"] = traffic["warp_kernel_hbm_bytes_per_launch"]
+            roof["traffic_note"] = "HBM bytes of one single-member fused period launch (PMC pass over --streams 1 --batch 1)"
         if prof["warp_launches"]:
             avg_ms = prof["warp_ms"] / prof["warp_launches"]
             fpl = prof["warp_frames"] / prof["warp_launches"]     # output frames per launch (a batch's period is one fused launch)
@@ -528,8 +537,7 @@ def main():
                            "frames once for all its outputs; 'real' prices the bytes the PMC counters saw"}
             # bytes one member's period moves through this kernel: from the PMC pass over the pipeline (the kernel the pipeline runs) or,
             # failing that, from the pass over single-member launches
-            per_k = (pipe.get("per_kernel_bytes_per_pair_and_period") or {})
-            warp_bytes = next((v["read"] + v["write"] for k, v in per_k.items() if k.startswith("warp_")), None)
+            warp_bytes = warp_bytes_member
             if warp_bytes is None and traffic and abs(traffic.get("units_per_launch", 0) - isolated["fpl"]) < 0.75:
                 warp_bytes = traffic.get("warp_kernel_hbm_bytes_per_launch")
             if warp_bytes:

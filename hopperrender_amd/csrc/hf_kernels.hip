@@ -911,7 +911,10 @@ __device__ __forceinline__ void warp_wg_body(const Geom& g, const WarpArgs& a, c
         if (need_a) { b4[0] = wave_pk_max_i16(pk_i16(-c_lo_a, -y_lo_a)); b4[1] = wave_pk_max_i16(pk_i16(c_hi_a, y_hi_a)); }
         if (need_b) { b4[2] = wave_pk_max_i16(pk_i16(-c_lo_b, -y_lo_b)); b4[3] = wave_pk_max_i16(pk_i16(c_hi_b, y_hi_b)); }
     }
-    if (lane < 4) s_bounds[wave][lane] = b4[lane];
+    {   // (selects, not b4[lane]: a dynamically indexed array would live in scratch memory -- 16 bytes per lane of HBM traffic)
+        const uint32_t mine = lane == 0 ? b4[0] : lane == 1 ? b4[1] : lane == 2 ? b4[2] : b4[3];
+        if (lane < 4) s_bounds[wave][lane] = mine;
+    }
     if (lane == 0) s_state[wave] = state;
     __syncthreads();
     bool wg_ok = true;
