@@ -1136,7 +1136,10 @@ static bool launch_warp_fast(const Geom& g, const WarpBatchArgs& b, hipStream_t 
     // 10 % shorter inside the pipeline (1,385 vs 1,545-1,595 us per 16 members; + 6.5 % frames/s) and as fast alone (39.5 vs 39.0 us
     // per member); ONE member's period alone is 12 % slower that way (49.9 vs 44.3 us: two barriers and a serial prologue per
     // workgroup with nothing to overlap them), so single launches keep the global path.
-    if constexpr (VB == 16) if (group == VEC && dw && out_chunk > 1 && max_out >= 2 && (long)n_tiles * b.n >= 4 * 8192) {
+#ifndef HF_WARP_WG_MIN_WAVES
+#define HF_WARP_WG_MIN_WAVES (4 * 8192)
+#endif
+    if constexpr (VB == 16) if (group == VEC && dw && out_chunk > 1 && max_out >= 2 && (long)n_tiles * b.n >= HF_WARP_WG_MIN_WAVES) {
         constexpr int NW = HF_WARP_WG;
         const int y_tiles_ = (y_groups + kWarpTY - 1) / kWarpTY, uv_tiles_ = (uv_groups + kWarpTY - 1) / kWarpTY;
         const int nb = wpr * ((y_tiles_ + NW - 1) / NW + (uv_tiles_ + NW - 1) / NW);
