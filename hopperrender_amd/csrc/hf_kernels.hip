@@ -412,9 +412,14 @@ __device__ __forceinline__ Run<E, G> run_from_dwords(const uint32_t* w, unsigned
         for (int j = 0; j < NDW; j++) o[j] = __builtin_amdgcn_alignbit(w[j + 1], w[j], sh);
     } else {
         uint32_t L[NDW + 1];
+        if constexpr (sizeof(E) == 2) {   // a 16-bit chroma run starts at an even element: always dword-aligned (sh == 0)
 #pragma unroll
-        for (int j = 0; j < NDW; j++) L[j] = __builtin_amdgcn_alignbit(w[j + 1], w[j], sh);
-        L[NDW] = w[NDW] >> sh;
+            for (int j = 0; j <= NDW; j++) L[j] = w[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < NDW; j++) L[j] = __builtin_amdgcn_alignbit(w[j + 1], w[j], sh);
+            L[NDW] = w[NDW] >> sh;
+        }
         const uint32_t sel = sizeof(E) == 2 ? (odd ? 0x07060100u : 0x03020100u) : (odd ? 0x05020300u : 0x03020100u);
 #pragma unroll
         for (int j = 0; j < NDW; j++) o[j] = __builtin_amdgcn_perm(L[j + 1], L[j], sel);
@@ -826,34 +831,36 @@ __global__ __launch_bounds__(64 * warp_max_waves(sizeof(E), GROUP, VB)) void war
 #endif
 constexpr int wg_chunks(int nw) { return nw >= 16 ? nw * 160 : nw * HF_WARP_WG_CPW; }   // 16-byte chunks per source window (12 KB for 4 waves)
 
-typedef short short2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) {
-    short2v x, y;
+typedef unsigned short ushort2w __attribute__((ext_vector_type(2)));
+// min / max of both unsigned 16-bit halves (v_pk_min_u16 / v_pk_max_u16)
+template <bool MAX>
+__device__ __forceinline__ uint32_t pk_mm_u16(uint32_t a, uint32_t b) {
+    ushort2w x, y;
     __builtin_memcpy(&x, &a, 4); __builtin_memcpy(&y, &b, 4);
-    const short2v m = __builtin_elementwise_max(x, y);
+    const ushort2w m = MAX ? __builtin_elementwise_max(x, y) : __builtin_elementwise_min(x, y);
     uint32_t r;
     __builtin_memcpy(&r, &m, 4);
     return r;
 }
-__device__ __forceinline__ uint32_t pk_i16(int lo, int hi) { return ((uint32_t)lo & 0xFFFFu) | ((uint32_t)hi << 16); }
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp_mov(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true); }
-// max of both 16-bit halves over the wave (all 64 lanes active): xor butterfly inside every 16-lane row on the DPP path
-// (quad_perm 1032 / 2301, row_half_mirror, row_mirror), then the four rows on the scalar unit
-__device__ __forceinline__ uint32_t wave_pk_max_i16(uint32_t v) {
-    v = pk_max_i16(v, dpp_mov<0xB1>(v));
-    v = pk_max_i16(v, dpp_mov<0x4E>(v));
-    v = pk_max_i16(v, dpp_mov<0x141>(v));
-    v = pk_max_i16(v, dpp_mov<0x140>(v));
+// ... over the wave (all 64 lanes active): xor butterfly inside every 16-lane row on the DPP path (quad_perm 1032 / 2301,
+// row_half_mirror, row_mirror), then the four rows on the scalar unit
+template <bool MAX>
+__device__ __forceinline__ uint32_t wave_pk_mm_u16(uint32_t v) {
+    v = pk_mm_u16<MAX>(v, dpp_mov<0xB1>(v));
+    v = pk_mm_u16<MAX>(v, dpp_mov<0x4E>(v));
+    v = pk_mm_u16<MAX>(v, dpp_mov<0x141>(v));
+    v = pk_mm_u16<MAX>(v, dpp_mov<0x140>(v));
     const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), r1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 16),
                    r2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), r3 = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
-    return pk_max_i16(pk_max_i16(r0, r1), pk_max_i16(r2, r3));
+    return pk_mm_u16<MAX>(pk_mm_u16<MAX>(r0, r1), pk_mm_u16<MAX>(r2, r3));
 }
 
 template <typename E, int MODE, int CZ, int NW>
 __device__ __forceinline__ void warp_wg_body(const Geom& g, const WarpArgs& a, const int cy0, const int cx0, const bool lane_valid, const int wave,
                                              unsigned char* const lds, uint32_t (*s_bounds)[4], int* s_state) {
-    constexpr int VEC = 16 / (int)sizeof(E), ROWS = 2, NDW = 4, CHUNKS = wg_chunks(NW);
+    constexpr int VEC = 16 / (int)sizeof(E), ROWS = 2, NDW = 4, CHUNKS = wg_chunks(NW), SZ = (int)sizeof(E);
     constexpr bool need_a = MODE != 1, need_b = MODE != 0;
     const int H = g.H, W = g.W, Si = g.in_stride, So = g.out_stride, rs = g.rs, lw = g.lw, lh = g.lh;
     const int dim_y = CZ ? (H >> 1) : H;
@@ -862,10 +869,12 @@ __device__ __forceinline__ void warp_wg_body(const Geom& g, const WarpArgs& a, c
     const uint64_t valid_mask = __builtin_amdgcn_ballot_w64(lane_valid);
     const bool present = valid_mask != 0, full = valid_mask == ~0ull;          // wave-uniform
 
-    // ---- phase A: the runs of every output (computed once, kept packed: row << 16 | byte offset in the row) and their bounds
+    // ---- phase A: the run of every output in each source, computed once -- the same arithmetic as the global path
+    // (warp_fast_body::issue) -- and kept as ONE word: row << 16 | byte offset of the run's first element in its row (rows < 32768;
+    // row bytes < 32768 is a precondition).  Their extremes over outputs are two packed 16-bit min / max per source and output.
     uint32_t run_a[kMaxWarpOutputs], run_b[kMaxWarpOutputs], odd_ab = 0u;
-    int c_lo_a = 32767, c_hi_a = 0, y_lo_a = 32767, y_hi_a = 0, c_lo_b = 32767, c_hi_b = 0, y_lo_b = 32767, y_hi_b = 0;
-    bool ok = lane_valid && cy0 + ROWS <= dim_y && cx0 + VEC <= W && (unsigned)Si * (unsigned)sizeof(E) < 65536u;
+    uint32_t lo_a = 0xFFFFFFFFu, hi_a = 0u, lo_b = 0xFFFFFFFFu, hi_b = 0u;
+    bool ok = lane_valid && cy0 + ROWS <= dim_y && cx0 + VEC <= W && (unsigned)Si * (unsigned)SZ < 32768u && dim_y < 32768;
 #pragma unroll
     for (int j = 0; j < kMaxWarpOutputs; j++) run_a[j] = run_b[j] = 0u;
     if (full) {
@@ -876,62 +885,70 @@ __device__ __forceinline__ void warp_wg_body(const Geom& g, const WarpArgs& a, c
         const int py = clampi(ly - (oy12 >> rs), 0, lh - 1), px = clampi(lx - (ox12 >> rs), 0, lw - 1);
         const uint32_t f21 = a.flow_xy[(size_t)py * lw + px];
         const int ox21 = (int)(int16_t)(f21 & 0xFFFFu), oy21 = (int)(int16_t)(f21 >> 16);
+        int neg = 0;                                                            // any coordinate below zero (sign bits collected)
 #pragma unroll
         for (int j = 0; j < kMaxWarpOutputs; j++) {
-            if (j < n) {   // the same arithmetic as the global path (warp_fast_body::issue)
+            if (j < n) {
                 const float s12t = a.s12v[j], s21t = a.s21v[j];
                 const int xa = cx0 + (int)roundf((float)ox12 * s12t), xb = cx0 - (int)roundf((float)ox21 * s21t);
-                const int dya = CZ ? (int)roundf((float)oy12 * s12t * 0.5f) : (int)roundf((float)oy12 * s12t);
-                const int dyb = CZ ? -(int)roundf((float)oy21 * s21t * 0.5f) : -(int)roundf((float)oy21 * s21t);
+                const int ya = cy0 + (CZ ? (int)roundf((float)oy12 * s12t * 0.5f) : (int)roundf((float)oy12 * s12t));
+                const int yb = cy0 - (CZ ? (int)roundf((float)oy21 * s21t * 0.5f) : (int)roundf((float)oy21 * s21t));
                 if (need_a) {
-                    ok = ok && xa >= 1 && xa + VEC - 1 <= W - 2 && cy0 + dya >= 1 && cy0 + ROWS - 1 + dya <= dim_y - 2;   // mirrorCoordinate is the identity
-                    const unsigned off = (unsigned)(CZ ? (xa & ~1) : xa) * (unsigned)sizeof(E);
-                    const int b0 = (int)(off & ~3u), y = cy0 + dya;
-                    c_lo_a = min(c_lo_a, b0 >> 4); c_hi_a = max(c_hi_a, (b0 + 4 * NDW + 3) >> 4);
-                    y_lo_a = min(y_lo_a, y); y_hi_a = max(y_hi_a, y + ROWS - 1);
-                    run_a[j] = ((uint32_t)y << 16) | off;
-                    odd_ab |= ((unsigned)xa & 1u) << j;
+                    neg |= xa | ya;
+                    run_a[j] = ((uint32_t)ya << 16) | ((unsigned)(CZ ? (xa & ~1) : xa) * (unsigned)SZ);
+                    lo_a = pk_mm_u16<false>(lo_a, run_a[j]); hi_a = pk_mm_u16<true>(hi_a, run_a[j]);
+                    if (CZ) odd_ab |= ((unsigned)xa & 1u) << j;
                 }
                 if (need_b) {
-                    ok = ok && xb >= 1 && xb + VEC - 1 <= W - 2 && cy0 + dyb >= 1 && cy0 + ROWS - 1 + dyb <= dim_y - 2;
-                    const unsigned off = (unsigned)(CZ ? (xb & ~1) : xb) * (unsigned)sizeof(E);
-                    const int b0 = (int)(off & ~3u), y = cy0 + dyb;
-                    c_lo_b = min(c_lo_b, b0 >> 4); c_hi_b = max(c_hi_b, (b0 + 4 * NDW + 3) >> 4);
-                    y_lo_b = min(y_lo_b, y); y_hi_b = max(y_hi_b, y + ROWS - 1);
-                    run_b[j] = ((uint32_t)y << 16) | off;
-                    odd_ab |= ((unsigned)xb & 1u) << (8 + j);
+                    neg |= xb | yb;
+                    run_b[j] = ((uint32_t)yb << 16) | ((unsigned)(CZ ? (xb & ~1) : xb) * (unsigned)SZ);
+                    lo_b = pk_mm_u16<false>(lo_b, run_b[j]); hi_b = pk_mm_u16<true>(hi_b, run_b[j]);
+                    if (CZ) odd_ab |= ((unsigned)xb & 1u) << (8 + j);
                 }
             }
         }
+        // mirrorCoordinate is the identity for every run of this lane?  From the extremes (conservative for chroma, whose byte
+        // offset drops the parity of x): 1 <= x, x + VEC - 1 <= W - 2, 1 <= y, y + ROWS - 1 <= dim_y - 2
+        ok = ok && neg >= 0;
+        if (need_a) ok = ok && (int)(lo_a & 0xFFFFu) >= SZ && (int)(hi_a & 0xFFFFu) / SZ + (CZ ? 1 : 0) + VEC - 1 <= W - 2 &&
+                      (int)(lo_a >> 16) >= 1 && (int)(hi_a >> 16) + ROWS - 1 <= dim_y - 2;
+        if (need_b) ok = ok && (int)(lo_b & 0xFFFFu) >= SZ && (int)(hi_b & 0xFFFFu) / SZ + (CZ ? 1 : 0) + VEC - 1 <= W - 2 &&
+                      (int)(lo_b >> 16) >= 1 && (int)(hi_b >> 16) + ROWS - 1 <= dim_y - 2;
     }
     // wave state: 2 = no tile (past the plane's end), 1 = stageable, 0 = needs the global path (partial wave, edge, mirror zone)
     const int state = !present ? 2 : (full && __builtin_amdgcn_ballot_w64(!ok) == 0) ? 1 : 0;
-    uint32_t b4[4] = {0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u};   // neutral element of the packed signed max
-    if (state == 1) {   // all values are in [0, 32767]
-        if (need_a) { b4[0] = wave_pk_max_i16(pk_i16(-c_lo_a, -y_lo_a)); b4[1] = wave_pk_max_i16(pk_i16(c_hi_a, y_hi_a)); }
-        if (need_b) { b4[2] = wave_pk_max_i16(pk_i16(-c_lo_b, -y_lo_b)); b4[3] = wave_pk_max_i16(pk_i16(c_hi_b, y_hi_b)); }
+    uint32_t b0 = 0xFFFFFFFFu, b1 = 0u, b2 = 0xFFFFFFFFu, b3 = 0u;              // neutral elements of the packed min / max
+    if (state == 1) {
+        if (need_a) { b0 = wave_pk_mm_u16<false>(lo_a); b1 = wave_pk_mm_u16<true>(hi_a); }
+        if (need_b) { b2 = wave_pk_mm_u16<false>(lo_b); b3 = wave_pk_mm_u16<true>(hi_b); }
     }
-    {   // (selects, not b4[lane]: a dynamically indexed array would live in scratch memory -- 16 bytes per lane of HBM traffic)
-        const uint32_t mine = lane == 0 ? b4[0] : lane == 1 ? b4[1] : lane == 2 ? b4[2] : b4[3];
+    {   // (selects, not an array indexed by the lane: that would live in scratch memory -- 16 bytes per lane of HBM traffic)
+        const uint32_t mine = lane == 0 ? b0 : lane == 1 ? b1 : lane == 2 ? b2 : b3;
         if (lane < 4) s_bounds[wave][lane] = mine;
     }
     if (lane == 0) s_state[wave] = state;
     __syncthreads();
     bool wg_ok = true;
-    uint32_t m4[4] = {0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u};
+    uint32_t m0 = 0xFFFFFFFFu, m1 = 0u, m2 = 0xFFFFFFFFu, m3 = 0u;
 #pragma unroll
     for (int w = 0; w < NW; w++) {
-        const int st = s_state[w];
-        wg_ok = wg_ok && st != 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) m4[k] = pk_max_i16(m4[k], s_bounds[w][k]);
+        wg_ok = wg_ok && s_state[w] != 0;
+        m0 = pk_mm_u16<false>(m0, s_bounds[w][0]); m1 = pk_mm_u16<true>(m1, s_bounds[w][1]);
+        m2 = pk_mm_u16<false>(m2, s_bounds[w][2]); m3 = pk_mm_u16<true>(m3, s_bounds[w][3]);
     }
+    // window of a source: 16-byte chunks [cmin, cmin + C) x rows [ymin, ymin + R); a run spans NDW + 1 dwords from its first byte's
     int cmin_a = 0, ymin_a = 0, C_a = 1, R_a = 0, cmin_b = 0, ymin_b = 0, C_b = 1, R_b = 0;
     if (wg_ok) {
-        const uint32_t la = (uint32_t)__builtin_amdgcn_readfirstlane((int)m4[0]), ha = (uint32_t)__builtin_amdgcn_readfirstlane((int)m4[1]);
-        const uint32_t lb = (uint32_t)__builtin_amdgcn_readfirstlane((int)m4[2]), hb = (uint32_t)__builtin_amdgcn_readfirstlane((int)m4[3]);
-        if (need_a) { cmin_a = -(int)(int16_t)(la & 0xFFFFu); ymin_a = -((int)la >> 16); C_a = (int)(int16_t)(ha & 0xFFFFu) - cmin_a + 1; R_a = ((int)ha >> 16) - ymin_a + 1; }
-        if (need_b) { cmin_b = -(int)(int16_t)(lb & 0xFFFFu); ymin_b = -((int)lb >> 16); C_b = (int)(int16_t)(hb & 0xFFFFu) - cmin_b + 1; R_b = ((int)hb >> 16) - ymin_b + 1; }
+        const uint32_t la = (uint32_t)__builtin_amdgcn_readfirstlane((int)m0), ha = (uint32_t)__builtin_amdgcn_readfirstlane((int)m1);
+        const uint32_t lb = (uint32_t)__builtin_amdgcn_readfirstlane((int)m2), hb = (uint32_t)__builtin_amdgcn_readfirstlane((int)m3);
+        if (need_a) {
+            cmin_a = (int)(la & 0xFFFFu) >> 4; ymin_a = (int)(la >> 16);
+            C_a = (int)(((ha & 0xFFFCu) + 4u * NDW + 3u) >> 4) - cmin_a + 1; R_a = (int)(ha >> 16) + ROWS - 1 - ymin_a + 1;
+        }
+        if (need_b) {
+            cmin_b = (int)(lb & 0xFFFFu) >> 4; ymin_b = (int)(lb >> 16);
+            C_b = (int)(((hb & 0xFFFCu) + 4u * NDW + 3u) >> 4) - cmin_b + 1; R_b = (int)(hb >> 16) + ROWS - 1 - ymin_b + 1;
+        }
         // (a direct-to-LDS instruction writes 64 chunks: the windows are rounded up to that)
         wg_ok = ((R_a * C_a + 63) & ~63) <= CHUNKS && ((R_b * C_b + 63) & ~63) <= CHUNKS && C_a <= 64 && C_b <= 64;
     }
@@ -942,7 +959,7 @@ __device__ __forceinline__ void warp_wg_body(const Geom& g, const WarpArgs& a, c
     }
 
     // ---- phase B: copy the windows.  Chunk q of a window lies at row q / C, column q % C; its LDS address is 16 q.
-    const unsigned pitch_b = (unsigned)Si * (unsigned)sizeof(E);
+    const unsigned pitch_b = (unsigned)Si * (unsigned)SZ;
     const unsigned plane_bytes = (unsigned)dim_y * pitch_b;
     const E* __restrict__ A = (const E*)a.frame12 + (size_t)CZ * H * Si;
     const E* __restrict__ B = (const E*)a.frame21 + (size_t)CZ * H * Si;
@@ -969,27 +986,35 @@ __device__ __forceinline__ void warp_wg_body(const Geom& g, const WarpArgs& a, c
     __syncthreads();
     if (state != 1) return;                                                     // a wave without a tile only helped copying
 
-    // ---- phase C: every output from LDS
+    // ---- phase C: every output from LDS.  Address of a run's first dword in its window: ((row - ymin) C - cmin) 16 + (offset & ~3)
     const Levels lv = make_levels(a.black, a.white);
     using Src = WarpSrc<E, VEC, ROWS, 1>;
-    auto lds_run = [&](const unsigned char* win, const uint32_t run, const int r, const int ymin, const int cmin, const int C, const unsigned odd) {
-        const unsigned off = run & 0xFFFFu;
-        const int wrow = (int)(run >> 16) + r - ymin;
-        const uint32_t* p = (const uint32_t*)(win + (unsigned)(__umul24((unsigned)wrow, (unsigned)C) - (unsigned)cmin) * 16u + (off & ~3u));
+    auto lds_run = [&](const unsigned char* p8, const unsigned off, const unsigned odd) {
+        const uint32_t* p = (const uint32_t*)p8;
         uint32_t w[NDW + 1];
 #pragma unroll
         for (int k = 0; k <= NDW; k++) w[k] = p[k];
         return run_from_dwords<E, VEC, CZ>(w, off, odd);
     };
+    const unsigned rowb_a = (unsigned)C_a * 16u, rowb_b = (unsigned)C_b * 16u;
+    const unsigned char* const win_a = lds - (unsigned)(ymin_a * C_a + cmin_a) * 16u;           // (pointer arithmetic only: never dereferenced below lds)
+    const unsigned char* const win_b = lds + CHUNKS * 16 - (unsigned)(ymin_b * C_b + cmin_b) * 16u;
     const size_t out_off = (size_t)CZ * H * So + (size_t)cy0 * So + cx0;
 #pragma unroll
     for (int j = 0; j < kMaxWarpOutputs; j++) {
         if (j < n) {
             Src S;
-#pragma unroll
-            for (int r = 0; r < ROWS; r++) {
-                if (need_a) S.ra[r][0] = lds_run(lds, run_a[j], r, ymin_a, cmin_a, C_a, (odd_ab >> j) & 1u);
-                if (need_b) S.rb[r][0] = lds_run(lds + CHUNKS * 16, run_b[j], r, ymin_b, cmin_b, C_b, (odd_ab >> (8 + j)) & 1u);
+            if (need_a) {
+                const unsigned off = run_a[j] & 0xFFFFu, odd = (odd_ab >> j) & 1u;
+                const unsigned char* p = win_a + __umul24(run_a[j] >> 16, rowb_a) + (off & ~3u);
+                S.ra[0][0] = lds_run(p, off, odd);
+                S.ra[1][0] = lds_run(p + rowb_a, off, odd);
+            }
+            if (need_b) {
+                const unsigned off = run_b[j] & 0xFFFFu, odd = (odd_ab >> (8 + j)) & 1u;
+                const unsigned char* p = win_b + __umul24(run_b[j] >> 16, rowb_b) + (off & ~3u);
+                S.rb[0][0] = lds_run(p, off, odd);
+                S.rb[1][0] = lds_run(p + rowb_b, off, odd);
             }
             E* __restrict__ out = (E*)a.outv[j] + out_off;
             warp_finish<E, VEC, ROWS, MODE, CZ, 16>(S, a.s12v[j], a.s21v[j], out, So, ROWS, lv);
