@@ -954,7 +954,36 @@ __device__ __forceinline__ void warp_wg_body(const Geom& g, const WarpArgs& a, c
     }
     wg_ok = __builtin_amdgcn_readfirstlane((int)wg_ok) != 0;
     if (!wg_ok) {   // workgroup-uniform: no barrier follows
-        if (lane_valid) warp_fast_body<E, VEC, ROWS, MODE, CZ, 16, true>(g, a, cy0, cx0, 0, n);
+        if (state == 1) {
+            // this wave's runs are all interior, only the WORKGROUP's window does not fit (fast or diverging motion): the global
+            // path straight from the runs computed above -- no second displacement pass, no edge tests
+            const unsigned pitch_g = (unsigned)Si * (unsigned)SZ;
+            const unsigned plane_g = (unsigned)dim_y * pitch_g;
+            const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)((const E*)a.frame12 + (size_t)CZ * H * Si), 0, (int)plane_g, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc((void*)((const E*)a.frame21 + (size_t)CZ * H * Si), 0, (int)plane_g, 0x00020000);
+            const Levels lvg = make_levels(a.black, a.white);
+            const size_t out_g = (size_t)CZ * H * So + (size_t)cy0 * So + cx0;
+            for (int j = 0; j < n; j++) {
+                WarpSrc<E, VEC, ROWS, 1> S;
+                // (run_a / run_b are indexed by the loop counter of a fully unrolled loop elsewhere; here by a select chain)
+                uint32_t ra = run_a[0], rb = run_b[0];
+#pragma unroll
+                for (int k = 1; k < kMaxWarpOutputs; k++) { ra = j == k ? run_a[k] : ra; rb = j == k ? run_b[k] : rb; }
+                if (need_a) {
+                    const unsigned off = ra & 0xFFFFu, odd = (odd_ab >> j) & 1u, o = __umul24(ra >> 16, pitch_g) + off;
+                    S.ra[0][0] = get_run_buf<E, VEC, CZ>(rsrcA, o, odd);
+                    S.ra[1][0] = get_run_buf<E, VEC, CZ>(rsrcA, o + pitch_g, odd);
+                }
+                if (need_b) {
+                    const unsigned off = rb & 0xFFFFu, odd = (odd_ab >> (8 + j)) & 1u, o = __umul24(rb >> 16, pitch_g) + off;
+                    S.rb[0][0] = get_run_buf<E, VEC, CZ>(rsrcB, o, odd);
+                    S.rb[1][0] = get_run_buf<E, VEC, CZ>(rsrcB, o + pitch_g, odd);
+                }
+                warp_finish<E, VEC, ROWS, MODE, CZ, 16>(S, a.s12v[j], a.s21v[j], (E*)a.outv[j] + out_g, So, ROWS, lvg);
+            }
+        } else if (lane_valid) {
+            warp_fast_body<E, VEC, ROWS, MODE, CZ, 16, true>(g, a, cy0, cx0, 0, n);
+        }
         return;
     }
 
