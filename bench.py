@@ -417,15 +417,15 @@ def main():
             for k in prof:
                 prof[k] += p[k]
 
-    # Context for the roofline figure, OUTSIDE the timed region: the dominant kernel alone on the GPU -- one batch of 4 members (the
-    # smallest launch that takes the same kernel as the pipeline's 16-member launches), one fused period launch at a time, source
-    # frames rotating so that they come from HBM -- and the flow chain of one pair alone.
+    # Context for the roofline figure, OUTSIDE the timed region: the dominant kernel alone on the GPU -- one batch of a.batch members,
+    # i.e. exactly the launch the pipeline issues (same kernel, same grid), one fused period launch at a time, source frames
+    # rotating so that they come from HBM -- and the flow chain of one pair alone.
     isolated = None
     if rank == 0 and not a.no_profile:
         for b in batches:
             b.close()
         batches = []
-        nb = min(4, len(calcs))
+        nb = min(max(a.batch, 1), len(calcs))
         c = calcs[0]
         for x in calcs[:nb]:
             x.setProfileInterval(1, 1)
@@ -444,7 +444,7 @@ def main():
                 small.runPeriod(small.preparePeriod([pools[s][(i + s) % a.pool].ptr for s in range(nb)], None, None))
                 small.sync()                           # phase planes + chain alone ...
                 small.runPeriod(small.preparePeriod(None, ts, out_ptrs[:nb], 2, calculate_flow=False))
-                small.sync()                           # ... then the fused warp launch of the 4 members alone
+                small.sync()                           # ... then the fused warp launch of the batch alone
             else:
                 c.updateFrameDeviceRef(pools[0][i % a.pool].ptr); c.calculateOpticalFlow(); c.sync()
                 c.interpolateOnly(ts[0], out_ptrs[0], 2); c.sync()
@@ -532,7 +532,7 @@ def main():
                    "output_frames_per_member": round(isolated["fpl"], 3),
                    "algorithmic_GBps": round(alg, 1), "algorithmic_frac": round(alg / HBM_PEAK_GBS, 4),
                    "members_per_launch": isolated["members"],
-                   "note": "the same kernel alone on the GPU (a 4-member launch of fused periods at a time, per member, sources from HBM), after the timed "
+                   "note": "the same kernel alone on the GPU (one launch of the fused periods of a whole batch at a time = the launch the pipeline issues, times per member, sources from HBM), after the timed "
                            "region.  'algorithmic' credits 3F + 4N per output frame although the fused launch reads the two source "
                            "frames once for all its outputs; 'real' prices the bytes the PMC counters saw"}
             # bytes one member's period moves through this kernel: from the PMC pass over the pipeline (the kernel the pipeline runs) or,
