@@ -141,11 +141,13 @@ def test_two_batches_of_16_match_the_reference(native_lib, name, modes):
             b.free()
 
 
-@pytest.mark.parametrize("hdr,H,W,n", [(0, 2160, 3840, 1), (0, 2160, 3840, 3), (1, 1080, 1920, 12), (0, 1440, 2560, 4)])
+@pytest.mark.parametrize("hdr,H,W,n", [(0, 2160, 3840, 1), (0, 2160, 3840, 3), (1, 1080, 1920, 12), (0, 1440, 2560, 4), (0, 4320, 7680, 2), (1, 4320, 7680, 2)])
 def test_fused_period_of_other_launch_shapes_matches_the_oracle(native_lib, hdr, H, W, n):
     """The fused period in the launch shapes the golden files do not reach, judged by the pinned oracle at full size: 8-bit 2160p
     (16-byte threads with TWO flow cells each: the merged-run path), 16-bit 1080p in a batch of 12 (all outputs per thread with two
-    cells per thread), 8-bit 1440p (rs = 3, 16 elements per thread)."""
+    cells per thread), 8-bit 1440p (rs = 3, 16 elements per thread), and 4320p in batches of 2 (rs = 4: a 16-byte thread lies inside ONE
+    flow cell also for 8-bit frames, two threads per cell for 16-bit ones -- the unsigned-char instantiation and the two-lanes-per-cell
+    case of the LDS-staged workgroup kernel)."""
     from hopperrender_amd import capi, synth
     from hopperrender_amd.calc import DeviceBuffer, FlowBatch, OpticalFlowCalcHDR, OpticalFlowCalcSDR
     from oracle import oracle
