@@ -82,6 +82,7 @@ def parse_args():
     ap.add_argument("--member-warps", action="store_true", help="A-B: one fused warp launch and one phase-plane launch per member instead of per batch")
     ap.add_argument("--dual-stream-contexts", action="store_true", help="A-B: HF_FLAG_DUAL_STREAM members (warps overlap the context's own chain)")
     ap.add_argument("--no-fused-warp", action="store_true", help="A-B: one warp launch per output frame instead of one per source period")
+    ap.add_argument("--eager-planes", action="store_true", help="A-B: HF_FLAG_BATCH_EAGER_PLANES, every phase plane built by the stand-alone kernel when its frame arrives")
     ap.add_argument("--no-lazy-argmin", action="store_true", help="A-B: HF_FLAG_NO_LAZY_ARGMIN, 6 more (tiny) launches per flow chain")
     ap.add_argument("--timing-events", action="store_true",
                     help="keep the reference's per-call timing events (m_ofcCalcTime, m_warpCalcTime); default off in the bench")
@@ -276,6 +277,8 @@ def main():
         flags |= capi.HF_FLAG_DUAL_STREAM
     if a.no_lazy_argmin:
         flags |= capi.HF_FLAG_NO_LAZY_ARGMIN
+    if a.eager_planes:
+        flags |= capi.HF_FLAG_BATCH_EAGER_PLANES
     cls = OpticalFlowCalcHDR if hdr else OpticalFlowCalcSDR
     calcs, outbufs, plans = [], [], []
     P = a.periods_per_step
@@ -305,6 +308,7 @@ def main():
     # The schedule of a throughput driver is known ahead of time: the arguments of every hf_batch_run_period call (ONE native
     # call per batch and source period -- include/hopperflow.h) are marshalled before the timed region, as a C host's would be.
     one_call = bool(batches) and not (a.member_warps or a.copy_in or a.diagnose or a.py_period_calls)
+    deferred_planes = one_call and batches[0].defersPlanes()
     prepared, prepared_frames = {}, {}
     if one_call:
         for i in range(total_periods):
@@ -566,7 +570,7 @@ def main():
                        "pair_streams_per_gpu": a.streams, "pair_streams_total": a.streams * n_gpus,
                        "host_calls_per_batch_and_period": 1 if one_call else 3, "flow_batch": a.batch, "batch_streams_per_gpu": a.streams // a.batch,
                        "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
-                       "launches_per_batch_and_period": "1 phase-plane build + 12-launch chain graph + 1 fused warp" if (batches or a.batch > 1) and not a.member_warps else "per member",
+                       "launches_per_batch_and_period": ("1 phase-plane build + 12-launch chain graph + 1 fused warp" if a.eager_planes or not deferred_planes else "1 grid-sample launch + 1 fused warp (also builds the phase planes of frame N-1) + 12-launch chain graph") if (batches or a.batch > 1) and not a.member_warps else "per member",
                        "source_frames": "copied into the ring" if a.copy_in else "referenced in place (zero-copy)",
                        "source_periods_per_step": a.streams * P, "source_periods_per_stream_and_step": P,
                        "output_frames_total": int(frames_total), "parallelism": f"pair-sharded x{n_gpus}, no collective",

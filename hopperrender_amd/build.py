@@ -45,7 +45,7 @@ def build_flow(force=False):
     extra = os.environ.get("HF_CXXFLAGS", "").split()   # experiments only (e.g. -DHF_EXP=1)
     force = force or bool(extra)
     srcs = [os.path.join(CSRC, f) for f in ("hf_kernels.hip", "hf_flow.hip", "hf_capi.hip", "hf_filter.cpp", "hf_hostio.cpp")]
-    deps = srcs + [os.path.join(CSRC, "hf_kernels.h"), os.path.join(INCLUDE, "hopperflow.h"), os.path.join(INCLUDE, "config.h")]
+    deps = srcs + [os.path.join(CSRC, "hf_kernels.h"), os.path.join(CSRC, "hf_phase_plane.h"), os.path.join(INCLUDE, "hopperflow.h"), os.path.join(INCLUDE, "config.h")]
     if force or _stale(LIB_FLOW, deps):
         objs = []
         hdrs = deps[len(srcs):]

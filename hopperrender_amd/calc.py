@@ -56,6 +56,7 @@ class OpticalFlowCalc:
         self.m_opticalFlowResScalar = st.res_scalar
         self.m_opticalFlowFrameWidth, self.m_opticalFlowFrameHeight = st.low_width, st.low_height
         self.input_frame_bytes, self.output_frame_bytes = st.input_frame_bytes, st.output_frame_bytes
+        self.phase_plane_bytes = st.phase_plane_bytes
         self.dtype = np.uint16 if self.is_hdr else np.uint8
 
     # ---- public fields of the reference object, backed by the context ----
@@ -202,6 +203,15 @@ class OpticalFlowCalc:
         capi.check(self._lib.hf_read_blurred_flow(self._ctx, idx, _ptr(a)), self._ctx)
         return a
 
+    def readPhasePlane(self, ring_slot):
+        """(plane as uint32 words, complete?) -- hf_read_phase_plane"""
+        import ctypes
+        n = int(self.phase_plane_bytes)
+        a = np.empty(n // 4, dtype=np.uint32)
+        done = ctypes.c_int(0)
+        capi.check(self._lib.hf_read_phase_plane(self._ctx, ring_slot, _ptr(a), ctypes.byref(done)), self._ctx)
+        return a, bool(done.value)
+
     def writeBlurredFlow(self, idx, flow):
         a = np.ascontiguousarray(flow, dtype=np.int16)
         assert a.shape == (2, self.m_opticalFlowFrameHeight, self.m_opticalFlowFrameWidth)
@@ -304,6 +314,10 @@ class FlowBatch:
         if rc != 0:
             raise capi.HopperFlowError(rc, (self._lib.hf_batch_last_error(None) or b"").decode())
         self._b = out
+
+    def defersPlanes(self):
+        """hf_batch_defers_planes: runPeriod samples only the grid of a new frame, the next period's warp launch builds its plane"""
+        return bool(self._lib.hf_batch_defers_planes(self._b))
 
     def calculateOpticalFlow(self):
         self._check(self._lib.hf_batch_calculate_optical_flow(self._b))

@@ -16,6 +16,7 @@ HF_FLAG_DUAL_STREAM = 0x40
 HF_FLAG_NO_FUSED_WARP = 0x80
 HF_FLAG_NO_TIMING = 0x200
 HF_FLAG_BATCH_NORMAL_PRIORITY = 0x800
+HF_FLAG_BATCH_EAGER_PLANES = 0x1000
 HF_MAX_PERIOD_OUTPUTS = 6
 
 (HF_OK, HF_ERR_INVALID_ARGUMENT, HF_ERR_NO_DEVICE, HF_ERR_OUT_OF_MEMORY, HF_ERR_HIP, HF_ERR_STATE) = (0, -1, -2, -3, -4, -5)
@@ -115,6 +116,7 @@ SIGNATURES = {
     "hf_batch_update_frames_device_ref": (_i, [_vp, C.POINTER(_vp)]),
     "hf_batch_interpolate_period": (_i, [_vp, C.POINTER(_i), C.POINTER(C.c_float), C.POINTER(_vp), _i]),
     "hf_batch_run_period": (_i, [_vp, C.POINTER(_vp), _i, C.POINTER(_i), C.POINTER(C.c_float), C.POINTER(_vp), _i]),
+    "hf_batch_defers_planes": (_i, [_vp]),
     "hf_batch_sync": (_i, [_vp]),
     "hf_batch_size": (_i, [_vp]),
     "hf_batch_last_error": (C.c_char_p, [_vp]),
@@ -123,6 +125,7 @@ SIGNATURES = {
     "hf_sync": (_i, [_vp]),
     "hf_read_offsets": (_i, [_vp, _vp]),
     "hf_read_blurred_flow": (_i, [_vp, _i, _vp]),
+    "hf_read_phase_plane": (_i, [_vp, _i, _vp, _vp]),
     "hf_write_blurred_flow": (_i, [_vp, _i, _vp]),
     "hf_device_rcp": (_i, [_vp, _vp, _vp, _i]),
     "hf_get_profile": (_i, [_vp, C.POINTER(HfProfile)]),

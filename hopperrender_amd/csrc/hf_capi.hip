@@ -73,6 +73,7 @@ struct hf_ctx {
     void* ring[3] = {nullptr, nullptr, nullptr};       // m_inputFrameArray, ring[2] = newest (may point at caller memory)
     void* ring_store[3] = {nullptr, nullptr, nullptr}; // the context's own frame buffers, rotating with the ring
     uint32_t* pp[3] = {nullptr, nullptr, nullptr};     // phase plane of each ring frame (hf_flow.hip)
+    bool plane_pending[3] = {false, false, false};     // deferred build (hf_batch_run_period): pp[i] holds only the grid samples so far
     hf::PhaseLayout pl{};
     void* out_frame = nullptr;                         // m_outputFrameArray
     void* out_target = nullptr;                        // where warp/copy write (out_frame or caller's)
@@ -279,6 +280,23 @@ int enqueue_flow_chain(hf_ctx* const* cs, int n, hipStream_t s) {
 }
 int enqueue_flow_chain(hf_ctx* c) { return enqueue_flow_chain(&c, 1, c->stream); }
 
+// Deferred phase planes (hf_batch_run_period): the chain reads the FULL plane of frame N-1.  Members whose pp[1] still holds only
+// the grid samples -- no warp launch took the build up -- get it from the stand-alone plane kernel now, in one launch.
+static int ensure_older_planes(hf_ctx* const* cs, int n, hipStream_t s) {
+    hf::PrepBatch pb{};
+    for (int i = 0; i < n; i++) {
+        hf_ctx* m = cs[i];
+        if (!m->plane_pending[1]) continue;
+        pb.frame[pb.n] = m->ring[1]; pb.pp[pb.n] = m->pp[1]; pb.n++;
+        m->plane_pending[1] = false;
+    }
+    if (pb.n) {
+        hf::launch_prep_frames(cs[0]->g, cs[0]->pl, pb, s);
+        if (hipGetLastError() != hipSuccess) return HF_ERR_HIP;
+    }
+    return HF_OK;
+}
+
 void finish_flow_timing(hf_ctx* c) {
     // opticalFlowCalcSDR.cpp:125-138
     if (!c->flow_timing_pending) return;
@@ -386,9 +404,10 @@ int rotate_after_upload(hf_ctx* c) {
     hipEvent_t es = c->ev_slot_prep[0];
     c->ev_slot_prep[0] = c->ev_slot_prep[1]; c->ev_slot_prep[1] = c->ev_slot_prep[2]; c->ev_slot_prep[2] = es;
     uint32_t* pp = c->pp[0];
-    c->ring[0] = c->ring[1]; c->pp[0] = c->pp[1];
-    c->ring[1] = c->ring[2]; c->pp[1] = c->pp[2];
-    c->ring[2] = f;          c->pp[2] = pp;
+    const bool pend = c->plane_pending[0];
+    c->ring[0] = c->ring[1]; c->pp[0] = c->pp[1]; c->plane_pending[0] = c->plane_pending[1];
+    c->ring[1] = c->ring[2]; c->pp[1] = c->pp[2]; c->plane_pending[1] = c->plane_pending[2];
+    c->ring[2] = f;          c->pp[2] = pp;       c->plane_pending[2] = pend;
     c->ring_phase = (c->ring_phase + 1) % 3;
     c->p.frame_count++;
     return HF_OK;
@@ -441,6 +460,7 @@ int update_common(hf_ctx* c, const void* src, hipMemcpyKind kind, bool by_refere
         HF_HIP(c, hipMemcpyAsync(c->ring[0], src, c->in_bytes, kind, c->stream));
     }
     hf::launch_prep_frame(c->g, c->pl, c->ring[0], c->pp[0], c->stream);
+    c->plane_pending[0] = false;
     HF_HIP(c, hipGetLastError());
     if (c->io_in) HF_HIP(c, hipEventRecord(c->ev_slot_prep[0], c->stream));
     rotate_after_upload(c);
@@ -715,6 +735,7 @@ int hf_update_frame_async(hf_ctx* c, const void* pinned_host_frame) {
     HF_HIP(c, hipStreamWaitEvent(c->stream, c->ev_h2d, 0));
     c->ring[0] = c->ring_store[0];
     hf::launch_prep_frame(c->g, c->pl, c->ring[0], c->pp[0], c->stream);
+    c->plane_pending[0] = false;
     HF_HIP(c, hipGetLastError());
     HF_HIP(c, hipEventRecord(c->ev_slot_prep[0], c->stream));
     rotate_after_upload(c);
@@ -799,6 +820,7 @@ int hf_calculate_optical_flow(hf_ctx* c) {
     if (int rc = set_device(c)) return rc;
     if (int rc = check_flow_params(c)) return rc;
     if (int rc = leave_warp_stream(c)) return rc;
+    if (ensure_older_planes(&c, 1, c->stream)) return fail(c, HF_ERR_HIP, "phase-plane launch failed");
 
     int span = -1;
     if (c->cfg.flags & HF_FLAG_NO_GRAPH) {
@@ -842,6 +864,7 @@ struct hf_batch {
     std::vector<hipStream_t> warp_streams;  // HF_FLAG_DUAL_STREAM members: shared streams their warps are issued on
     hipStream_t stream = nullptr;           // = members[0]'s stream, shared by all members while the batch exists
     std::map<std::vector<int>, hipGraphExec_t> graphs;
+    bool defer_planes = false;              // hf_batch_run_period: grid samples at update, full plane of frame N-1 from the warp launch
     std::string err;
 };
 
@@ -923,6 +946,10 @@ int hf_batch_create(hf_ctx* const* members, int n, hf_batch** out) {
         m->warp_stream = m->dual() ? b->warp_streams[(size_t)i % b->warp_streams.size()] : b->stream;
         m->batch = b;
     }
+    // Deferred phase planes: where the batched period warp is the workgroup-staged kernel it can build the full plane of the frame
+    // it reads anyway (hf_kernels.hip emit_plane_rows); hf_batch_run_period then only samples the grid at update time.
+    b->defer_planes = !l->dual() && !(l->cfg.flags & HF_FLAG_BATCH_EAGER_PLANES) && hf::warp_period_can_build_planes(l->g, l->pl, n);
+    for (int i = 0; i < n; i++) b->defer_planes = b->defer_planes && !(members[i]->cfg.flags & HF_FLAG_NO_FUSED_WARP);
     *out = b;
     return HF_OK;
 }
@@ -948,7 +975,12 @@ void hf_batch_destroy(hf_batch* b) {
     delete b;
 }
 
-int hf_batch_update_frames_device_ref(hf_batch* b, const void* const* device_frames) {
+static int batch_update(hf_batch* b, const void* const* device_frames, bool defer);
+int hf_batch_update_frames_device_ref(hf_batch* b, const void* const* device_frames) { return batch_update(b, device_frames, false); }
+
+// defer: only the grid samples of the new frames now (what the chain of this period reads of them); their full planes are built by
+// the next period's warp launch or, failing that, by ensure_older_planes
+static int batch_update(hf_batch* b, const void* const* device_frames, bool defer) {
     if (!b) return batch_fail(nullptr, HF_ERR_INVALID_ARGUMENT, "null batch");
     if (!device_frames) return batch_fail(b, HF_ERR_INVALID_ARGUMENT, "hf_batch_update_frames_device_ref: null argument");
     hf_ctx* l = b->members[0];
@@ -969,8 +1001,10 @@ int hf_batch_update_frames_device_ref(hf_batch* b, const void* const* device_fra
         m->ring[0] = const_cast<void*>(device_frames[i]);   // the ring references the caller's frame (hf_update_frame_device_ref)
         pb.frame[i] = m->ring[0];
         pb.pp[i] = m->pp[0];
+        m->plane_pending[0] = defer;
     }
-    hf::launch_prep_frames(l->g, l->pl, pb, b->stream);     // the phase planes of all new frames in one launch
+    if (defer) hf::launch_prep_grid(l->g, l->pl, pb, b->stream);
+    else hf::launch_prep_frames(l->g, l->pl, pb, b->stream);     // the phase planes of all new frames in one launch
     if (hipGetLastError() != hipSuccess) return batch_fail(b, HF_ERR_HIP, "phase-plane launch failed");
     for (hf_ctx* m : b->members) rotate_after_upload(m);
     return HF_OK;
@@ -989,6 +1023,7 @@ int hf_batch_calculate_optical_flow(hf_batch* b) {
             return batch_fail(b, HF_ERR_INVALID_ARGUMENT, "hf_batch_calculate_optical_flow: members differ in search radius / delta / neighbor scalar");
         key.push_back(m->ring_phase * 2 + m->blur_phase);
     }
+    if (ensure_older_planes(b->members.data(), n, b->stream)) return batch_fail(b, HF_ERR_HIP, "phase-plane launch failed");
     auto it = b->graphs.find(key);
     if (it == b->graphs.end()) {
         hipGraph_t graph = nullptr;
@@ -1061,10 +1096,11 @@ int hf_interpolate_period(hf_ctx* c, const void* device_frame, int n_out, const 
 }
 
 // Fills the period descriptor of one context: frames N-2 / N-1, the PREVIOUS flow (:154-156), levels, outputs.
-static void fill_period(hf_ctx* c, int n, const float* t, void* const* outs, hf::WarpPeriod& p) {
+// flow_index 1: the period is issued BEFORE the chain of its source period -- the previous flow is still the newest one
+static void fill_period(hf_ctx* c, int n, const float* t, void* const* outs, hf::WarpPeriod& p, int flow_index = 0) {
     const float scale = c->g.hdr ? 256.0f : 1.0f;
     p.frame12 = c->ring[0]; p.frame21 = c->ring[1];
-    p.flow = c->blurred[0]; p.flow_xy = c->blurred_xy[0];
+    p.flow = c->blurred[flow_index]; p.flow_xy = c->blurred_xy[flow_index];
     p.black = c->p.black_level * scale; p.white = c->p.white_level * scale;
     p.n_out = n;
     for (int i = 0; i < n; i++) { p.ts[i] = t[i]; p.outs[i] = outs[i] ? outs[i] : c->out_frame; }
@@ -1123,7 +1159,16 @@ int hf_interpolate_period_ex(hf_ctx* c, const void* device_frame, int n_out, con
     return rc;
 }
 
+static int batch_interpolate(hf_batch* b, const int* n_out, const float* t, void* const* device_out, int mode, bool before_chain, bool* launched);
 int hf_batch_interpolate_period(hf_batch* b, const int* n_out, const float* t, void* const* device_out, int mode) {
+    return batch_interpolate(b, n_out, t, device_out, mode, false, nullptr);
+}
+
+// before_chain (hf_batch_run_period with deferred phase planes): the period's warps go out AHEAD of the period's chain -- they read
+// frames N-2 / N-1 and the previous flow, which the chain does not touch -- and build the full plane of frame N-1 that the chain
+// then reads.  Only the one-launch path qualifies; *launched = false means nothing was enqueued and the caller keeps the usual order.
+static int batch_interpolate(hf_batch* b, const int* n_out, const float* t, void* const* device_out, int mode, bool before_chain, bool* launched) {
+    if (launched) *launched = false;
     if (!b) return batch_fail(nullptr, HF_ERR_INVALID_ARGUMENT, "null batch");
     if (!n_out || !t || !device_out) return batch_fail(b, HF_ERR_INVALID_ARGUMENT, "hf_batch_interpolate_period: null argument");
     if (mode < 0 || mode > 6) return batch_fail(b, HF_ERR_INVALID_ARGUMENT, "warpFrames: frame output mode outside [0, 6]");
@@ -1149,20 +1194,26 @@ int hf_batch_interpolate_period(hf_batch* b, const int* n_out, const float* t, v
         hf::WarpPeriod periods[hf::kMaxFlowBatch];
         for (int m = 0; m < n; m++) {
             hf_ctx* c = b->members[m];
-            fill_period(c, n_out[m], t + m * HF_MAX_PERIOD_OUTPUTS, device_out + m * HF_MAX_PERIOD_OUTPUTS, periods[m]);
+            fill_period(c, n_out[m], t + m * HF_MAX_PERIOD_OUTPUTS, device_out + m * HF_MAX_PERIOD_OUTPUTS, periods[m], before_chain ? 1 : 0);
+            if (before_chain && c->plane_pending[1]) periods[m].plane21 = c->pp[1];
             if (!c->warp_started && c->timing()) {   // m_warpCalcTime span of the member (opticalFlowCalcSDR.cpp:36-41), as in hf_warp_frames
                 if (hipEventRecord(c->ev_warp_start, b->stream) != hipSuccess) return batch_fail(b, HF_ERR_HIP, "hipEventRecord failed");
                 c->warp_started = true;
             }
         }
         const int span = span_open(l, 0);
-        if (hf::launch_warp_periods(l->g, n, periods, mode, b->stream, span >= 0 ? l->spans[span].b : nullptr, span >= 0 ? l->spans[span].e : nullptr)) {
+        bool built[hf::kMaxFlowBatch];
+        if (hf::launch_warp_periods(l->g, n, periods, mode, b->stream, span >= 0 ? l->spans[span].b : nullptr, span >= 0 ? l->spans[span].e : nullptr,
+                                    before_chain ? &l->pl : nullptr, built)) {
             if (span >= 0) { int f = 0; for (int m = 0; m < n; m++) f += n_out[m]; l->spans[span].frames = f; }
             if (hipGetLastError() != hipSuccess) return batch_fail(b, HF_ERR_HIP, "fused warp launch failed");
+            for (int m = 0; m < n; m++) if (built[m]) b->members[m]->plane_pending[1] = false;
+            if (launched) *launched = true;
             return HF_OK;
         }
         if (span >= 0) { l->ev_pool.push_back(l->spans[span].b); l->ev_pool.push_back(l->spans[span].e); l->spans.pop_back(); }
     }
+    if (before_chain) return HF_OK;   // not eligible for one launch: the caller issues the period after the chain, as usual
     for (int m = 0; m < n; m++)   // not eligible (diagnostic modes, odd shapes, dual-stream members): member by member
         if (int rc = hf_interpolate_period_ex(b->members[m], nullptr, n_out[m], t + m * HF_MAX_PERIOD_OUTPUTS, device_out + m * HF_MAX_PERIOD_OUTPUTS, mode, 0))
             return batch_fail(b, rc, b->members[m]->err);
@@ -1172,11 +1223,21 @@ int hf_batch_interpolate_period(hf_batch* b, const int* n_out, const float* t, v
 int hf_batch_run_period(hf_batch* b, const void* const* device_frames, int calculate_flow, const int* n_out, const float* t,
                         void* const* device_out, int mode) {
     if (!b) return batch_fail(nullptr, HF_ERR_INVALID_ARGUMENT, "null batch");
-    if (device_frames) if (int rc = hf_batch_update_frames_device_ref(b, device_frames)) return rc;
+    if (device_frames) if (int rc = batch_update(b, device_frames, b->defer_planes)) return rc;
+    // Deferred phase planes: a period whose older frame still lacks its full plane issues its warps FIRST (they do not depend on
+    // this period's chain) and lets that launch build the plane; same results as the order of the three calls.
+    bool warped = false;
+    if (n_out && calculate_flow && b->defer_planes && mode >= 0 && mode <= 2) {
+        bool pending = false;
+        for (hf_ctx* m : b->members) pending = pending || m->plane_pending[1];
+        if (pending) if (int rc = batch_interpolate(b, n_out, t, device_out, mode, true, &warped)) return rc;
+    }
     if (calculate_flow) if (int rc = hf_batch_calculate_optical_flow(b)) return rc;
-    if (n_out) if (int rc = hf_batch_interpolate_period(b, n_out, t, device_out, mode)) return rc;
+    if (n_out && !warped) if (int rc = hf_batch_interpolate_period(b, n_out, t, device_out, mode)) return rc;
     return HF_OK;
 }
+
+int hf_batch_defers_planes(const hf_batch* b) { return b && b->defer_planes ? 1 : 0; }
 
 int hf_batch_sync(hf_batch* b) {
     if (!b) return batch_fail(nullptr, HF_ERR_INVALID_ARGUMENT, "null batch");
@@ -1332,6 +1393,17 @@ int hf_read_blurred_flow(hf_ctx* c, int idx, int16_t* host_out) {
     if (int rc = sync_ctx(c)) return rc;
     HF_HIP(c, hipMemcpyAsync(host_out, c->blurred[idx], 2 * c->plane_elems * sizeof(int16_t), hipMemcpyDeviceToHost, c->stream));
     HF_HIP(c, hipStreamSynchronize(c->stream));
+    return HF_OK;
+}
+
+int hf_read_phase_plane(hf_ctx* c, int ring_slot, void* host_out, int* complete) {
+    HF_CHECK_CTX(c);
+    if (!host_out || ring_slot < 0 || ring_slot > 2) return fail(c, HF_ERR_INVALID_ARGUMENT, "hf_read_phase_plane: bad argument");
+    if (int rc = set_device(c)) return rc;
+    if (int rc = sync_ctx(c)) return rc;
+    HF_HIP(c, hipMemcpyAsync(host_out, c->pp[ring_slot], c->pl.bytes, hipMemcpyDeviceToHost, c->stream));
+    HF_HIP(c, hipStreamSynchronize(c->stream));
+    if (complete) *complete = c->plane_pending[ring_slot] ? 0 : 1;
     return HF_OK;
 }
 

@@ -23,6 +23,7 @@
 //     and Y of a level run in ONE launch (5 launches for levels 32..2).  Larger windows take two
 //     launches per axis (partial sums with one atomic per candidate per workgroup, then a tiny argmin).
 #include "hf_kernels.h"
+#include "hf_phase_plane.h"
 
 namespace hf {
 
@@ -43,17 +44,9 @@ __device__ __forceinline__ int mirror_clamp(int p, int dim) {
     return clampi(p, 0, dim - 1);
 }
 
-template <typename E> __device__ __forceinline__ unsigned top8(E v);
-template <> __device__ __forceinline__ unsigned top8<uint8_t>(uint8_t v) { return v; }
-template <> __device__ __forceinline__ unsigned top8<uint16_t>(uint16_t v) { return (unsigned)(v >> 8); }  // calcDeltaSumsKernelHDR.h:98
-
 // ------------------------------------------------------------------------------------------
 // phase plane
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t pack_element(uint32_t ya, uint32_t yb, uint32_t u, uint32_t v) {
-    return ya | (yb << 8) | (u << 16) | (v << 24);
-}
-
 // Generic build (any geometry): one workgroup per full-resolution luma row.  The luma row and its chroma row are
 // read once with coalesced 16-byte loads, reduced to their top 8 bits in LDS, and written back as nph2 phase rows
 // including the mirrored margins.
@@ -92,63 +85,10 @@ __global__ __launch_bounds__(256) void prep_phase_kernel(const PrepBatch batch, 
     }
 }
 
-// Fast path of the plane build (no LDS): a thread takes the 4 << RS consecutive elements behind 4 consecutive grid
-// columns of TWO luma rows (2m, 2m + 1) and of their chroma row m, and emits one 16-byte store (4 columns) per phase
-// pair and luma row.  A wave therefore reads 64 x 16..64 contiguous bytes per row and writes 1 KB per phase row.
-// The mirrored margins need no extra loads:
-//     PP[ph2][-1-k] = swap(PP[nph2-1-ph2][k])        PP[ph2][lw+k] = swap(PP[nph2-1-ph2][lw-1-k])
-// (swap = the two luma bytes exchanged; rs = 0 has one luma byte per element and no swap), because reflecting
-// x -> -x-1 (or 2W-x-1) maps phase ph of column j to phase nph-1-ph of column -j-1 and keeps the chroma pair, so a
-// thread whose columns lie within `mx` of an edge also stores its elements, columns reversed, into the margin.
-// Requires W == lw << RS, lw % 4 == 0, mx <= lw and 16-byte aligned rows (else: prep_phase_kernel).
+// Fast path of the plane build (no LDS): one plane_fast_task (hf_phase_plane.h) per thread.
 template <typename E, int RS>
 __global__ __launch_bounds__(128) void prep_phase_fast_kernel(const PrepBatch batch, int H, int W, int S, PhaseLayout pl) {
-    const E* __restrict__ f = (const E*)batch.frame[blockIdx.z];     // blockIdx.z: frame of the batch
-    uint32_t* __restrict__ pp = batch.pp[blockIdx.z];
-    constexpr int NPH = 1 << RS, NE = 4 << RS;               // phases, elements per thread and row
-    constexpr int NPH2 = NPH > 1 ? NPH / 2 : 1;
-    const int m = blockIdx.y;                                // chroma row = pair of luma rows
-    const int t = blockIdx.x * 128 + threadIdx.x;            // group of 4 grid columns
-    const int lw = W >> RS;
-    if (4 * t >= lw) return;
-    __attribute__((aligned(16))) E e[3][NE];                 // luma row 2m, luma row 2m + 1, chroma row m
-#pragma unroll
-    for (int z = 0; z < 3; z++) {
-        const E* __restrict__ src = (z < 2 ? f + (size_t)(2 * m + z) * S : f + (size_t)H * S + (size_t)m * S) + (size_t)t * NE;
-        if (NE * sizeof(E) >= 16) {
-#pragma unroll
-            for (int i = 0; i < NE * (int)sizeof(E) / 16; i++) ((uint4*)e[z])[i] = ((const uint4*)src)[i];
-        } else {                                             // RS = 0..1 with 8-bit elements: 4 or 8 bytes per thread
-#pragma unroll
-            for (int i = 0; i < NE; i++) e[z][i] = src[i];
-        }
-    }
-    const int j0 = 4 * t;                                    // first column of this thread
-    const int jl = pl.mx - 4 - j0;                           // plane index of the mirrored group in the left margin
-    const int jr = pl.mx + 2 * lw - 4 - j0;                  // ... and in the right margin
-    const bool left = j0 + 4 <= pl.mx, right = j0 >= lw - pl.mx;
-#pragma unroll
-    for (int z = 0; z < 2; z++) {
-        uint32_t* __restrict__ base = pp + (size_t)(2 * m + z) * NPH2 * pl.lwp;
-#pragma unroll
-        for (int p2 = 0; p2 < NPH2; p2++) {
-            uint32_t el[4], sw[4];
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const int x = RS > 0 ? c * NPH + 2 * p2 : c;     // element index of the column's sample inside e[]
-                const int xc = x & ~1;
-                const uint32_t ya = top8<E>(e[z][x]), yb = RS > 0 ? top8<E>(e[z][x + 1]) : 0u;
-                const uint32_t u = top8<E>(e[2][xc]), v = top8<E>(e[2][xc + 1]);
-                el[c] = pack_element(ya, yb, u, v);
-                sw[c] = RS > 0 ? pack_element(yb, ya, u, v) : el[c];
-            }
-            *(uint4*)(base + (size_t)p2 * pl.lwp + pl.mx + j0) = make_uint4(el[0], el[1], el[2], el[3]);
-            uint32_t* mrow = base + (size_t)(NPH2 - 1 - p2) * pl.lwp;
-            const uint4 rev = make_uint4(sw[3], sw[2], sw[1], sw[0]);
-            if (left) *(uint4*)(mrow + jl) = rev;
-            if (right) *(uint4*)(mrow + jr) = rev;
-        }
-    }
+    plane_fast_task<E, RS, 2>((const E*)batch.frame[blockIdx.z], batch.pp[blockIdx.z], H, W, S, pl, (int)blockIdx.y, (int)(blockIdx.x * 128 + threadIdx.x), 0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -760,11 +700,33 @@ static bool launch_prep_fast(const Geom& g, const PhaseLayout& pl, const PrepBat
 }
 
 void launch_prep_frames(const Geom& g, const PhaseLayout& pl, const PrepBatch& b, hipStream_t stream) {
+#ifdef HF_SW_NOPREP   // STOPWATCH ONLY (wrong results): no phase-plane launches after the first HF_SW_NOPREP batched ones
+    { static int calls = 0; if (b.n > 1 && ++calls > HF_SW_NOPREP) return; }
+#endif
     if (g.hdr ? launch_prep_fast<uint16_t>(g, pl, b, stream) : launch_prep_fast<uint8_t>(g, pl, b, stream)) return;
     const size_t smem = 2 * (size_t)((g.W + 15) / 16) * 16;
     const dim3 grd(g.H, b.n);
     if (g.hdr) prep_phase_kernel<uint16_t><<<grd, 256, smem, stream>>>(b, g.H, g.W, g.in_stride, pl);
     else prep_phase_kernel<uint8_t><<<grd, 256, smem, stream>>>(b, g.H, g.W, g.in_stride, pl);
+}
+
+// Grid samples only: element (cy << rs, phase pair 0, column j) of the plane = what load_strip reads of the newer frame.
+template <typename E>
+__global__ __launch_bounds__(256) void prep_grid_kernel(const PrepBatch batch, int H, int S, PhaseLayout pl, int lw) {
+    const E* __restrict__ f = (const E*)batch.frame[blockIdx.z];
+    uint32_t* __restrict__ pp = batch.pp[blockIdx.z];
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= lw) return;
+    const int sy = (int)blockIdx.y << pl.rs, x = j << pl.rs;     // rs >= 1: x is even and x + 1 lies inside the row
+    const E* __restrict__ yr = f + (size_t)sy * S + x;
+    const E* __restrict__ cr = f + (size_t)H * S + (size_t)(sy >> 1) * S + x;
+    pp[(size_t)sy * pl.nph2 * pl.lwp + pl.mx + j] = pack_element(top8<E>(yr[0]), top8<E>(yr[1]), top8<E>(cr[0]), top8<E>(cr[1]));
+}
+
+void launch_prep_grid(const Geom& g, const PhaseLayout& pl, const PrepBatch& b, hipStream_t stream) {
+    const dim3 grd((g.lw + 255) / 256, g.lh, b.n);
+    if (g.hdr) prep_grid_kernel<uint16_t><<<grd, 256, 0, stream>>>(b, g.H, g.in_stride, pl, g.lw);
+    else prep_grid_kernel<uint8_t><<<grd, 256, 0, stream>>>(b, g.H, g.in_stride, pl, g.lw);
 }
 
 void launch_prep_frame(const Geom& g, const PhaseLayout& pl, const void* frame, uint32_t* pp, hipStream_t stream) {

@@ -108,6 +108,9 @@ struct PrepBatch {
     uint32_t* pp[kMaxFlowBatch];
 };
 void launch_prep_frames(const Geom& g, const PhaseLayout& pl, const PrepBatch& b, hipStream_t stream);
+// Deferred plane build: only the grid samples of the new frames (phase pair 0 of the rows cy << rs -- all the chain reads of the
+// NEWER frame's plane); the full plane follows from the next period's warp launch (launch_warp_periods) or launch_prep_frames.
+void launch_prep_grid(const Geom& g, const PhaseLayout& pl, const PrepBatch& b, hipStream_t stream);
 // Windows <= 32: X and Y step of one level in a single launch.
 void launch_flow_level_small(const Geom& g, const FlowBatch& b, hipStream_t stream);
 // Windows > 32, one axis: partial SAD sums (atomics), then argmin + table update.
@@ -131,9 +134,16 @@ struct WarpPeriod {
     void* outs[kMaxWarpOutputs];
     float ts[kMaxWarpOutputs];
     float black, white;      // already scaled for HDR
+    uint32_t* plane21 = nullptr;   // deferred phase plane: build the full plane of frame21 here if the launch can (see below)
 };
+// pl + planes_built[n] (optional): members whose period carries a plane21 pointer get the full phase plane of their frame21 built
+// by the launch itself when it is the workgroup-staged kernel and geometry / alignment allow (planes_built[m] says so); everyone
+// else's plane stays untouched and has to be built by launch_prep_frames.
 bool launch_warp_periods(const Geom& g, int n, const WarpPeriod* periods, int mode, hipStream_t stream,
-                         hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+                         hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, const PhaseLayout* pl = nullptr,
+                         bool* planes_built = nullptr);
+// Static part of that decision for a batch of n_members contexts of geometry g (hf_batch decides once whether it defers its planes).
+bool warp_period_can_build_planes(const Geom& g, const PhaseLayout& pl, int n_members);
 // warpFrameKernel, both planes in one launch.  black/white already scaled for HDR.
 void launch_warp(const Geom& g, const void* frame12, const void* frame21, const int16_t* flow, const uint32_t* flow_xy,
                  void* out, float t, int mode, float black, float white, hipStream_t stream,

@@ -12,6 +12,7 @@
 // (measured, tests/golden/levels_ramp.npz): "a*u + b*t" is contracted to fma(a, u, b*t); the
 // division in apply_levels* is x * v_rcp_f32(y); "q*max + mid" is fma(q, max, mid).
 #include "hf_kernels.h"
+#include "hf_phase_plane.h"
 #include <type_traits>
 
 #include <hip/hip_ext.h>
@@ -221,6 +222,7 @@ struct WarpArgs {
     int n_out;
     float s12v[kMaxWarpOutputs], s21v[kMaxWarpOutputs];
     void* outv[kMaxWarpOutputs];
+    uint32_t* plane21;     // warp_wg_kernel: also build the full phase plane of frame21 here (nullptr: no) -- see emit_plane_rows
 };
 // The fused period launches of up to kMaxFlowBatch contexts of one geometry as ONE launch (hf_batch): the unit index
 // selects the member, so a batch of 8 pairs is one bandwidth-bound launch instead of 8 serialised ones.
@@ -1051,8 +1053,23 @@ __device__ __forceinline__ void warp_wg_body(const Geom& g, const WarpArgs& a, c
     }
 }
 
+// Deferred phase-plane build (hf_phase_plane.h): the chain of the NEXT source period needs the full plane of frame21, and this
+// launch reads that frame anyway -- so the launch also carries plane-building workgroups (the stand-alone kernel's own task code,
+// 16-byte loads and stores) for every member that asks (WarpArgs::plane21), placed right in front of the warp workgroups of the same
+// picture rows: the frame's rows are fetched from HBM once for both, and the stand-alone plane kernel with its 25 MB re-read of the
+// frame is not launched (prep_grid_kernel supplies the grid samples the chain of THIS period needs).
+struct PlaneOut { PhaseLayout pl; int blocks; };   // blocks: plane-building workgroups per super row (0: the launch builds no planes)
+
+// Block order per member: "super rows" = [plane-building blocks,] two luma block rows, then the chroma block row of the same
+// picture region (a chroma block of NW stacked tiles spans twice the picture rows of a luma block), so that a region's luma and
+// chroma rows pass through L2 at about the same time.
+__host__ __device__ __forceinline__ int wg_super_rows(int yb, int ub) { return ub > (yb + 1) / 2 ? ub : (yb + 1) / 2; }
+__host__ __device__ __forceinline__ int wg_blocks_per_member(int wpr, int yb, int ub, int plane_blocks) {
+    return (wpr * 3 + plane_blocks) * wg_super_rows(yb, ub);
+}
+
 template <typename E, int MODE, int NW>
-__global__ __launch_bounds__(64 * NW) void warp_wg_kernel(const Geom g, const WarpBatchArgs batch, int y_groups) {
+__global__ __launch_bounds__(64 * NW) void warp_wg_kernel(const Geom g, const WarpBatchArgs batch, int y_groups, const PlaneOut po) {
     constexpr int VEC = 16 / (int)sizeof(E), ROWS = 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char wg_windows[];   // 2 x wg_chunks(NW) x 16 bytes
     __shared__ uint32_t s_bounds[NW][4];
@@ -1061,16 +1078,33 @@ __global__ __launch_bounds__(64 * NW) void warp_wg_kernel(const Geom g, const Wa
     const int wpr = (g.W + kWarpTX * VEC - 1) / (kWarpTX * VEC);
     const int y_tiles = (y_groups + kWarpTY - 1) / kWarpTY, uv_tiles = (uv_groups + kWarpTY - 1) / kWarpTY;
     const int yb = (y_tiles + NW - 1) / NW, ub = (uv_tiles + NW - 1) / NW;     // blocks of NW stacked tiles per tile column
-    const int n_blocks = wpr * (yb + ub);                                      // per member
+    const int per_sr = wpr * 3 + po.blocks;
+    const int n_blocks = wg_blocks_per_member(wpr, yb, ub, po.blocks);
     const int total = n_blocks * batch.n;
     const int per_band = (total + 7) >> 3;                                     // contiguous bands of units per XCD, as in warp_fast_kernel
     const int u = (blockIdx.x & 7) * per_band + (blockIdx.x >> 3);
     if (u >= total) return;
     const int member = u / n_blocks, blk = u - member * n_blocks;
     const WarpArgs& a = batch.s[member];
-    const bool chroma = blk >= wpr * yb;
-    const int b2 = chroma ? blk - wpr * yb : blk;
-    const int brow = b2 / wpr, tcol = b2 - brow * wpr;
+    const int srow = blk / per_sr;
+    int r = blk - srow * per_sr;
+    if (r < po.blocks) {   // plane-building block: the chroma rows (= luma row pairs) of this super row x groups of 4 grid columns
+        if (!a.plane21) return;
+        constexpr int LR = 2 * NW * kWarpTY * ROWS;                            // luma rows per super row (2 luma block rows)
+        const int cgs = (g.W >> g.rs) >> 2;
+        const int task = r * (64 * NW) + (int)threadIdx.x;                     // one luma row x 4 columns per thread
+        const int lr = task / cgs, cg = task - lr * cgs;
+        const int y = srow * LR + lr;
+        if (lr >= LR || y >= g.H) return;
+        if (sizeof(E) == 2 && g.rs == 3) plane_fast_task<E, 3, 1>((const E*)a.frame21, a.plane21, g.H, g.W, g.in_stride, po.pl, y >> 1, cg, y & 1);
+        else plane_fast_task<E, 4, 1>((const E*)a.frame21, a.plane21, g.H, g.W, g.in_stride, po.pl, y >> 1, cg, y & 1);
+        return;
+    }
+    r -= po.blocks;
+    const int k = r / wpr, tcol = r - k * wpr;
+    const bool chroma = k == 2;
+    const int brow = chroma ? srow : 2 * srow + k;
+    if (brow >= (chroma ? ub : yb)) return;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int trow = brow * NW + wave;
     const int cx0 = (tcol * kWarpTX + (lane & (kWarpTX - 1))) * VEC;
@@ -1158,8 +1192,17 @@ static constexpr bool warp_small_frame(const Geom& g) {   // frames up to 1080p 
     return (size_t)g.W * g.H * sizeof(E) <= (size_t)1920 * 1088;
 }
 
+// Can the staged kernel build the phase planes of its members' frame21 (emit_plane_rows)?  The geometry part of the answer.
+static bool plane_emission_geometry(const Geom& g, const PhaseLayout& pl) {   // = the conditions of the fast plane kernel (hf_flow.hip launch_prep_fast)
+    const size_t esz = g.hdr ? 2 : 1;
+    const int lw = g.W >> g.rs;
+    return g.rs >= 3 && g.rs <= 4 && pl.rs == g.rs && (lw << g.rs) == g.W && lw == g.lw && (lw & 3) == 0 && pl.mx <= lw && (pl.mx & 3) == 0 &&
+           (pl.lwp & 3) == 0 && ((size_t)g.in_stride * esz) % 16 == 0 && ((size_t)g.H * g.in_stride * esz) % 16 == 0 && (g.H & 1) == 0;
+}
+
 template <typename E, int VB>
-static bool launch_warp_fast(const Geom& g, const WarpBatchArgs& b, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+static bool launch_warp_fast(const Geom& g, const WarpBatchArgs& b, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1,
+                             const PhaseLayout* pl = nullptr, bool* planes_built = nullptr) {
     constexpr int VEC = VB / sizeof(E);
     const int cell = 1 << g.rs;
     const int group = cell < VEC ? cell : VEC;
@@ -1196,14 +1239,27 @@ static bool launch_warp_fast(const Geom& g, const WarpBatchArgs& b, hipStream_t 
     if constexpr (VB == 16) if (group == VEC && dw && out_chunk > 1 && max_out >= 2 && (long)n_tiles * b.n >= HF_WARP_WG_MIN_WAVES) {
         constexpr int NW = HF_WARP_WG;
         const int y_tiles_ = (y_groups + kWarpTY - 1) / kWarpTY, uv_tiles_ = (uv_groups + kWarpTY - 1) / kWarpTY;
-        const int nb = wpr * ((y_tiles_ + NW - 1) / NW + (uv_tiles_ + NW - 1) / NW);
+        // deferred phase planes: members that ask for one (plane21) get it from this launch if geometry and alignment allow
+        WarpBatchArgs bb = b;
+        PlaneOut po{};
+        bool emit = pl && plane_emission_geometry(g, *pl);
+        for (int m = 0; m < bb.n; m++)
+            if (!emit || (((uintptr_t)bb.s[m].frame21) & 15) != 0) bb.s[m].plane21 = nullptr;
+        emit = false;
+        for (int m = 0; m < bb.n; m++) emit = emit || bb.s[m].plane21 != nullptr;
+        if (planes_built) for (int m = 0; m < bb.n; m++) planes_built[m] = bb.s[m].plane21 != nullptr;
+        if (emit) {
+            po.pl = *pl;
+            po.blocks = ((g.lw >> 2) * (2 * NW * kWarpTY * 2) + 64 * NW - 1) / (64 * NW);   // (groups of 4 columns) x (luma rows of a super row) tasks
+        }
+        const int nb = wg_blocks_per_member(wpr, (y_tiles_ + NW - 1) / NW, (uv_tiles_ + NW - 1) / NW, po.blocks);
         const dim3 wg(((nb * b.n + 7) / 8) * 8), wb(64 * NW);
         const size_t lds_bytes = (size_t)2 * wg_chunks(NW) * 16;
 #define HF_WARP_WG_LAUNCH(M)                                                                                                                  \
         do {                                                                                                                                      \
             auto kern = warp_wg_kernel<E, M, NW>;                                                                                                 \
             if (lds_bytes > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);  \
-            hipExtLaunchKernelGGL(kern, wg, wb, lds_bytes, stream, ev0, ev1, 0, g, b, y_groups);                                                  \
+            hipExtLaunchKernelGGL(kern, wg, wb, lds_bytes, stream, ev0, ev1, 0, g, bb, y_groups, po);                                             \
         } while (0)
         if (mode == 0) HF_WARP_WG_LAUNCH(0);
         else if (mode == 1) HF_WARP_WG_LAUNCH(1);
@@ -1238,10 +1294,11 @@ static bool launch_warp_fast(const Geom& g, const WarpBatchArgs& b, hipStream_t 
 
 // frames up to 1080p 8-bit: 8 bytes per thread (twice the waves); larger frames: 16 bytes per thread
 template <typename E>
-static bool launch_warp_fast_any(const Geom& g, const WarpBatchArgs& b, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+static bool launch_warp_fast_any(const Geom& g, const WarpBatchArgs& b, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1,
+                                 const PhaseLayout* pl = nullptr, bool* planes_built = nullptr) {
     const bool small = warp_small_frame<E>(g);   // (1080p SDR, 5-output period: 18.9 us with 8-byte threads, 26.8 us with 16-byte ones)
     if (small && launch_warp_fast<E, 8>(g, b, stream, ev0, ev1)) return true;   // (also in a batch of 16: 114.3 k frames/s against 100.2 k with 16-byte threads)
-    return launch_warp_fast<E, 16>(g, b, stream, ev0, ev1);
+    return launch_warp_fast<E, 16>(g, b, stream, ev0, ev1, pl, planes_built);
 }
 
 template <typename E>
@@ -1261,7 +1318,7 @@ void launch_warp(const Geom& g, const void* frame12, const void* frame21, const 
     WarpArgs a;
     a.frame12 = frame12; a.frame21 = frame21; a.flow = flow; a.flow_xy = flow_xy; a.out = out;
     a.s12 = t; a.s21 = 1.0f - t; a.mode = mode; a.black = black; a.white = white;
-    a.n_out = 1; a.s12v[0] = a.s12; a.s21v[0] = a.s21; a.outv[0] = out;
+    a.n_out = 1; a.s12v[0] = a.s12; a.s21v[0] = a.s21; a.outv[0] = out; a.plane21 = nullptr;
     if (g.hdr) launch_warp_t<uint16_t>(g, a, stream, ev0, ev1);
     else launch_warp_t<uint8_t>(g, a, stream, ev0, ev1);
 }
@@ -1278,6 +1335,7 @@ static bool fill_warp_batch(const WarpPeriod* periods, int n, int first, int mod
         a.n_out = p.n_out;
         for (int i = 0; i < p.n_out; i++) { a.s12v[i] = p.ts[i]; a.s21v[i] = 1.0f - p.ts[i]; a.outv[i] = p.outs[i]; }
         a.s12 = a.s12v[0]; a.s21 = a.s21v[0];
+        a.plane21 = p.plane21;
     }
     return true;
 }
@@ -1287,7 +1345,9 @@ static bool warp_fast_any_shape(const Geom& g, const WarpBatchArgs& b) {
     return (warp_small_frame<E>(g) && warp_fast_shape<E, 8>(g, b, dw)) || warp_fast_shape<E, 16>(g, b, dw);
 }
 
-bool launch_warp_periods(const Geom& g, int n, const WarpPeriod* periods, int mode, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+bool launch_warp_periods(const Geom& g, int n, const WarpPeriod* periods, int mode, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1,
+                         const PhaseLayout* pl, bool* planes_built) {
+    if (planes_built) for (int m = 0; m < n; m++) planes_built[m] = false;
     if (n < 1 || n > kMaxFlowBatch) return false;
     // at most kMaxWarpBatch members per launch (kernel-argument space): a batch of 32 is two launches.  ALL of them are
     // checked before the first one goes out, so a set of periods is either rendered by these launches or not touched at all
@@ -1300,10 +1360,27 @@ bool launch_warp_periods(const Geom& g, int n, const WarpPeriod* periods, int mo
         WarpBatchArgs b;
         fill_warp_batch(periods, n, first, mode, b);
         hipEvent_t e0 = first == 0 ? ev0 : nullptr, e1 = first + kMaxWarpBatch >= n ? ev1 : nullptr;
-        const bool ok = g.hdr ? launch_warp_fast_any<uint16_t>(g, b, stream, e0, e1) : launch_warp_fast_any<uint8_t>(g, b, stream, e0, e1);
+        bool* pb = planes_built ? planes_built + first : nullptr;
+        const bool ok = g.hdr ? launch_warp_fast_any<uint16_t>(g, b, stream, e0, e1, pl, pb) : launch_warp_fast_any<uint8_t>(g, b, stream, e0, e1, pl, pb);
         if (!ok) return false;   // (cannot happen after the check above)
     }
     return true;
+}
+
+bool warp_period_can_build_planes(const Geom& g, const PhaseLayout& pl, int n_members) {
+#if HF_WARP_WG
+    const size_t esz = g.hdr ? 2 : 1;
+    const int VEC = (int)(16 / esz), cell = 1 << g.rs;
+    if (cell < VEC || (size_t)g.W * g.H * esz <= (size_t)1920 * 1088) return false;     // one flow cell per 16-byte thread, no 8-byte threads
+    const int y_groups = (g.H + 1) / 2, uv_groups = ((g.H >> 1) + 1) / 2;
+    const int wpr = (g.W + kWarpTX * VEC - 1) / (kWarpTX * VEC);
+    const long n_tiles = (long)wpr * ((y_groups + kWarpTY - 1) / kWarpTY + (uv_groups + kWarpTY - 1) / kWarpTY);
+    const int per_launch = n_members < kMaxWarpBatch ? n_members : kMaxWarpBatch;
+    return n_tiles * per_launch >= HF_WARP_WG_MIN_WAVES && g.H == (g.lh << g.rs) && plane_emission_geometry(g, pl);
+#else
+    (void)g; (void)pl; (void)n_members;
+    return false;
+#endif
 }
 
 template <typename E>

@@ -64,6 +64,9 @@ typedef enum hf_output_mode {
 #define HF_FLAG_NO_FUSED_WARP 0x80 /* hf_interpolate_period: one warp launch per output frame (debug / A-B timing) */
 #define HF_FLAG_BATCH_NORMAL_PRIORITY 0x800 /* on the leader passed to hf_batch_create: give the batch a normal-priority stream
                                                 (default: highest priority, see hf_batch_create) */
+#define HF_FLAG_BATCH_EAGER_PLANES 0x1000 /* on the leader passed to hf_batch_create: hf_batch_run_period builds every phase plane in
+                                              full when its frame arrives (default for large frames: grid samples only, the full
+                                              plane comes out of the next period's warp launch -- see hf_batch_run_period) */
 #define HF_FLAG_NO_TIMING 0x200 /* do not record the events behind m_ofcCalcTime / m_warpCalcTime (hf_stats times stay 0).
                                    Every timing event is a barrier packet on the stream: measured 5-6 us each between
                                    back-to-back kernels, ~15 us per source period in a throughput pipeline */
@@ -223,9 +226,19 @@ int hf_batch_interpolate_period(hf_batch* batch, const int* n_out, const float* 
 /* One source period of the whole batch in ONE call (what a throughput driver issues per period -- three calls' worth of
  * argument marshalling matter when a period is ~70 us of GPU time): hf_batch_update_frames_device_ref(device_frames) unless
  * device_frames == NULL, hf_batch_calculate_optical_flow() if calculate_flow, hf_batch_interpolate_period(n_out, t,
- * device_out, mode) unless n_out == NULL.  Same results and same error behaviour as the three calls. */
+ * device_out, mode) unless n_out == NULL.  Same results and same error behaviour as the three calls.
+ * Where the batched period warp is the workgroup-staged kernel (batches of frames > 1080p, one flow cell per 16-byte thread) the
+ * call defers the phase planes: at update time only the grid samples of the new frame are taken, and the full plane of frame
+ * N-1, which the chain of the NEXT period reads, is built by that period's warp launch -- it reads the frame anyway -- which
+ * is then enqueued ahead of the period's chain (it uses the previous flow and frames N-2 / N-1, so the order is free).  Saves
+ * the stand-alone plane kernel's re-read of every frame.  Any period that cannot do that (no outputs, diagnostic modes, a
+ * separate hf_batch_calculate_optical_flow / hf_calculate_optical_flow call) builds the missing plane with the stand-alone
+ * kernel first.  Side effect: m_ofcCalcTime of the members then includes the warp launch.  HF_FLAG_BATCH_EAGER_PLANES on the
+ * leader turns it off. */
 int hf_batch_run_period(hf_batch* batch, const void* const* device_frames, int calculate_flow, const int* n_out, const float* t,
                         void* const* device_out, int mode);
+/* 1: hf_batch_run_period defers the phase planes of this batch (see above); 0: it builds them eagerly. */
+int hf_batch_defers_planes(const hf_batch* batch);
 int hf_batch_sync(hf_batch* batch);   /* hf_sync() of every member */
 int hf_batch_size(const hf_batch* batch);
 const char* hf_batch_last_error(const hf_batch* batch);   /* batch == NULL: error of the last failed hf_batch_create (per thread) */
@@ -243,6 +256,10 @@ int hf_read_offsets(hf_ctx* ctx, int16_t* host_out);
 /* m_blurredOffsetArray[idx]: idx 0 = flow consumed by warpFrames, 1 = newest (opticalFlowCalcSDR.cpp:121-123) */
 int hf_read_blurred_flow(hf_ctx* ctx, int idx, int16_t* host_out);
 int hf_write_blurred_flow(hf_ctx* ctx, int idx, const int16_t* host_in);
+/* This build's phase plane of ring frame ring_slot (0 = N-2, 1 = N-1, 2 = N; hf_stats.phase_plane_bytes bytes; the re-laid top-8-bit
+ * copy of a frame that replaces the strided sampling of calcDeltaSumsKernelSDR.h:78-100).  *complete = 0: the
+ * plane holds only its grid samples so far (deferred build, hf_batch_run_period). */
+int hf_read_phase_plane(hf_ctx* ctx, int ring_slot, void* host_out, int* complete);
 
 /* v_rcp_f32 of the device for n <= 32 values.  The reference's apply_levels* divide through it when
  * built by AMD OpenCL (x / y -> x * rcp(y)); CPU checkers use this to reproduce levels bit-exactly. */

@@ -17,6 +17,7 @@ for a, b in pairs:
     else:
         print("MISSING", a)
 frame_bytes = {"hdr2160_24to120": 3840 * 2160 * 3, "sdr1080_24to60": 1920 * 1080 * 3 // 2}   # P010 / NV12 output frame
+outputs_per_period = {"hdr2160_24to120": 417083 / 83333, "sdr1080_24to60": 417083 / 166667}     # source / target frame time (HopperRender.cpp:162-163)
 
 
 def reduce_rows(path, counter, keep):
@@ -26,7 +27,7 @@ def reduce_rows(path, counter, keep):
 
 for wl in ("hdr2160_24to120", "sdr1080_24to60"):
     for kind, prefix, keep, extra in (("warp_period", "pmc", lambda n: "::warp_" in n, []),
-                                      ("pipeline", "pmcpipe", lambda n: "hf::" in n, ["--pipeline", "--batch", "16"])):
+                                      ("pipeline", "pmcpipe", lambda n: "hf::" in n, ["--pipeline", "--batch", "16", "--outputs-per-period", "%.5f" % outputs_per_period[wl]])):
         files = []
         for c in ("FETCH_SIZE", "WRITE_SIZE"):
             p = os.path.join(src, f"{prefix}_{wl}_{c}", "p_counter_collection.csv")

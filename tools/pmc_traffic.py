@@ -56,7 +56,9 @@ def pipeline_entry(a):
         raise SystemExit("no %s dispatches" % a.kernel)
     warp = max(warp, key=lambda n: sum(wb[n]))
     periods_w, periods_f = len(wb[warp]) * a.batch, len(fb[warp]) * a.batch      # pair-periods seen by each pass
-    frames_per_pair_period = sum(wb[warp]) * 1024 / a.frame_bytes / periods_w
+    # output frames per pair and period: the workload's schedule (source / target frame time) when given -- the warp launch may also
+    # write the phase planes of a frame (deferred build), so its WRITE_SIZE is not only output frames
+    frames_per_pair_period = a.outputs_per_period if a.outputs_per_period > 0 else sum(wb[warp]) * 1024 / a.frame_bytes / periods_w
     per_kernel_bytes, total = {}, 0.0
     for name in sorted(set(fb) | set(wb)):
         rd = 2 * sum(fb.get(name, [])) * 1024 / periods_f                          # FETCH_SIZE x 2 (gfx950 note), KiB -> bytes
@@ -89,6 +91,7 @@ def main():
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "roofline_traffic.json"))
     ap.add_argument("--kernel", default="::warp_", help="substring of the dominant kernel's name (warp_fast_kernel / warp_wg_kernel)")
     ap.add_argument("--units-per-launch", type=float, default=0.0, help="output frames of the launches selected (0: take it from --frames-by-write)")
+    ap.add_argument("--outputs-per-period", type=float, default=0.0, help="--pipeline: output frames per pair and source period of the workload's schedule")
     ap.add_argument("--frame-bytes", type=int, default=0, help="bytes of one output frame: units per launch = WRITE_SIZE / frame bytes")
     a = ap.parse_args()
     if a.pipeline:
