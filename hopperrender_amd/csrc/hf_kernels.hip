@@ -1020,6 +1020,10 @@ __device__ __forceinline__ void warp_wg_body(const Geom& g, const WarpArgs& a, c
     // ---- phase C: every output from LDS.  Address of a run's first dword in its window: ((row - ymin) C - cmin) 16 + (offset & ~3)
     const Levels lv = make_levels(a.black, a.white);
     using Src = WarpSrc<E, VEC, ROWS, 1>;
+    // (Dword reads at the lanes' 16-byte stride hit 8 of the 32 banks of the 4-byte read mode: SQ_LDS_BANK_CONFLICT is 72 % of the
+    // kernel's LDS cycles, the LDS array 42 % busy.  Three conflict-poor ds_read_b64 from the 8-byte-aligned address below the run
+    // + one v_cndmask per dword were measured SLOWER -- 698-706 vs 675 us per 16-member launch, 76.4-76.9 vs 77.5 k frames/s: the
+    // conflicts hide behind the other waves, the five selects per run do not.)
     auto lds_run = [&](const unsigned char* p8, const unsigned off, const unsigned odd) {
         const uint32_t* p = (const uint32_t*)p8;
         uint32_t w[NDW + 1];
