@@ -1072,6 +1072,7 @@ __host__ __device__ __forceinline__ int wg_blocks_per_member(int wpr, int yb, in
     return (wpr * 3 + plane_blocks) * wg_super_rows(yb, ub);
 }
 
+// (88 VGPRs = 5 waves per SIMD; amdgpu_waves_per_eu(6) = 80 VGPRs + 16 spilled: 77.4-77.8 vs 78.0-78.2 k frames/s -- not kept)
 template <typename E, int MODE, int NW>
 __global__ __launch_bounds__(64 * NW) void warp_wg_kernel(const Geom g, const WarpBatchArgs batch, int y_groups, const PlaneOut po) {
     constexpr int VEC = 16 / (int)sizeof(E), ROWS = 2;
