@@ -20,7 +20,7 @@ def _upload(frames):
     return out
 
 
-def _run(cls, H, W, flags, frames_dev, n, schedule, ts_by_member, dt, R=16):
+def _run(cls, H, W, flags, frames_dev, n, schedule, ts_by_member, dt, R=16, check=None):
     """One batch of n members through hf_batch_run_period following `schedule` = [(with_outputs, mode, separate_calls)] per frame;
     returns per period: planes (slot 1) + completeness, blurred flows, deltas, outputs."""
     from hopperrender_amd.calc import DeviceBuffer, FlowBatch
@@ -44,6 +44,10 @@ def _run(cls, H, W, flags, frames_dev, n, schedule, ts_by_member, dt, R=16):
         rec = {"planes": [], "flows": [], "delta": [], "outs": []}
         for i, m in enumerate(members):
             m.sync()
+            if check is not None and i not in check:
+                for key in rec:
+                    rec[key].append(None)
+                continue
             rec["planes"].append(m.readPhasePlane(1))
             rec["flows"].append(m.readBlurredFlow(1).copy())
             rec["delta"].append(m.m_totalFrameDelta)
@@ -122,3 +126,29 @@ def test_deferral_is_taken_and_reported(native_lib):  # noqa
             m.close()
         for d in dev:
             d.free()
+
+
+def test_deferred_planes_in_a_batch_of_20(native_lib):
+    """20 members = a warp launch of 16 (staged kernel, builds the planes) + one of 4 (too few waves for the staged kernel: those
+    members' planes come from the plane kernel): both kinds in one batch, same results as the eager batch."""
+    from hopperrender_amd import capi, synth
+    from hopperrender_amd.calc import OpticalFlowCalcHDR
+    H, W, n = 2160, 3840, 20
+    sc = synth.Scene(H, W, True, 31)
+    dev = _upload([sc.frame(k) for k in range(4)])
+    ts = [[0.0, 0.1988, 0.3996, 0.5984, 0.7992] for _ in range(n)]
+    schedule = [(False, 2, False), (True, 2, False), (True, 2, False), (True, 2, False)]
+    check = (0, 15, 16, 19)
+    eager = _run(OpticalFlowCalcHDR, H, W, capi.HF_FLAG_ASYNC | capi.HF_FLAG_BATCH_EAGER_PLANES, dev, n, schedule, ts, np.uint16, R=8, check=check)
+    lazy = _run(OpticalFlowCalcHDR, H, W, capi.HF_FLAG_ASYNC, dev, n, schedule, ts, np.uint16, R=8, check=check)
+    for k, (a, b) in enumerate(zip(eager, lazy)):
+        for i in check:
+            if k >= 1:
+                assert b["planes"][i][1], (k, i)
+                assert np.array_equal(a["planes"][i][0], b["planes"][i][0]), (k, i)
+            assert np.array_equal(a["flows"][i], b["flows"][i]), (k, i)
+            assert a["delta"][i] == b["delta"][i], (k, i)
+            for j, (x, y) in enumerate(zip(a["outs"][i], b["outs"][i])):
+                assert np.array_equal(x, y), (k, i, j)
+    for d in dev:
+        d.free()
