@@ -831,6 +831,11 @@ __global__ __launch_bounds__(64 * warp_max_waves(sizeof(E), GROUP, VB)) void war
 #ifndef HF_WARP_WG_CPW
 #define HF_WARP_WG_CPW 192
 #endif
+#ifndef HF_WARP_WG_ROWS
+#define HF_WARP_WG_ROWS 2   // rows per thread in the staged kernel (4: half the waves, HF_WARP_WG / 2 waves per workgroup, same tile; bit-exact,
+                            // alone 672 vs 663 us per 16 members, pipeline 69.4 vs 72.4 k frames/s: the other stream's chain waits longer
+                            // for the fewer, longer waves -- 52 vs 37 us per pair)
+#endif
 constexpr int wg_chunks(int nw) { return nw >= 16 ? nw * 160 : nw * HF_WARP_WG_CPW; }   // 16-byte chunks per source window (12 KB for 4 waves)
 
 typedef unsigned short ushort2w __attribute__((ext_vector_type(2)));
@@ -859,10 +864,10 @@ __device__ __forceinline__ uint32_t wave_pk_mm_u16(uint32_t v) {
     return pk_mm_u16<MAX>(pk_mm_u16<MAX>(r0, r1), pk_mm_u16<MAX>(r2, r3));
 }
 
-template <typename E, int MODE, int CZ, int NW>
+template <typename E, int MODE, int CZ, int NW, int ROWS>
 __device__ __forceinline__ void warp_wg_body(const Geom& g, const WarpArgs& a, const int cy0, const int cx0, const bool lane_valid, const int wave,
                                              unsigned char* const lds, uint32_t (*s_bounds)[4], int* s_state) {
-    constexpr int VEC = 16 / (int)sizeof(E), ROWS = 2, NDW = 4, CHUNKS = wg_chunks(NW), SZ = (int)sizeof(E);
+    constexpr int VEC = 16 / (int)sizeof(E), NDW = 4, CHUNKS = wg_chunks(NW * ROWS / 2), SZ = (int)sizeof(E);
     constexpr bool need_a = MODE != 1, need_b = MODE != 0;
     const int H = g.H, W = g.W, Si = g.in_stride, So = g.out_stride, rs = g.rs, lw = g.lw, lh = g.lh;
     const int dim_y = CZ ? (H >> 1) : H;
@@ -973,18 +978,20 @@ __device__ __forceinline__ void warp_wg_body(const Geom& g, const WarpArgs& a, c
                 for (int k = 1; k < kMaxWarpOutputs; k++) { ra = j == k ? run_a[k] : ra; rb = j == k ? run_b[k] : rb; }
                 if (need_a) {
                     const unsigned off = ra & 0xFFFFu, odd = (odd_ab >> j) & 1u, o = __umul24(ra >> 16, pitch_g) + off;
-                    S.ra[0][0] = get_run_buf<E, VEC, CZ>(rsrcA, o, odd);
-                    S.ra[1][0] = get_run_buf<E, VEC, CZ>(rsrcA, o + pitch_g, odd);
+#pragma unroll
+                    for (int r = 0; r < ROWS; r++) S.ra[r][0] = get_run_buf<E, VEC, CZ>(rsrcA, o + (unsigned)r * pitch_g, odd);
                 }
                 if (need_b) {
                     const unsigned off = rb & 0xFFFFu, odd = (odd_ab >> (8 + j)) & 1u, o = __umul24(rb >> 16, pitch_g) + off;
-                    S.rb[0][0] = get_run_buf<E, VEC, CZ>(rsrcB, o, odd);
-                    S.rb[1][0] = get_run_buf<E, VEC, CZ>(rsrcB, o + pitch_g, odd);
+#pragma unroll
+                    for (int r = 0; r < ROWS; r++) S.rb[r][0] = get_run_buf<E, VEC, CZ>(rsrcB, o + (unsigned)r * pitch_g, odd);
                 }
                 warp_finish<E, VEC, ROWS, MODE, CZ, 16>(S, a.s12v[j], a.s21v[j], (E*)a.outv[j] + out_g, So, ROWS, lvg);
             }
         } else if (lane_valid) {
-            warp_fast_body<E, VEC, ROWS, MODE, CZ, 16, true>(g, a, cy0, cx0, 0, n);
+#pragma unroll
+            for (int r = 0; r < ROWS; r += 2)   // (the generic body takes two rows)
+                if (cy0 + r < dim_y) warp_fast_body<E, VEC, 2, MODE, CZ, 16, true>(g, a, cy0 + r, cx0, 0, n);
         }
         return;
     }
@@ -1042,14 +1049,14 @@ __device__ __forceinline__ void warp_wg_body(const Geom& g, const WarpArgs& a, c
             if (need_a) {
                 const unsigned off = run_a[j] & 0xFFFFu, odd = (odd_ab >> j) & 1u;
                 const unsigned char* p = win_a + __umul24(run_a[j] >> 16, rowb_a) + (off & ~3u);
-                S.ra[0][0] = lds_run(p, off, odd);
-                S.ra[1][0] = lds_run(p + rowb_a, off, odd);
+#pragma unroll
+                for (int r = 0; r < ROWS; r++) S.ra[r][0] = lds_run(p + (unsigned)r * rowb_a, off, odd);
             }
             if (need_b) {
                 const unsigned off = run_b[j] & 0xFFFFu, odd = (odd_ab >> (8 + j)) & 1u;
                 const unsigned char* p = win_b + __umul24(run_b[j] >> 16, rowb_b) + (off & ~3u);
-                S.rb[0][0] = lds_run(p, off, odd);
-                S.rb[1][0] = lds_run(p + rowb_b, off, odd);
+#pragma unroll
+                for (int r = 0; r < ROWS; r++) S.rb[r][0] = lds_run(p + (unsigned)r * rowb_b, off, odd);
             }
             E* __restrict__ out = (E*)a.outv[j] + out_off;
             warp_finish<E, VEC, ROWS, MODE, CZ, 16>(S, a.s12v[j], a.s21v[j], out, So, ROWS, lv);
@@ -1073,9 +1080,10 @@ __host__ __device__ __forceinline__ int wg_blocks_per_member(int wpr, int yb, in
 }
 
 // (88 VGPRs = 5 waves per SIMD; amdgpu_waves_per_eu(6) = 80 VGPRs + 16 spilled: 77.4-77.8 vs 78.0-78.2 k frames/s -- not kept)
-template <typename E, int MODE, int NW>
-__global__ __launch_bounds__(64 * NW) void warp_wg_kernel(const Geom g, const WarpBatchArgs batch, int y_groups, const PlaneOut po) {
-    constexpr int VEC = 16 / (int)sizeof(E), ROWS = 2;
+template <typename E, int MODE, int NW, int ROWS>
+__global__ __launch_bounds__(64 * NW) void warp_wg_kernel(const Geom g, const WarpBatchArgs batch, const PlaneOut po) {
+    constexpr int VEC = 16 / (int)sizeof(E);
+    const int y_groups = (g.H + ROWS - 1) / ROWS;
     extern __shared__ __attribute__((aligned(16))) unsigned char wg_windows[];   // 2 x wg_chunks(NW) x 16 bytes
     __shared__ uint32_t s_bounds[NW][4];
     __shared__ int s_state[NW];
@@ -1115,8 +1123,8 @@ __global__ __launch_bounds__(64 * NW) void warp_wg_kernel(const Geom g, const Wa
     const int cx0 = (tcol * kWarpTX + (lane & (kWarpTX - 1))) * VEC;
     const int rg = trow * kWarpTY + (lane / kWarpTX);
     const bool lane_valid = trow < (chroma ? uv_tiles : y_tiles) && cx0 < g.W && rg < (chroma ? uv_groups : y_groups);
-    if (chroma) warp_wg_body<E, MODE, 1, NW>(g, a, rg * ROWS, cx0, lane_valid, wave, wg_windows, s_bounds, s_state);
-    else warp_wg_body<E, MODE, 0, NW>(g, a, rg * ROWS, cx0, lane_valid, wave, wg_windows, s_bounds, s_state);
+    if (chroma) warp_wg_body<E, MODE, 1, NW, ROWS>(g, a, rg * ROWS, cx0, lane_valid, wave, wg_windows, s_bounds, s_state);
+    else warp_wg_body<E, MODE, 0, NW, ROWS>(g, a, rg * ROWS, cx0, lane_valid, wave, wg_windows, s_bounds, s_state);
 }
 
 template <typename E, int VEC, bool ALIGNED>
@@ -1242,8 +1250,9 @@ static bool launch_warp_fast(const Geom& g, const WarpBatchArgs& b, hipStream_t 
 #define HF_WARP_WG_MIN_WAVES (4 * 8192)
 #endif
     if constexpr (VB == 16) if (group == VEC && dw && out_chunk > 1 && max_out >= 2 && (long)n_tiles * b.n >= HF_WARP_WG_MIN_WAVES) {
-        constexpr int NW = HF_WARP_WG;
-        const int y_tiles_ = (y_groups + kWarpTY - 1) / kWarpTY, uv_tiles_ = (uv_groups + kWarpTY - 1) / kWarpTY;
+        constexpr int WR = HF_WARP_WG_ROWS, NW = HF_WARP_WG * 2 / WR;          // rows per thread, waves per workgroup (tile height HF_WARP_WG x 8 rows)
+        const int y_groups_w = (g.H + WR - 1) / WR, uv_groups_w = ((g.H >> 1) + WR - 1) / WR;
+        const int y_tiles_ = (y_groups_w + kWarpTY - 1) / kWarpTY, uv_tiles_ = (uv_groups_w + kWarpTY - 1) / kWarpTY;
         // deferred phase planes: members that ask for one (plane21) get it from this launch if geometry and alignment allow
         WarpBatchArgs bb = b;
         PlaneOut po{};
@@ -1255,16 +1264,16 @@ static bool launch_warp_fast(const Geom& g, const WarpBatchArgs& b, hipStream_t 
         if (planes_built) for (int m = 0; m < bb.n; m++) planes_built[m] = bb.s[m].plane21 != nullptr;
         if (emit) {
             po.pl = *pl;
-            po.blocks = ((g.lw >> 2) * (2 * NW * kWarpTY * 2) + 64 * NW - 1) / (64 * NW);   // (groups of 4 columns) x (luma rows of a super row) tasks
+            po.blocks = ((g.lw >> 2) * (2 * NW * kWarpTY * WR) + 64 * NW - 1) / (64 * NW);   // (groups of 4 columns) x (luma rows of a super row) tasks
         }
         const int nb = wg_blocks_per_member(wpr, (y_tiles_ + NW - 1) / NW, (uv_tiles_ + NW - 1) / NW, po.blocks);
         const dim3 wg(((nb * b.n + 7) / 8) * 8), wb(64 * NW);
-        const size_t lds_bytes = (size_t)2 * wg_chunks(NW) * 16;
+        const size_t lds_bytes = (size_t)2 * wg_chunks(NW * WR / 2) * 16;
 #define HF_WARP_WG_LAUNCH(M)                                                                                                                  \
         do {                                                                                                                                      \
-            auto kern = warp_wg_kernel<E, M, NW>;                                                                                                 \
+            auto kern = warp_wg_kernel<E, M, NW, WR>;                                                                                                 \
             if (lds_bytes > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);  \
-            hipExtLaunchKernelGGL(kern, wg, wb, lds_bytes, stream, ev0, ev1, 0, g, bb, y_groups, po);                                             \
+            hipExtLaunchKernelGGL(kern, wg, wb, lds_bytes, stream, ev0, ev1, 0, g, bb, po);                                             \
         } while (0)
         if (mode == 0) HF_WARP_WG_LAUNCH(0);
         else if (mode == 1) HF_WARP_WG_LAUNCH(1);
