@@ -288,11 +288,11 @@ static int ensure_older_planes(hf_ctx* const* cs, int n, hipStream_t s) {
         hf_ctx* m = cs[i];
         if (!m->plane_pending[1]) continue;
         pb.frame[pb.n] = m->ring[1]; pb.pp[pb.n] = m->pp[1]; pb.n++;
-        m->plane_pending[1] = false;
     }
     if (pb.n) {
         hf::launch_prep_frames(cs[0]->g, cs[0]->pl, pb, s);
         if (hipGetLastError() != hipSuccess) return HF_ERR_HIP;
+        for (int i = 0; i < n; i++) cs[i]->plane_pending[1] = false;
     }
     return HF_OK;
 }
@@ -947,7 +947,8 @@ int hf_batch_create(hf_ctx* const* members, int n, hf_batch** out) {
         m->batch = b;
     }
     // Deferred phase planes: where the batched period warp is the workgroup-staged kernel it can build the full plane of the frame
-    // it reads anyway (hf_kernels.hip emit_plane_rows); hf_batch_run_period then only samples the grid at update time.
+    // it reads anyway (plane-building workgroups of warp_wg_kernel, hf_kernels.hip); hf_batch_run_period then only samples the grid
+    // at update time.
     b->defer_planes = !l->dual() && !(l->cfg.flags & HF_FLAG_BATCH_EAGER_PLANES) && hf::warp_period_can_build_planes(l->g, l->pl, n);
     for (int i = 0; i < n; i++) b->defer_planes = b->defer_planes && !(members[i]->cfg.flags & HF_FLAG_NO_FUSED_WARP);
     *out = b;
@@ -1230,7 +1231,9 @@ int hf_batch_run_period(hf_batch* b, const void* const* device_frames, int calcu
     if (n_out && calculate_flow && b->defer_planes && mode >= 0 && mode <= 2) {
         bool pending = false;
         for (hf_ctx* m : b->members) pending = pending || m->plane_pending[1];
-        if (pending) if (int rc = batch_interpolate(b, n_out, t, device_out, mode, true, &warped)) return rc;
+        // (an error from this early attempt is not reported here: if nothing was enqueued the period takes the usual order below,
+        //  which reports the same error where the three separate calls would -- after the update and the chain)
+        if (pending) if (int rc = batch_interpolate(b, n_out, t, device_out, mode, true, &warped)) { if (warped) return rc; }
     }
     if (calculate_flow) if (int rc = hf_batch_calculate_optical_flow(b)) return rc;
     if (n_out && !warped) if (int rc = hf_batch_interpolate_period(b, n_out, t, device_out, mode)) return rc;

@@ -152,3 +152,46 @@ def test_deferred_planes_in_a_batch_of_20(native_lib):
                 assert np.array_equal(x, y), (k, i, j)
     for d in dev:
         d.free()
+
+
+def test_error_behaviour_is_that_of_the_three_calls(native_lib):
+    """A period with an invalid blending scalar (> 1: opticalFlowCalcSDR.cpp:143-146) fails in hf_batch_run_period AFTER its update and
+    its chain have been enqueued -- as with the three separate calls -- also on a batch that defers its planes and would issue the
+    warps first: the flow of the failed period exists, and the following period equals the eager batch's."""
+    from hopperrender_amd import capi, synth
+    from hopperrender_amd.calc import DeviceBuffer, FlowBatch, OpticalFlowCalcHDR
+    H, W, n = 2160, 3840, 4
+    sc = synth.Scene(H, W, True, 13)
+    dev = _upload([sc.frame(k) for k in range(4)])
+    good, bad = [0.0, 0.25, 0.5, 0.75], [0.0, 0.25, 1.5, 0.75]
+    results = []
+    for flags in (capi.HF_FLAG_ASYNC | capi.HF_FLAG_BATCH_EAGER_PLANES, capi.HF_FLAG_ASYNC):
+        members = [OpticalFlowCalcHDR(H, W, search_radius=8, flags=flags) for _ in range(n)]
+        batch = FlowBatch(members)
+        outs = [[DeviceBuffer(members[0].output_frame_bytes) for _ in good] for _ in range(n)]
+        optr = [[b.ptr for b in o] for o in outs]
+        batch.runPeriod(batch.preparePeriod([dev[0].ptr] * n, None, None, calculate_flow=False))
+        batch.runPeriod(batch.preparePeriod([dev[1].ptr] * n, [good] * n, optr, 2))
+        with pytest.raises(capi.HopperFlowError):
+            batch.runPeriod(batch.preparePeriod([dev[2].ptr] * n, [good] * (n - 1) + [bad], optr, 2))
+        batch.sync()
+        flow_after_error = [m.readBlurredFlow(1).copy() for m in members]
+        batch.runPeriod(batch.preparePeriod([dev[3].ptr] * n, [good] * n, optr, 2))
+        batch.sync()
+        results.append((flow_after_error, [m.readBlurredFlow(1).copy() for m in members], [m.m_totalFrameDelta for m in members],
+                        [[b.download(np.uint16).copy() for b in o] for o in outs]))
+        batch.close()
+        for m in members:
+            m.close()
+        for o in outs:
+            for b in o:
+                b.free()
+    (fe_a, f_a, d_a, o_a), (fe_b, f_b, d_b, o_b) = results
+    assert d_a == d_b
+    for i in range(n):
+        assert fe_a[i].any(), i                                  # the failed period's chain did run
+        assert np.array_equal(fe_a[i], fe_b[i]) and np.array_equal(f_a[i], f_b[i]), i
+        for x, y in zip(o_a[i], o_b[i]):
+            assert np.array_equal(x, y), i
+    for d in dev:
+        d.free()
