@@ -60,7 +60,17 @@ TOTAL_PAIRS = {"sdr1080_64pairs": 64}                                           
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 # the dominant kernel of the batched pipeline: 2160p HDR (one flow cell per 16-byte thread) runs the LDS-staged period warp
 # (one window per workgroup of 4 wave tiles), 1080p SDR the global-path kernel
-WARP_SYMBOL = {1: "warp_wg_kernel<unsigned short, 2, 4>", 0: "warp_fast_kernel<unsigned char, 4, 2, 2, 8, true>"}
+# (template prefix: the full symbol -- waves per workgroup, rows per thread -- is read from the shipped binary, see warp_symbol())
+WARP_SYMBOL_PREFIX = {1: "warp_wg_kernel<unsigned short, 2,", 0: "warp_fast_kernel<unsigned char, 4, 2, 2, 8, true>"}
+# the other BASELINE configs, run as short legs behind the timed region of the default workload (fresh child processes, never `value`)
+OTHER_WORKLOADS = {"sdr1080_24to60": 24, "sdr1080_64pairs": 24, "hdr2160_nb10_blur32": 8}   # name: steps (about 1 s timed each)
+
+
+def warp_symbol(hdr):
+    """Name of the dominant kernel as `rocprofv3 --kernel-trace` prints it, taken from the symbol table of the library this process
+    loaded (nm -C), so that the bench line can never name a kernel the binary does not contain."""
+    from hopperrender_amd import capi
+    return capi.kernel_symbol(WARP_SYMBOL_PREFIX[hdr])
 
 
 def parse_args():
@@ -99,6 +109,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference", action="store_true")
     ap.add_argument("--no-host-io", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true", help="skip the short legs of the other BASELINE configs behind the default workload")
     ap.add_argument("--cpu-sample-pairs", type=int, default=8)
     return ap.parse_args()
 
@@ -190,6 +201,28 @@ def host_io_block(hdr, H, W, target, n_periods=24, device=0, async_only=False):
     res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     res["note"] = (f"one context, {n_periods} source periods, frames enter and leave through host memory (PCIe Gen5 x16), every output "
                    "frame returned to the host; child process; never the bench `value`")
+    return res
+
+
+def other_workloads(a):
+    """BASELINE configs 2, 4 and 5 as ~1 s legs of this same script in fresh child processes (their own HIP runtime and hardware
+    queues), AFTER the timed region of the default workload: what the driver's one bench line would otherwise never show.  Reported
+    next to `value`, never part of it."""
+    import subprocess
+    res = {}
+    for name, steps in OTHER_WORKLOADS.items():
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", name, "--steps", str(steps), "--warmup", "2", "--radius", str(a.radius),
+               "--no-cpu-baseline", "--no-reference", "--no-host-io", "--no-other-workloads"]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+            d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+            roof = d["roofline"]
+            res[name] = {"value": d["value"], "unit": d["unit"], "frac": roof["frac"], "frac_algorithmic": roof["frac_algorithmic"],
+                         "ms_per_flow_calc": d["ms_per_flow_calc"], "timed_region_s": d["timed_region_s"], "steps": d["steps"],
+                         "pair_streams": d["config"]["pair_streams_total"], "flow_batch": d["config"]["flow_batch"],
+                         "kernel": roof["kernel"], "bytes_per_output_frame": roof["traffic_pipeline"]["hbm_bytes_per_output_frame"]}
+        except Exception as e:
+            res[name] = {"error": repr(e)[:300]}
     return res
 
 
@@ -376,6 +409,10 @@ def main():
 
     if not pg_done:
         init_dist()
+    rank_devices = [dev_index]
+    if world > 1:     # which device every rank opened (rank r -> r % device_count): part of the line, checked by the multi-rank tests
+        rank_devices = [None] * world
+        dist.all_gather_object(rank_devices, dev_index)
     for k in range(a.warmup):
         run_step(k)
     sync_all()
@@ -511,7 +548,7 @@ def main():
                 "algorithmic_definition": "SURVEY.md 8(d): frames/s per GPU x B_out, B_out = 3F + 4N bytes per output frame",
                 "algorithmic_bytes_per_unit": b_out,
                 "traffic": None, "traffic_note": None,
-                "kernel": WARP_SYMBOL[hdr]}
+                "kernel": warp_symbol(hdr)}
         # HBM bytes of ONE launch of the dominant kernel as the pipeline issues it (a.batch members): PMC pass over the pipeline, else
         # the pass over single-member launches
         per_k = (pipe.get("per_kernel_bytes_per_pair_and_period") or {})
@@ -570,7 +607,7 @@ def main():
                        "delta_scalar": 8, "neighbor_scalar": a.neighbor, "blur_radius": a.blur_radius,
                        "pair_streams_per_gpu": a.streams, "pair_streams_total": a.streams * n_gpus,
                        "host_calls_per_batch_and_period": 1 if one_call else 3, "flow_batch": a.batch, "batch_streams_per_gpu": a.streams // a.batch,
-                       "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                       "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "rank_devices": rank_devices, "device_count": torch.cuda.device_count(),
                        "launches_per_batch_and_period": ("1 phase-plane build + 12-launch chain graph + 1 fused warp" if a.eager_planes or not deferred_planes else "1 grid-sample launch + 1 fused warp (also builds the phase planes of frame N-1) + 12-launch chain graph") if (batches or a.batch > 1) and not a.member_warps else "per member",
                        "source_frames": "copied into the ring" if a.copy_in else "referenced in place (zero-copy)",
                        "source_periods_per_step": a.streams * P, "source_periods_per_stream_and_step": P,
@@ -592,6 +629,8 @@ def main():
                 "errors": [r.get("error") for r in host_io_ranks if r and "error" in r],
                 "note": "every rank at the same time: one asynchronous context per GPU (child process), pinned host buffers, H2D / D2H on side "
                         "streams, every output frame returned to the host (PCIe-inclusive; never the bench `value`)"}
+        if world == 1 and a.workload == "hdr2160_24to120" and not a.no_other_workloads:
+            out["other_workloads"] = other_workloads(a)
         if not a.no_host_io and world == 1:
             try:
                 out["host_io"] = host_io_block(hdr, H, W, target)

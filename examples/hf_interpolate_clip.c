@@ -45,9 +45,18 @@ static int worker(const char* in, const char* out, int W, int H, int hdr, int64_
     hf_timeline_chunk ch;
     if (hf_shard_timeline(n_frames, world, rank, src_t, tgt_t, 3, 12, &ch, NULL, NULL, 0)) { fprintf(stderr, "%s\n", hf_hostio_last_error(NULL)); return 1; }
     if (ch.n_periods == 0) return 0;
-    int32_t* n_out = (int32_t*)malloc(sizeof(int32_t) * (size_t)ch.n_periods);
-    float* t = (float*)malloc(sizeof(float) * (size_t)(ch.n_outputs ? ch.n_outputs : 1));
-    if (hf_shard_timeline(n_frames, world, rank, src_t, tgt_t, 3, 12, &ch, n_out, t, ch.n_outputs)) return 1;
+    /* everything that can fail without a GPU comes first; one exit path releases whatever exists */
+    int rc = 1;
+    int32_t* n_out = NULL;
+    float* t = NULL;
+    hf_ctx* ctx = NULL;
+    hf_hostio* hio = NULL;
+    Io io = {open(in, O_RDONLY), open(out, O_WRONLY), (size_t)W * (size_t)H * 3 / 2 * (hdr ? 2 : 1), ch.first_output, 0};
+    if (io.fd_in < 0 || io.fd_out < 0) { perror("open"); goto done; }
+    n_out = (int32_t*)malloc(sizeof(int32_t) * (size_t)ch.n_periods);
+    t = (float*)malloc(sizeof(float) * (size_t)(ch.n_outputs ? ch.n_outputs : 1));
+    if (!n_out || !t) { perror("malloc"); goto done; }
+    if (hf_shard_timeline(n_frames, world, rank, src_t, tgt_t, 3, 12, &ch, n_out, t, ch.n_outputs)) { fprintf(stderr, "%s\n", hf_hostio_last_error(NULL)); goto done; }
 
     hf_config cfg;
     memset(&cfg, 0, sizeof(cfg));
@@ -57,30 +66,28 @@ static int worker(const char* in, const char* out, int W, int H, int hdr, int64_
     cfg.device_index = rank % (hf_device_count() > 0 ? hf_device_count() : 1);
     cfg.search_radius = radius;
     cfg.flags = HF_FLAG_ASYNC | HF_FLAG_DUAL_STREAM;
-    hf_ctx* ctx = NULL;
-    if (hf_create(&cfg, &ctx)) { fprintf(stderr, "rank %d: %s\n", rank, hf_last_error(NULL)); return 1; }
+    if (hf_create(&cfg, &ctx)) { fprintf(stderr, "rank %d: %s\n", rank, hf_last_error(NULL)); goto done; }
     hf_hostio_config hc;
     memset(&hc, 0, sizeof(hc));
     hc.struct_size = sizeof(hc);
     hc.frame_output_mode = HF_MODE_BLENDED_FRAME;
     hc.scene_change_threshold = threshold;
     hc.source_frame_time = src_t; hc.target_frame_time = tgt_t;
-    hf_hostio* hio = NULL;
-    if (hf_hostio_create(ctx, &hc, &hio)) { fprintf(stderr, "rank %d: %s\n", rank, hf_hostio_last_error(NULL)); return 1; }
-    Io io = {open(in, O_RDONLY), open(out, O_WRONLY), (size_t)W * (size_t)H * 3 / 2 * (hdr ? 2 : 1), ch.first_output, 0};
-    if (io.fd_in < 0 || io.fd_out < 0) { perror("open"); return 1; }
-    const int rc = hf_hostio_run(hio, &ch, n_out, t, fill, sink, &io, NULL);
+    if (hf_hostio_create(ctx, &hc, &hio)) { fprintf(stderr, "rank %d: %s\n", rank, hf_hostio_last_error(NULL)); goto done; }
+    rc = hf_hostio_run(hio, &ch, n_out, t, fill, sink, &io, NULL) ? 1 : 0;
     if (rc) fprintf(stderr, "rank %d: %s\n", rank, hf_hostio_last_error(hio));
     uint64_t bi = 0, bo = 0;
     hf_hostio_get_traffic(hio, &bi, &bo);
     fprintf(stderr, "rank %d/%d device %d: source periods %lld..%lld (+%lld warm-up frames) -> %lld output frames from #%lld (%d copies), %.1f MB up, %.1f MB down\n",
             rank, world, hf_get_device(ctx), (long long)ch.first_period, (long long)(ch.first_period + ch.n_periods - 1),
             (long long)(ch.first_period - ch.first_frame), (long long)ch.n_outputs, (long long)ch.first_output, io.copies, bi / 1e6, bo / 1e6);
-    hf_hostio_destroy(hio);
-    hf_destroy(ctx);
-    close(io.fd_in); close(io.fd_out);
+done:
+    if (hio) hf_hostio_destroy(hio);
+    if (ctx) hf_destroy(ctx);
+    if (io.fd_in >= 0) close(io.fd_in);
+    if (io.fd_out >= 0) close(io.fd_out);
     free(n_out); free(t);
-    return rc ? 1 : 0;
+    return rc;
 }
 
 int main(int argc, char** argv) {

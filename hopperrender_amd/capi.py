@@ -187,6 +187,23 @@ def load():
     return _lib
 
 
+def kernel_symbol(prefix, path=None):
+    """The one kernel of the library whose demangled name contains `prefix`, as rocprofv3's kernel trace spells it up to the closing
+    '>' of its template arguments (e.g. 'warp_wg_kernel<unsigned short, 2, 4, 2>'), read from the library's symbol table with `nm -C`
+    (HIP keeps a handle symbol of that name per __global__ function).  Raises unless exactly one kernel matches."""
+    import subprocess
+    out = subprocess.run(["nm", "-C", path or lib_path()], capture_output=True, text=True, check=True).stdout
+    found = set()
+    for line in out.splitlines():
+        i = line.find("::" + prefix)
+        if i >= 0:
+            name = line[i + 2:]
+            found.add(name[:name.index("(")] if "(" in name else name)
+    if len(found) != 1:
+        raise RuntimeError(f"kernel symbol '{prefix}': {len(found)} matches in {path or lib_path()}: {sorted(found)[:4]}")
+    return found.pop()
+
+
 class HopperFlowError(RuntimeError):
     """Mirror of the reference's std::runtime_error (opticalFlowCalc.h:15-22); .code = hf_status."""
 

@@ -1011,17 +1011,26 @@ static int batch_update(hf_batch* b, const void* const* device_frames, bool defe
     return HF_OK;
 }
 
+// What hf_batch_calculate_optical_flow checks before it enqueues anything: valid flow parameters, equal in all members.
+static int batch_check_flow_params(hf_batch* b) {
+    hf_ctx* l = b->members[0];
+    for (hf_ctx* m : b->members) {
+        if (int rc = check_flow_params(m)) return batch_fail(b, rc, m->err);
+        if (m->p.search_radius != l->p.search_radius || m->p.delta_scalar != l->p.delta_scalar || m->p.neighbor_scalar != l->p.neighbor_scalar)
+            return batch_fail(b, HF_ERR_INVALID_ARGUMENT, "hf_batch_calculate_optical_flow: members differ in search radius / delta / neighbor scalar");
+    }
+    return HF_OK;
+}
+
 int hf_batch_calculate_optical_flow(hf_batch* b) {
     if (!b) return batch_fail(nullptr, HF_ERR_INVALID_ARGUMENT, "null batch");
     hf_ctx* l = b->members[0];
     const int n = (int)b->members.size();
     if (hipSetDevice(l->device) != hipSuccess) return batch_fail(b, HF_ERR_HIP, "hipSetDevice failed");
+    if (int rc = batch_check_flow_params(b)) return rc;
     std::vector<int> key = {l->p.search_radius, l->p.delta_scalar, l->p.neighbor_scalar};
     for (hf_ctx* m : b->members) {
         if (int rc = leave_warp_stream(m)) return batch_fail(b, rc, m->err);
-        if (int rc = check_flow_params(m)) return batch_fail(b, rc, m->err);
-        if (m->p.search_radius != l->p.search_radius || m->p.delta_scalar != l->p.delta_scalar || m->p.neighbor_scalar != l->p.neighbor_scalar)
-            return batch_fail(b, HF_ERR_INVALID_ARGUMENT, "hf_batch_calculate_optical_flow: members differ in search radius / delta / neighbor scalar");
         key.push_back(m->ring_phase * 2 + m->blur_phase);
     }
     if (ensure_older_planes(b->members.data(), n, b->stream)) return batch_fail(b, HF_ERR_HIP, "phase-plane launch failed");
@@ -1207,9 +1216,9 @@ static int batch_interpolate(hf_batch* b, const int* n_out, const float* t, void
         if (hf::launch_warp_periods(l->g, n, periods, mode, b->stream, span >= 0 ? l->spans[span].b : nullptr, span >= 0 ? l->spans[span].e : nullptr,
                                     before_chain ? &l->pl : nullptr, built)) {
             if (span >= 0) { int f = 0; for (int m = 0; m < n; m++) f += n_out[m]; l->spans[span].frames = f; }
+            if (launched) *launched = true;   // from here on the period's warps are enqueued: an error is final, never a reason to issue them again
             if (hipGetLastError() != hipSuccess) return batch_fail(b, HF_ERR_HIP, "fused warp launch failed");
             for (int m = 0; m < n; m++) if (built[m]) b->members[m]->plane_pending[1] = false;
-            if (launched) *launched = true;
             return HF_OK;
         }
         if (span >= 0) { l->ev_pool.push_back(l->spans[span].b); l->ev_pool.push_back(l->spans[span].e); l->spans.pop_back(); }
@@ -1229,10 +1238,14 @@ int hf_batch_run_period(hf_batch* b, const void* const* device_frames, int calcu
     // this period's chain) and lets that launch build the plane; same results as the order of the three calls.
     bool warped = false;
     if (n_out && calculate_flow && b->defer_planes && mode >= 0 && mode <= 2) {
+        // The early warps must not write the caller's output buffers in a period whose flow calculation is going to be refused: the three
+        // separate calls would have stopped at the chain, before any warp.  So the chain's own argument checks come first.
+        if (int rc = batch_check_flow_params(b)) return rc;
         bool pending = false;
         for (hf_ctx* m : b->members) pending = pending || m->plane_pending[1];
-        // (an error from this early attempt is not reported here: if nothing was enqueued the period takes the usual order below,
-        //  which reports the same error where the three separate calls would -- after the update and the chain)
+        // (an argument error of this early attempt -- nothing enqueued, `warped` false -- is not reported here: the period then takes the usual
+        //  order below, which reports the same error where the three separate calls would, after the update and the chain; a launch that was
+        //  enqueued and failed is reported at once)
         if (pending) if (int rc = batch_interpolate(b, n_out, t, device_out, mode, true, &warped)) { if (warped) return rc; }
     }
     if (calculate_flow) if (int rc = hf_batch_calculate_optical_flow(b)) return rc;

@@ -700,9 +700,6 @@ static bool launch_prep_fast(const Geom& g, const PhaseLayout& pl, const PrepBat
 }
 
 void launch_prep_frames(const Geom& g, const PhaseLayout& pl, const PrepBatch& b, hipStream_t stream) {
-#ifdef HF_SW_NOPREP   // STOPWATCH ONLY (wrong results): no phase-plane launches after the first HF_SW_NOPREP batched ones
-    { static int calls = 0; if (b.n > 1 && ++calls > HF_SW_NOPREP) return; }
-#endif
     if (g.hdr ? launch_prep_fast<uint16_t>(g, pl, b, stream) : launch_prep_fast<uint8_t>(g, pl, b, stream)) return;
     const size_t smem = 2 * (size_t)((g.W + 15) / 16) * 16;
     const dim3 grd(g.H, b.n);

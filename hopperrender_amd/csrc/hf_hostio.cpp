@@ -107,7 +107,12 @@ int hf_hostio_create(hf_ctx* ctx, const hf_hostio_config* cfg, hf_hostio** out) 
     hf_hostio* h = new (std::nothrow) hf_hostio();
     if (!h) return hio_fail(nullptr, HF_ERR_OUT_OF_MEMORY, "hf_hostio_create: host allocation failed");
     h->ctx = ctx;
-    if (cfg) h->cfg = *cfg;
+    if (cfg) {
+        h->cfg = *cfg;
+    } else {   // no configuration = the filter's defaults: blended output (m_iFrameOutput, HopperRender.cpp:129), default scene-change threshold
+        h->cfg.frame_output_mode = HF_MODE_BLENDED_FRAME;
+        h->cfg.scene_change_threshold = -1;
+    }
     h->cfg.struct_size = sizeof(hf_hostio_config);
     if (h->cfg.in_ring <= 0) h->cfg.in_ring = 3;
     if (h->cfg.out_ring <= 0) h->cfg.out_ring = 12;

@@ -7,6 +7,24 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Device debug build (`python -m hopperrender_amd.build --debug-bounds` => -DHF_DEBUG_BOUNDS, library libhopperflow_dbg.so): every
+// gather index of the kernels (frame / phase-plane / flow-table / LDS-window reads) is checked against its buffer; a violation prints
+// its site and traps the kernel.  This replaces the GPU AddressSanitizer the pool cannot offer (the reference's
+// own out-of-range case is the single reflection of calcDeltaSumsKernelSDR.h:86-95).  The product build compiles the checks away.
+#ifdef HF_DEBUG_BOUNDS
+#include <stdio.h>
+#define HF_DBG_CHECK(cond, site)                                                                                                   \
+    do {                                                                                                                           \
+        if (!(cond)) {                                                                                                             \
+            printf("[hopperflow] bounds violation: site %d, block %u, thread %u (%s:%d)\n", (int)(site), (unsigned)blockIdx.x,      \
+                   (unsigned)threadIdx.x, __FILE__, __LINE__);                                                                     \
+            __builtin_trap();                                                                                                      \
+        }                                                                                                                          \
+    } while (0)
+#else
+#define HF_DBG_CHECK(cond, site) do { } while (0)
+#endif
+
 namespace hf {
 
 // Geometry shared by all kernels (reference ctor, opticalFlowCalcSDR.cpp:206-222).
@@ -20,7 +38,7 @@ struct Geom {
 };
 
 constexpr int kMaxFlowBatch = 32;      // contexts per hf_batch (FlowBatch below)
-constexpr int kMaxWarpBatch = 16;      // members per fused warp launch (its per-member arguments are 160 bytes; a launch carries 4 KB)
+constexpr int kMaxWarpBatch = 16;      // members per fused warp launch (its per-member arguments are 168 bytes; a launch carries 4 KB)
 constexpr int kMaxWarpOutputs = 6;     // outputs of one source period at 24 -> 120 fps (HopperRender.cpp:944-948)
 
 // Phase-plane layout of a frame (hf_flow.hip).  ONE plane of 4-byte elements, one element per grid column, per pair of

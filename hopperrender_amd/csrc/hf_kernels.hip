@@ -864,88 +864,116 @@ __device__ __forceinline__ uint32_t wave_pk_mm_u16(uint32_t v) {
     return pk_mm_u16<MAX>(pk_mm_u16<MAX>(r0, r1), pk_mm_u16<MAX>(r2, r3));
 }
 
+// Extended coordinates of a staged workgroup.  A run may start up to kExtX elements left of / kExtY rows above the plane (and end as far
+// beyond it): mirrorCoordinate (warpFrameKernelSDR.h:12-20) folds such positions back into the frame, and the window of a workgroup at
+// the frame edge holds the plane EXTENDED that way (ext[y][x] = plane[mirror(y)][mirror(x)]), so that edge tiles read contiguous runs
+// from LDS like every other tile.  All packed (row, byte offset) words carry these biases; kExtX * sizeof(E) is a multiple of 16, so
+// 16-byte chunks of the extended row are 16-byte chunks of the plane row.
+constexpr int kExtX = 64, kExtY = 64;
+constexpr int kWgCells = 64;                       // flow cells of one workgroup tile at most (2160p HDR luma: 16 x 4)
+
+template <int NW>
+struct WgShared {                                  // static LDS of warp_wg_kernel
+    uint2 tab[kMaxWarpOutputs][kWgCells];          // per output and flow cell of the tile: displacement words of source A (x) and B (y)
+    uint32_t bounds[NW][4];                        // per wave: packed min / max of its items' run starts, A then B
+    int state[NW];                                 // per wave: 2 = no tile (past the plane's end), 1 = full tile, 0 = partial tile
+    int item[NW];                                  // per wave: bit 0 = all its items stageable, bit 1 = all of them interior (no mirroring)
+};
+
+constexpr int ilog2c(int v) { return v <= 1 ? 0 : 1 + ilog2c(v >> 1); }
+
 template <typename E, int MODE, int CZ, int NW, int ROWS>
-__device__ __forceinline__ void warp_wg_body(const Geom& g, const WarpArgs& a, const int cy0, const int cx0, const bool lane_valid, const int wave,
-                                             unsigned char* const lds, uint32_t (*s_bounds)[4], int* s_state) {
+__device__ __forceinline__ void warp_wg_body(const Geom& g, const WarpArgs& a, const int tx0, const int ty0, const bool lane_valid, const int wave,
+                                             unsigned char* const lds, WgShared<NW>& sh) {
     constexpr int VEC = 16 / (int)sizeof(E), NDW = 4, CHUNKS = wg_chunks(NW * ROWS / 2), SZ = (int)sizeof(E);
+    constexpr int TW = kWarpTX * VEC, TH = NW * kWarpTY * ROWS, NT = 64 * NW;      // tile of the workgroup (elements x rows), its threads
     constexpr bool need_a = MODE != 1, need_b = MODE != 0;
     const int H = g.H, W = g.W, Si = g.in_stride, So = g.out_stride, rs = g.rs, lw = g.lw, lh = g.lh;
     const int dim_y = CZ ? (H >> 1) : H;
     const int n = a.n_out;
-    const unsigned lane = threadIdx.x & 63u;
+    const unsigned tid = threadIdx.x, lane = tid & 63u;
+    const int cx0 = tx0 + (int)(lane & (kWarpTX - 1)) * VEC, cy0 = ty0 + (wave * kWarpTY + (int)(lane / kWarpTX)) * ROWS;
     const uint64_t valid_mask = __builtin_amdgcn_ballot_w64(lane_valid);
     const bool present = valid_mask != 0, full = valid_mask == ~0ull;          // wave-uniform
 
-    // ---- phase A: the run of every output in each source, computed once -- the same arithmetic as the global path
-    // (warp_fast_body::issue) -- and kept as ONE word: row << 16 | byte offset of the run's first element in its row (rows < 32768;
-    // row bytes < 32768 is a precondition).  Their extremes over outputs are two packed 16-bit min / max per source and output.
-    uint32_t run_a[kMaxWarpOutputs], run_b[kMaxWarpOutputs], odd_ab = 0u;
-    uint32_t lo_a = 0xFFFFFFFFu, hi_a = 0u, lo_b = 0xFFFFFFFFu, hi_b = 0u;
-    bool ok = lane_valid && cy0 + ROWS <= dim_y && cx0 + VEC <= W && (unsigned)Si * (unsigned)SZ < 32768u && dim_y < 32768;
-#pragma unroll
-    for (int j = 0; j < kMaxWarpOutputs; j++) run_a[j] = run_b[j] = 0u;
-    if (full) {
-        const int ly = CZ ? ((cy0 >> rs) << 1) : (cy0 >> rs);
-        const int lx = CZ ? ((cx0 >> rs) & ~1) : (cx0 >> rs);
-        const uint32_t f12 = a.flow_xy[(size_t)ly * lw + lx];
-        const int ox12 = (int)(int16_t)(f12 & 0xFFFFu), oy12 = (int)(int16_t)(f12 >> 16);
-        const int py = clampi(ly - (oy12 >> rs), 0, lh - 1), px = clampi(lx - (ox12 >> rs), 0, lw - 1);
-        const uint32_t f21 = a.flow_xy[(size_t)py * lw + px];
-        const int ox21 = (int)(int16_t)(f21 & 0xFFFFu), oy21 = (int)(int16_t)(f21 >> 16);
-        int neg = 0;                                                            // any coordinate below zero (sign bits collected)
-#pragma unroll
-        for (int j = 0; j < kMaxWarpOutputs; j++) {
-            if (j < n) {
-                const float s12t = a.s12v[j], s21t = a.s21v[j];
-                const int xa = cx0 + (int)roundf((float)ox12 * s12t), xb = cx0 - (int)roundf((float)ox21 * s21t);
-                const int ya = cy0 + (CZ ? (int)roundf((float)oy12 * s12t * 0.5f) : (int)roundf((float)oy12 * s12t));
-                const int yb = cy0 - (CZ ? (int)roundf((float)oy21 * s21t * 0.5f) : (int)roundf((float)oy21 * s21t));
-                if (need_a) {
-                    neg |= xa | ya;
-                    run_a[j] = ((uint32_t)ya << 16) | ((unsigned)(CZ ? (xa & ~1) : xa) * (unsigned)SZ);
-                    lo_a = pk_mm_u16<false>(lo_a, run_a[j]); hi_a = pk_mm_u16<true>(hi_a, run_a[j]);
-                    if (CZ) odd_ab |= ((unsigned)xa & 1u) << j;
+    // ---- phase A, per FLOW CELL instead of per lane.  All lanes of a flow cell share their displacements (a cell is 2^rs luma rows
+    // high and one (luma) or two (chroma: lx & ~1) cells wide; a 16-byte thread lies inside one cell), and a run is
+    //     (row, first byte) = (cy0 + dy, (cx0 + dx) * SZ),
+    // so the workgroup computes ONE displacement word dy << 16 + dx * SZ (+ the parity of dx for chroma) per cell, output and source --
+    // thread t takes cell t % cells and the outputs t / cells, t / cells + threads / cells, ... -- and leaves it in LDS; a lane adds its own
+    // (cy0, cx0) word.  (Round 3 computed all 2 x n runs in every lane: four row-group lanes of a wave repeated the same arithmetic.)
+    const int lcw = rs + CZ;                                                    // log2 of the cell width in elements
+    const int lgx = max(0, ilog2c(TW) - lcw), lgy = max(0, ilog2c(TH) - rs);    // log2 of the cells per tile row / column
+    const int lg = lgx + lgy;
+    const int cw = min(1 << lcw, TW), ch = min(1 << rs, TH);                    // extent of a cell inside the tile
+    uint32_t lo_a = 0xFFFFFFFFu, hi_a = 0u, lo_b = 0xFFFFFFFFu, hi_b = 0u;      // packed row << 16 | byte extremes of the run STARTS (biased)
+    bool it_ok = lg <= ilog2c(kWgCells), it_in = true;
+    {
+        const int cell = (int)tid & ((1 << lg) - 1);
+        const int cell_x0 = tx0 + ((cell & ((1 << lgx) - 1)) << lcw), cell_y0 = ty0 + ((cell >> lgx) << rs);
+        if (it_ok && cell_x0 < W && cell_y0 < dim_y) {                          // (cells past the plane's end belong to waves without a tile)
+            const int ly = min(CZ ? ((cell_y0 >> rs) << 1) : (cell_y0 >> rs), lh - 1);
+            const int lx = min(CZ ? ((cell_x0 >> rs) & ~1) : (cell_x0 >> rs), lw - 1);
+            const uint32_t f12 = a.flow_xy[(size_t)ly * lw + lx];
+            const int ox12 = (int)(int16_t)(f12 & 0xFFFFu), oy12 = (int)(int16_t)(f12 >> 16);
+            const int py = clampi(ly - (oy12 >> rs), 0, lh - 1), px = clampi(lx - (ox12 >> rs), 0, lw - 1);
+            const uint32_t f21 = a.flow_xy[(size_t)py * lw + px];
+            const int ox21 = (int)(int16_t)(f21 & 0xFFFFu), oy21 = (int)(int16_t)(f21 >> 16);
+            // one source of one output: displacement word; extremes of the run starts over the lanes of the cell; stageable? interior?
+            auto item = [&](const int dx, const int dy, uint32_t& lo, uint32_t& hi) -> uint32_t {
+                const int dxe = CZ ? (dx & ~1) : dx;
+                const int x_lo = cell_x0 + dxe, x_hi = x_lo + cw - VEC, y_lo = cell_y0 + dy, y_hi = y_lo + ch - ROWS;
+                const int bx_lo = (x_lo + kExtX) * SZ, bx_hi = (x_hi + kExtX) * SZ, by_lo = y_lo + kExtY, by_hi = y_hi + kExtY;
+                // inside the extended plane (every field of every packed word stays in 16 bits, run tails included); a chroma run that
+                // reaches the RIGHT mirror zone is not stageable: there the element a slot reads depends on the parity of dx, i.e. the
+                // extended chroma row is not a function of the position alone (on the left and for luma it is)
+                bool ok = bx_lo >= 0 && bx_hi + 4 * NDW + 4 <= 0xFFFF && by_lo >= 0 && by_hi + ROWS <= 0xFFFF;
+                if (CZ) ok = ok && x_hi + VEC <= W - 2;
+                it_ok = it_ok && ok;
+                it_in = it_in && x_lo >= 1 && x_hi + VEC - 1 + CZ <= W - 2 && y_lo >= 1 && y_hi + ROWS - 1 <= dim_y - 2;
+                if (ok) {
+                    lo = pk_mm_u16<false>(lo, ((uint32_t)by_lo << 16) | (uint32_t)bx_lo);
+                    hi = pk_mm_u16<true>(hi, ((uint32_t)by_hi << 16) | (uint32_t)bx_hi);
                 }
-                if (need_b) {
-                    neg |= xb | yb;
-                    run_b[j] = ((uint32_t)yb << 16) | ((unsigned)(CZ ? (xb & ~1) : xb) * (unsigned)SZ);
-                    lo_b = pk_mm_u16<false>(lo_b, run_b[j]); hi_b = pk_mm_u16<true>(hi_b, run_b[j]);
-                    if (CZ) odd_ab |= ((unsigned)xb & 1u) << (8 + j);
-                }
+                return (uint32_t)(dy * 65536 + dxe * SZ + (CZ ? (dx & 1) : 0));
+            };
+            for (int j = (int)tid >> lg; j < n; j += NT >> lg) {
+                float s12t = a.s12v[0], s21t = a.s21v[0];                      // (j differs between the lanes of a wave when the tile has < 64 cells)
+#pragma unroll
+                for (int k = 1; k < kMaxWarpOutputs; k++) { s12t = j == k ? a.s12v[k] : s12t; s21t = j == k ? a.s21v[k] : s21t; }
+                uint2 w = make_uint2(0u, 0u);
+                if (need_a) w.x = item((int)roundf((float)ox12 * s12t), CZ ? (int)roundf((float)oy12 * s12t * 0.5f) : (int)roundf((float)oy12 * s12t), lo_a, hi_a);
+                if (need_b) w.y = item(-(int)roundf((float)ox21 * s21t), -(CZ ? (int)roundf((float)oy21 * s21t * 0.5f) : (int)roundf((float)oy21 * s21t)), lo_b, hi_b);
+                sh.tab[j][cell] = w;
             }
         }
-        // mirrorCoordinate is the identity for every run of this lane?  From the extremes (conservative for chroma, whose byte
-        // offset drops the parity of x): 1 <= x, x + VEC - 1 <= W - 2, 1 <= y, y + ROWS - 1 <= dim_y - 2
-        ok = ok && neg >= 0;
-        if (need_a) ok = ok && (int)(lo_a & 0xFFFFu) >= SZ && (int)(hi_a & 0xFFFFu) / SZ + (CZ ? 1 : 0) + VEC - 1 <= W - 2 &&
-                      (int)(lo_a >> 16) >= 1 && (int)(hi_a >> 16) + ROWS - 1 <= dim_y - 2;
-        if (need_b) ok = ok && (int)(lo_b & 0xFFFFu) >= SZ && (int)(hi_b & 0xFFFFu) / SZ + (CZ ? 1 : 0) + VEC - 1 <= W - 2 &&
-                      (int)(lo_b >> 16) >= 1 && (int)(hi_b >> 16) + ROWS - 1 <= dim_y - 2;
     }
-    // wave state: 2 = no tile (past the plane's end), 1 = stageable, 0 = needs the global path (partial wave, edge, mirror zone)
-    const int state = !present ? 2 : (full && __builtin_amdgcn_ballot_w64(!ok) == 0) ? 1 : 0;
-    uint32_t b0 = 0xFFFFFFFFu, b1 = 0u, b2 = 0xFFFFFFFFu, b3 = 0u;              // neutral elements of the packed min / max
-    if (state == 1) {
+    {   // per wave: extremes of its items, and what kind of tile it has
+        const bool ok_all = __builtin_amdgcn_ballot_w64(!it_ok) == 0, in_all = __builtin_amdgcn_ballot_w64(!it_in) == 0;
+        uint32_t b0 = 0xFFFFFFFFu, b1 = 0u, b2 = 0xFFFFFFFFu, b3 = 0u;
         if (need_a) { b0 = wave_pk_mm_u16<false>(lo_a); b1 = wave_pk_mm_u16<true>(hi_a); }
         if (need_b) { b2 = wave_pk_mm_u16<false>(lo_b); b3 = wave_pk_mm_u16<true>(hi_b); }
-    }
-    {   // (selects, not an array indexed by the lane: that would live in scratch memory -- 16 bytes per lane of HBM traffic)
+        // (selects, not an array indexed by the lane: that would live in scratch memory -- 16 bytes per lane of HBM traffic)
         const uint32_t mine = lane == 0 ? b0 : lane == 1 ? b1 : lane == 2 ? b2 : b3;
-        if (lane < 4) s_bounds[wave][lane] = mine;
+        if (lane < 4) sh.bounds[wave][lane] = mine;
+        if (lane == 0) { sh.state[wave] = !present ? 2 : full ? 1 : 0; sh.item[wave] = (ok_all ? 1 : 0) | (in_all ? 2 : 0); }
     }
-    if (lane == 0) s_state[wave] = state;
     __syncthreads();
-    bool wg_ok = true;
+    bool wg_ok = true, wg_in = true;
     uint32_t m0 = 0xFFFFFFFFu, m1 = 0u, m2 = 0xFFFFFFFFu, m3 = 0u;
 #pragma unroll
     for (int w = 0; w < NW; w++) {
-        wg_ok = wg_ok && s_state[w] != 0;
-        m0 = pk_mm_u16<false>(m0, s_bounds[w][0]); m1 = pk_mm_u16<true>(m1, s_bounds[w][1]);
-        m2 = pk_mm_u16<false>(m2, s_bounds[w][2]); m3 = pk_mm_u16<true>(m3, s_bounds[w][3]);
+        wg_ok = wg_ok && sh.state[w] != 0 && (sh.item[w] & 1) != 0;
+        wg_in = wg_in && (sh.item[w] & 2) != 0;
+        m0 = pk_mm_u16<false>(m0, sh.bounds[w][0]); m1 = pk_mm_u16<true>(m1, sh.bounds[w][1]);
+        m2 = pk_mm_u16<false>(m2, sh.bounds[w][2]); m3 = pk_mm_u16<true>(m3, sh.bounds[w][3]);
     }
-    // window of a source: 16-byte chunks [cmin, cmin + C) x rows [ymin, ymin + R); a run spans NDW + 1 dwords from its first byte's
+    const bool runs_ok = __builtin_amdgcn_readfirstlane((int)wg_ok) != 0;       // every wave full or absent, every run inside the extended plane
+    wg_in = __builtin_amdgcn_readfirstlane((int)wg_in) != 0;
+    // window of a source: 16-byte chunks [cmin, cmin + C) x rows [ymin, ymin + R) of the extended plane; a run spans NDW + 1 dwords from
+    // the dword of its first byte
     int cmin_a = 0, ymin_a = 0, C_a = 1, R_a = 0, cmin_b = 0, ymin_b = 0, C_b = 1, R_b = 0;
-    if (wg_ok) {
+    if (runs_ok) {
         const uint32_t la = (uint32_t)__builtin_amdgcn_readfirstlane((int)m0), ha = (uint32_t)__builtin_amdgcn_readfirstlane((int)m1);
         const uint32_t lb = (uint32_t)__builtin_amdgcn_readfirstlane((int)m2), hb = (uint32_t)__builtin_amdgcn_readfirstlane((int)m3);
         if (need_a) {
@@ -960,10 +988,13 @@ __device__ __forceinline__ void warp_wg_body(const Geom& g, const WarpArgs& a, c
         wg_ok = ((R_a * C_a + 63) & ~63) <= CHUNKS && ((R_b * C_b + 63) & ~63) <= CHUNKS && C_a <= 64 && C_b <= 64;
     }
     wg_ok = __builtin_amdgcn_readfirstlane((int)wg_ok) != 0;
+    // this lane's own word and cell: run of output j in source A = base + tab[j][ci].x (row << 16 | byte offset, biased; chroma: bit 0 = dx odd)
+    const uint32_t base = ((uint32_t)(cy0 + kExtY) << 16) | (uint32_t)((cx0 + kExtX) * SZ);
+    const int ci = (((cy0 - ty0) >> rs) << lgx) | ((cx0 - tx0) >> lcw);
     if (!wg_ok) {   // workgroup-uniform: no barrier follows
-        if (state == 1) {
-            // this wave's runs are all interior, only the WORKGROUP's window does not fit (fast or diverging motion): the global
-            // path straight from the runs computed above -- no second displacement pass, no edge tests
+        if (runs_ok && wg_in && full) {
+            // every run of the workgroup is interior, only its window does not fit (fast or diverging motion): the global path straight
+            // from the run table -- no second displacement pass, no edge tests
             const unsigned pitch_g = (unsigned)Si * (unsigned)SZ;
             const unsigned plane_g = (unsigned)dim_y * pitch_g;
             const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)((const E*)a.frame12 + (size_t)CZ * H * Si), 0, (int)plane_g, 0x00020000);
@@ -972,23 +1003,24 @@ __device__ __forceinline__ void warp_wg_body(const Geom& g, const WarpArgs& a, c
             const size_t out_g = (size_t)CZ * H * So + (size_t)cy0 * So + cx0;
             for (int j = 0; j < n; j++) {
                 WarpSrc<E, VEC, ROWS, 1> S;
-                // (run_a / run_b are indexed by the loop counter of a fully unrolled loop elsewhere; here by a select chain)
-                uint32_t ra = run_a[0], rb = run_b[0];
-#pragma unroll
-                for (int k = 1; k < kMaxWarpOutputs; k++) { ra = j == k ? run_a[k] : ra; rb = j == k ? run_b[k] : rb; }
+                const uint2 d = sh.tab[j][ci];
                 if (need_a) {
-                    const unsigned off = ra & 0xFFFFu, odd = (odd_ab >> j) & 1u, o = __umul24(ra >> 16, pitch_g) + off;
+                    const uint32_t w = base + d.x, wb = w & 0xFFFFu, odd = CZ ? (wb & 1u) : 0u;
+                    const unsigned o = __umul24((w >> 16) - kExtY, pitch_g) + (CZ ? (wb & ~1u) : wb) - (unsigned)(kExtX * SZ);
+                    HF_DBG_CHECK((o & ~3u) + 4u * (NDW + 1) + (ROWS - 1) * pitch_g <= plane_g, 10);
 #pragma unroll
                     for (int r = 0; r < ROWS; r++) S.ra[r][0] = get_run_buf<E, VEC, CZ>(rsrcA, o + (unsigned)r * pitch_g, odd);
                 }
                 if (need_b) {
-                    const unsigned off = rb & 0xFFFFu, odd = (odd_ab >> (8 + j)) & 1u, o = __umul24(rb >> 16, pitch_g) + off;
+                    const uint32_t w = base + d.y, wb = w & 0xFFFFu, odd = CZ ? (wb & 1u) : 0u;
+                    const unsigned o = __umul24((w >> 16) - kExtY, pitch_g) + (CZ ? (wb & ~1u) : wb) - (unsigned)(kExtX * SZ);
+                    HF_DBG_CHECK((o & ~3u) + 4u * (NDW + 1) + (ROWS - 1) * pitch_g <= plane_g, 11);
 #pragma unroll
                     for (int r = 0; r < ROWS; r++) S.rb[r][0] = get_run_buf<E, VEC, CZ>(rsrcB, o + (unsigned)r * pitch_g, odd);
                 }
                 warp_finish<E, VEC, ROWS, MODE, CZ, 16>(S, a.s12v[j], a.s21v[j], (E*)a.outv[j] + out_g, So, ROWS, lvg);
             }
-        } else if (lane_valid) {
+        } else if (lane_valid) {   // partial tiles, runs beyond the extended plane, chroma in the right mirror zone: the generic body
 #pragma unroll
             for (int r = 0; r < ROWS; r += 2)   // (the generic body takes two rows)
                 if (cy0 + r < dim_y) warp_fast_body<E, VEC, 2, MODE, CZ, 16, true>(g, a, cy0 + r, cx0, 0, n);
@@ -1005,7 +1037,6 @@ __device__ __forceinline__ void warp_wg_body(const Geom& g, const WarpArgs& a, c
     auto stage = [&](const void* plane, const int cmin, const int ymin, const int C, const int R, unsigned char* const win) {
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(plane), 0, (int)plane_bytes, 0x00020000);
         const unsigned magic = ((1u << 20) + (unsigned)C - 1u) / (unsigned)C;   // q / C == (q * magic) >> 20 for q < 4096, C <= 64 (q * (magic C - 2^20) < 2^20)
-        const unsigned origin = __umul24((unsigned)ymin, pitch_b) + (unsigned)cmin * 16u;
         const int nq = R * C;
 #pragma unroll
         for (int i = 0; i < (CHUNKS + 64 * NW - 1) / (64 * NW); i++) {
@@ -1014,7 +1045,30 @@ __device__ __forceinline__ void warp_wg_body(const Geom& g, const WarpArgs& a, c
                 const unsigned q = (unsigned)q0 + lane;
                 const unsigned row = (q * magic) >> 20, col = q - __umul24(row, (unsigned)C);
                 // (chunks past the window's end land behind it inside the window's LDS share; reads past the plane return 0)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(win + (size_t)q0 * 16), 16, origin + __umul24(row, pitch_b) + col * 16u, 0, 0, 0);
+                if (wg_in) {   // the window lies where mirrorCoordinate is the identity: a rectangle of the plane
+                    const unsigned off = __umul24((unsigned)(ymin - kExtY) + row, pitch_b) + ((unsigned)cmin + col) * 16u - (unsigned)(kExtX * SZ);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(win + (size_t)q0 * 16), 16, off, 0, 0, 0);
+                } else {       // a tile at the frame edge: rows fold back as whole rows; a chunk that touches the left / right mirror zone is
+                               // gathered element by element (a reflected run is reversed) -- once per period, not once per output and row
+                    const int y = mirror_warp_bl(ymin - kExtY + (int)row, dim_y);
+                    const int x0 = (cmin + (int)col) * VEC - kExtX;            // first element of the chunk in its (extended) row
+                    const unsigned rowoff = __umul24((unsigned)y, pitch_b);
+                    const bool zone = x0 < 1 || (!CZ && x0 + VEC - 1 > W - 2);  // (chroma: only runs left of the right zone are staged)
+                    if (!zone) {
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(win + (size_t)q0 * 16), 16, rowoff + (unsigned)(x0 * SZ), 0, 0, 0);
+                    } else {
+                        __attribute__((aligned(16))) E v[VEC];
+#pragma unroll
+                        for (int k = 0; k < VEC; k++) {
+                            const int xs = mirror_warp_bl(x0 + k, W);
+                            const unsigned eo = rowoff + (unsigned)((CZ ? (xs & ~1) + ((x0 + k) & 1) : xs) * SZ);
+                            HF_DBG_CHECK(eo + SZ <= plane_bytes, 12);
+                            if constexpr (SZ == 2) v[k] = (E)__builtin_amdgcn_raw_buffer_load_b16(rsrc, eo, 0, 0);
+                            else v[k] = (E)__builtin_amdgcn_raw_buffer_load_b8(rsrc, eo, 0, 0);
+                        }
+                        *(uint4*)(win + (size_t)q * 16) = *(const uint4*)v;
+                    }
+                }
             }
         }
     };
@@ -1022,7 +1076,7 @@ __device__ __forceinline__ void warp_wg_body(const Geom& g, const WarpArgs& a, c
     if (need_b) stage(B, cmin_b, ymin_b, C_b, R_b, lds + CHUNKS * 16);
     __builtin_amdgcn_s_waitcnt(0x0F70);                                         // vmcnt(0): this wave's share of the windows is in LDS
     __syncthreads();
-    if (state != 1) return;                                                     // a wave without a tile only helped copying
+    if (!full) return;                                                          // a wave without a tile only helped copying
 
     // ---- phase C: every output from LDS.  Address of a run's first dword in its window: ((row - ymin) C - cmin) 16 + (offset & ~3)
     const Levels lv = make_levels(a.black, a.white);
@@ -1046,15 +1100,18 @@ __device__ __forceinline__ void warp_wg_body(const Geom& g, const WarpArgs& a, c
     for (int j = 0; j < kMaxWarpOutputs; j++) {
         if (j < n) {
             Src S;
+            const uint2 d = sh.tab[j][ci];
             if (need_a) {
-                const unsigned off = run_a[j] & 0xFFFFu, odd = (odd_ab >> j) & 1u;
-                const unsigned char* p = win_a + __umul24(run_a[j] >> 16, rowb_a) + (off & ~3u);
+                const uint32_t w = base + d.x, wb = w & 0xFFFFu, odd = CZ ? (wb & 1u) : 0u, off = CZ ? (wb & ~1u) : wb;
+                const unsigned char* p = win_a + __umul24(w >> 16, rowb_a) + (off & ~3u);
+                HF_DBG_CHECK(p >= lds && p + (ROWS - 1) * rowb_a + 4 * NDW + 4 <= lds + CHUNKS * 16, 13);
 #pragma unroll
                 for (int r = 0; r < ROWS; r++) S.ra[r][0] = lds_run(p + (unsigned)r * rowb_a, off, odd);
             }
             if (need_b) {
-                const unsigned off = run_b[j] & 0xFFFFu, odd = (odd_ab >> (8 + j)) & 1u;
-                const unsigned char* p = win_b + __umul24(run_b[j] >> 16, rowb_b) + (off & ~3u);
+                const uint32_t w = base + d.y, wb = w & 0xFFFFu, odd = CZ ? (wb & 1u) : 0u, off = CZ ? (wb & ~1u) : wb;
+                const unsigned char* p = win_b + __umul24(w >> 16, rowb_b) + (off & ~3u);
+                HF_DBG_CHECK(p >= lds + CHUNKS * 16 && p + (ROWS - 1) * rowb_b + 4 * NDW + 4 <= lds + 2 * CHUNKS * 16, 14);
 #pragma unroll
                 for (int r = 0; r < ROWS; r++) S.rb[r][0] = lds_run(p + (unsigned)r * rowb_b, off, odd);
             }
@@ -1080,13 +1137,17 @@ __host__ __device__ __forceinline__ int wg_blocks_per_member(int wpr, int yb, in
 }
 
 // (88 VGPRs = 5 waves per SIMD; amdgpu_waves_per_eu(6) = 80 VGPRs + 16 spilled: 77.4-77.8 vs 78.0-78.2 k frames/s -- not kept)
+#ifdef HF_WARP_WG_WPE   // experiment: force the occupancy (the plane-building and the generic-fallback code need more registers than the staged path)
+#define HF_WG_OCC __attribute__((amdgpu_waves_per_eu(HF_WARP_WG_WPE, HF_WARP_WG_WPE)))
+#else
+#define HF_WG_OCC
+#endif
 template <typename E, int MODE, int NW, int ROWS>
-__global__ __launch_bounds__(64 * NW) void warp_wg_kernel(const Geom g, const WarpBatchArgs batch, const PlaneOut po) {
+__global__ __launch_bounds__(64 * NW) HF_WG_OCC void warp_wg_kernel(const Geom g, const WarpBatchArgs batch, const PlaneOut po) {
     constexpr int VEC = 16 / (int)sizeof(E);
     const int y_groups = (g.H + ROWS - 1) / ROWS;
     extern __shared__ __attribute__((aligned(16))) unsigned char wg_windows[];   // 2 x wg_chunks(NW) x 16 bytes
-    __shared__ uint32_t s_bounds[NW][4];
-    __shared__ int s_state[NW];
+    __shared__ WgShared<NW> sh;
     const int uv_groups = ((g.H >> 1) + ROWS - 1) / ROWS;
     const int wpr = (g.W + kWarpTX * VEC - 1) / (kWarpTX * VEC);
     const int y_tiles = (y_groups + kWarpTY - 1) / kWarpTY, uv_tiles = (uv_groups + kWarpTY - 1) / kWarpTY;
@@ -1120,11 +1181,12 @@ __global__ __launch_bounds__(64 * NW) void warp_wg_kernel(const Geom g, const Wa
     if (brow >= (chroma ? ub : yb)) return;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int trow = brow * NW + wave;
-    const int cx0 = (tcol * kWarpTX + (lane & (kWarpTX - 1))) * VEC;
+    const int tx0 = tcol * kWarpTX * VEC, ty0 = brow * NW * kWarpTY * ROWS;   // origin of the workgroup's tile in its plane
+    const int cx0 = tx0 + (lane & (kWarpTX - 1)) * VEC;
     const int rg = trow * kWarpTY + (lane / kWarpTX);
     const bool lane_valid = trow < (chroma ? uv_tiles : y_tiles) && cx0 < g.W && rg < (chroma ? uv_groups : y_groups);
-    if (chroma) warp_wg_body<E, MODE, 1, NW, ROWS>(g, a, rg * ROWS, cx0, lane_valid, wave, wg_windows, s_bounds, s_state);
-    else warp_wg_body<E, MODE, 0, NW, ROWS>(g, a, rg * ROWS, cx0, lane_valid, wave, wg_windows, s_bounds, s_state);
+    if (chroma) warp_wg_body<E, MODE, 1, NW, ROWS>(g, a, tx0, ty0, lane_valid, wave, wg_windows, sh);
+    else warp_wg_body<E, MODE, 0, NW, ROWS>(g, a, tx0, ty0, lane_valid, wave, wg_windows, sh);
 }
 
 template <typename E, int VEC, bool ALIGNED>

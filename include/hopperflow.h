@@ -361,7 +361,9 @@ typedef struct hf_hostio_config {
 } hf_hostio_config;
 typedef int (*hf_hostio_fill_fn)(void* user, int64_t source_frame_index, void* pinned_frame);              /* 0 = ok */
 typedef int (*hf_hostio_sink_fn)(void* user, int64_t output_index_in_chunk, const void* frame, int32_t kind);   /* kind: 1 warp, 0 copy */
-/* ctx: an HF_FLAG_ASYNC (| HF_FLAG_DUAL_STREAM) context that the driver uses exclusively while it exists. */
+/* ctx: an HF_FLAG_ASYNC (| HF_FLAG_DUAL_STREAM) context that the driver uses exclusively while it exists.
+ * cfg == NULL: the filter's defaults -- rings 3 / 12, BlendedFrame output, DEFAULT_SCENE_CHANGE_THRESHOLD, 23.976 -> 60 fps.  (In a
+ * caller-supplied struct a scene_change_threshold of 0 means what it says: every non-zero frame delta is a scene change.) */
 int hf_hostio_create(hf_ctx* ctx, const hf_hostio_config* cfg, hf_hostio** out);
 void hf_hostio_destroy(hf_hostio* io);
 /* kinds (optional): [chunk->n_outputs] 1 warp / 0 copy per output frame. */

@@ -5,6 +5,8 @@ import os
 import re
 import subprocess
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -93,3 +95,20 @@ def test_cpp_adapter_header_is_self_contained(tmp_path):
     src = tmp_path / "t.cpp"
     src.write_text('#include "opticalFlowCalc.h"\nint main(){ OpticalFlowCalc* p = nullptr; (void)p; return sizeof(OpticalFlowCalcSDR) > 0 ? 0 : 1; }\n')
     subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"), str(src)])
+
+
+def test_bench_names_kernels_the_library_contains():
+    """bench.py prints roofline.kernel for rocprofv3 --kernel-trace to be matched against (the string had drifted from the
+    shipped symbol after a template parameter was added).  The name is read from the binary; exactly one kernel matches each prefix."""
+    import bench
+    from hopperrender_amd import build, capi
+    build.build_all()
+    for hdr, prefix in bench.WARP_SYMBOL_PREFIX.items():
+        name = bench.warp_symbol(hdr)
+        assert name.startswith(prefix) and name.endswith(">") and "(" not in name
+        assert name in subprocess.run(["nm", "-C", capi.lib_path()], capture_output=True, text=True, check=True).stdout
+    with pytest.raises(RuntimeError):
+        capi.kernel_symbol("no_such_kernel<")
+    with pytest.raises(RuntimeError):
+        capi.kernel_symbol("warp_wg_kernel<")          # ambiguous: several instantiations
+    assert set(bench.OTHER_WORKLOADS) < set(bench.WORKLOADS)

@@ -195,3 +195,42 @@ def test_error_behaviour_is_that_of_the_three_calls(native_lib):
             assert np.array_equal(x, y), i
     for d in dev:
         d.free()
+
+
+def test_a_refused_flow_calculation_leaves_the_outputs_untouched(native_lib):
+    """Members whose flow parameters differ make hf_batch_calculate_optical_flow fail (hf_capi: "members differ ...").  With the three
+    separate calls nothing is warped in that period; a plane-deferring hf_batch_run_period issues its warps BEFORE the chain, so it has
+    to make the chain's argument checks first: the caller's output buffers keep their contents."""
+    from hopperrender_amd import capi, synth
+    from hopperrender_amd.calc import DeviceBuffer, FlowBatch, OpticalFlowCalcHDR
+    H, W, n = 2160, 3840, 4
+    sc = synth.Scene(H, W, True, 21)
+    dev = _upload([sc.frame(k) for k in range(3)])
+    ts = [0.0, 0.25, 0.5, 0.75]
+    members = [OpticalFlowCalcHDR(H, W, search_radius=8, flags=capi.HF_FLAG_ASYNC) for _ in range(n)]
+    batch = FlowBatch(members)
+    assert batch.defersPlanes()
+    outs = [[DeviceBuffer(members[0].output_frame_bytes) for _ in ts] for _ in range(n)]
+    marker = np.full(members[0].output_frame_bytes // 2, 0x5A5A, np.uint16)
+    for o in outs:
+        for b in o:
+            b.upload(marker)
+    optr = [[b.ptr for b in o] for o in outs]
+    batch.runPeriod(batch.preparePeriod([dev[0].ptr] * n, None, None, calculate_flow=False))
+    batch.runPeriod(batch.preparePeriod([dev[1].ptr] * n, None, None))
+    members[2].m_opticalFlowSearchRadius = 7                      # the governor of ONE member moved: the batch cannot run one chain for all
+    with pytest.raises(capi.HopperFlowError):
+        batch.runPeriod(batch.preparePeriod([dev[2].ptr] * n, [ts] * n, optr, 2))
+    batch.sync()
+    for i, o in enumerate(outs):
+        for j, b in enumerate(o):
+            assert np.array_equal(b.download(np.uint16), marker), (i, j)
+    members[2].m_opticalFlowSearchRadius = 8                      # and the batch is usable again
+    batch.runPeriod(batch.preparePeriod(None, [ts] * n, optr, 2))
+    batch.sync()
+    assert not np.array_equal(outs[0][1].download(np.uint16), marker)
+    batch.close()
+    for m in members:
+        m.close()
+    for b in dev + [x for o in outs for x in o]:
+        b.free()

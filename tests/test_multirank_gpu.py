@@ -71,3 +71,30 @@ def test_host_io_leg_at_two_ranks():
     assert h["ranks_reporting"] == 2 and not h["errors"]
     assert h["aggregate_frames_per_s"] > 0 and len(h["per_rank_frames_per_s"]) == 2
     assert h["d2h_GB_per_s_per_gpu"] > 0 and h["h2d_GB_per_s_per_gpu"] > 0
+
+
+def test_eight_ranks_share_config_4_on_one_gpu():
+    """BASELINE config 4 in the shape it names -- 64 independent 1080p SDR pairs over 8 ranks = 8 pairs per rank -- as far as ONE GPU
+    allows: eight processes under torch.distributed.run on the single device (gloo reductions).  The job is the same 64 pairs whatever
+    the world size, every rank opens device rank % device_count, and rank 0 prints one line."""
+    one = run_bench([], 1, "sdr1080_64pairs")
+    eight = run_bench([], 8, "sdr1080_64pairs")
+    c = eight["config"]
+    assert eight["n_gpus"] == 8 and eight["scaling"] == "strong"
+    assert c["pair_streams_total"] == 64 and c["pair_streams_per_gpu"] == 8 and c["flow_batch"] == 8
+    assert c["output_frames_total"] == one["config"]["output_frames_total"]
+    assert c["rank_devices"] == [r % c["device_count"] for r in range(8)]
+    assert eight["value"] > 0 and "cpu_baseline" not in eight
+
+
+def test_default_line_carries_the_other_baseline_configs():
+    """The driver sees ONE bench line: behind the timed region of the default workload bench.py runs ~1 s legs of BASELINE configs 2, 4
+    and 5 in child processes and reports them under other_workloads (never part of `value`)."""
+    d = run_bench(["--no-profile"], 1, "hdr2160_24to120")
+    o = d["other_workloads"]
+    assert set(o) == {"sdr1080_24to60", "sdr1080_64pairs", "hdr2160_nb10_blur32"}
+    for name, w in o.items():
+        assert "error" not in w, (name, w)
+        assert w["value"] > 0 and 0 < w["frac"] < 1 and w["frac_algorithmic"] > 0 and w["timed_region_s"] > 0.3, (name, w)
+    assert o["sdr1080_64pairs"]["pair_streams"] == 64 and o["sdr1080_64pairs"]["flow_batch"] == 32
+    assert d["roofline"]["kernel"].startswith("warp_wg_kernel<unsigned short, 2,")

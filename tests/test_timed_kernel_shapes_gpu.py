@@ -1,0 +1,149 @@
+"""GPU: the launch bench.py times -- hf_batch_run_period on a batch that DEFERS its phase planes, i.e. the workgroup-staged
+period warp (warp_wg_kernel, csrc/hf_warp_staged.hip) that also builds the plane of its second source -- in the shapes the other
+staged-path tests leave out (VERDICT r3 "what's weak" 1-2), every output judged by the pinned oracle or the reference's golden SHA,
+never by another HIP launch:
+
+  * padded strides: in_stride 4096 / out_stride 3968 at 3840 x 2160 HDR -- the reason the reference has stride arguments at all
+    (opticalFlowCalcHDR.cpp:20, :279-282); the staged kernel has its own pitch arithmetic and the plane emission its alignment gate;
+  * per-member output levels 16/235 and 0/200 next to the default 0/255 (opticalFlowCalcHDR.cpp:151-152 scales them by 256);
+  * one member whose source frames are only 8-byte aligned: its plane cannot come from the warp launch (16-byte task loads), so that
+    member alone falls back to the plane kernel while the batch keeps deferring;
+  * the deferred path against the reference's own frames (golden SHA of hdr_2160p warp_m2_t0.3996 / t0.7992)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import Golden, sha
+
+pytestmark = pytest.mark.gpu
+
+T5 = [0.1988, 0.3996, 0.5984, 0.7992, 0.998]
+T6 = T5 + [0.0]
+LEVELS = [(0.0, 255.0), (16.0, 235.0), (0.0, 200.0)]
+
+
+def _oracle_rcp(calc, hdr):
+    """The oracle divides through the DEVICE's v_rcp_f32 for the level settings in play (as the reference's OpenCL build does)."""
+    from oracle import oracle
+    s = 256.0 if hdr else 1.0
+    ys = sorted({np.float32((w - b) * s) for b, w in LEVELS} | {np.float32(w * s) for _, w in LEVELS})
+    r = calc.deviceRcp(np.array(ys, np.float32))
+    oracle.set_flavour(1, 1, {float(y): float(x) for y, x in zip(ys, r)})
+
+
+def test_batch_of_16_strided_levels_and_a_misaligned_member(native_lib):
+    from hopperrender_amd import capi, synth
+    from hopperrender_amd.calc import DeviceBuffer, FlowBatch, OpticalFlowCalcHDR
+    from oracle import oracle
+    H, W, SI, SO, n, R = 2160, 3840, 4096, 3968, 16, 16
+    ODD = 5                                                   # the member whose frames sit at base + 8 bytes
+    g = oracle.make_geom(1, H, W, SI, SO)
+    sc = synth.Scene(H, W, True, 2024, in_stride=SI)
+    frames = [sc.frame(k) for k in range(4)]
+    assert frames[0].size == (H + H // 2) * SI
+    dev, dev_odd = [], []
+    for f in frames:
+        b = DeviceBuffer(f.nbytes); b.upload(f); dev.append(b)
+        o = DeviceBuffer(f.nbytes + 64)
+        capi.check(capi.load().hf_memcpy_h2d(0, C.c_void_p(o.ptr + 8), f.ctypes.data_as(C.c_void_p), f.nbytes))
+        dev_odd.append(o)
+    members = [OpticalFlowCalcHDR(H, W, SI, SO, 8, 6, *LEVELS[i % 3], 270, search_radius=R, flags=capi.HF_FLAG_ASYNC | capi.HF_FLAG_NO_TIMING) for i in range(n)]
+    batch = FlowBatch(members)
+    assert batch.defersPlanes()
+    F_out = members[0].output_frame_bytes
+    assert F_out == (H + H // 2) * SO * 2
+    outs = [[DeviceBuffer(F_out) for _ in range(6)] for _ in range(n)]
+    for o in outs:                                            # the padding columns of the output rows must stay untouched
+        for b in o:
+            b.upload(np.full(F_out // 2, 0xA5A5, np.uint16))
+    optr = [[b.ptr for b in o] for o in outs]
+    plans = [(T6[i % 6:] + T6[:i % 6])[:5 + (i % 2)] for i in range(n)]
+    src = lambda k: [(dev_odd[k].ptr + 8) if i == ODD else dev[k].ptr for i in range(n)]
+
+    flows = {}
+    for k in (1, 2):
+        _, flows[k], _, oob = oracle.calculate_optical_flow(frames[k - 1], frames[k], g, R)
+        assert oob == 0
+    try:
+        _oracle_rcp(members[0], True)
+        batch.runPeriod(batch.preparePeriod(src(0), None, None, calculate_flow=False))
+        batch.runPeriod(batch.preparePeriod(src(1), None, None))                     # flow (f0, f1); f0's plane from the plane kernel
+        for k in (2, 3):                                                             # deferred periods: warp first, it builds f(k-1)'s plane
+            batch.runPeriod(batch.preparePeriod(src(k), plans, optr, 2))
+            batch.sync()
+            want = {}
+            for i, m in enumerate(members):
+                if k == 3:
+                    assert np.array_equal(m.readBlurredFlow(0), flows[2]), i       # chain (f1, f2) ran on the plane the warp launch built
+                plane, complete = m.readPhasePlane(1)
+                assert complete, (k, i)
+                # [H][phase pairs][row pitch] elements; the pitch is rounded up to 128 bytes and the (never read) padding columns are
+                # only written by the generic plane kernel, which the misaligned member's frames take: compare the columns in use
+                plane = plane.reshape(H, 4, -1)
+                if i == 0:
+                    plane0 = plane
+                    used = int(np.flatnonzero(plane0.any(axis=(0, 1))).max()) + 1
+                    assert used >= g.lw and plane0.shape[2] - used < 32
+                else:
+                    assert np.array_equal(plane[:, :, :used], plane0[:, :, :used]), (k, i)   # the misaligned member's plane (plane kernel) == the others'
+                for j, t in enumerate(plans[i]):
+                    key = (t, LEVELS[i % 3])
+                    if key not in want:
+                        want[key] = oracle.warp_frames(frames[k - 2], frames[k - 1], flows[k - 1], g, np.float32(t), 2, *LEVELS[i % 3])
+                    got = outs[i][j].download(np.uint16)
+                    w2 = want[key].reshape(-1, SO)
+                    g2 = got.reshape(-1, SO)
+                    assert np.array_equal(g2[:, :W], w2[:, :W]), (k, i, j, t)
+                    assert (g2[:, W:] == 0xA5A5).all(), (k, i, j)
+    finally:
+        oracle.set_flavour(1, 1, None)
+        batch.close()
+        for m in members:
+            m.close()
+        for b in dev + dev_odd + [x for o in outs for x in o]:
+            b.free()
+
+
+def test_deferred_run_period_matches_the_reference_frames(native_lib):
+    """hf_batch_run_period with frames AND outputs on a plane-deferring batch -- the exact call of bench.py -- compared DIRECTLY
+    with the reference's golden frames (SHA-256), not through the eager order."""
+    from hopperrender_amd import capi
+    from hopperrender_amd.calc import DeviceBuffer, FlowBatch, OpticalFlowCalcHDR
+    g = Golden("hdr_2160p")
+    frames = g.frames()
+    key = "R16_d8_n6"
+    R, delta, nb = g.params(key)
+    dev = []
+    for f in frames:
+        b = DeviceBuffer(f.nbytes); b.upload(f); dev.append(b)
+    n = 16
+    lv = lambda i: (16.0, 235.0) if i % 4 == 3 else (0.0, 255.0)      # the golden file also holds warp_m2_t0.5_lv16_235
+    members = [OpticalFlowCalcHDR(g.case["H"], g.case["W"], g.case["si"], g.case["so"], delta, nb, *lv(i), g.case.get("max_res", 270),
+                                  search_radius=R, flags=capi.HF_FLAG_ASYNC | capi.HF_FLAG_NO_TIMING) for i in range(n)]
+    batch = FlowBatch(members)
+    assert batch.defersPlanes()
+    outs = [[DeviceBuffer(members[0].output_frame_bytes) for _ in range(6)] for _ in range(n)]
+    optr = [[b.ptr for b in o] for o in outs]
+    plans = [[0.5, 0.25, 0.75] if i % 4 == 3 else (T6[i % 6:] + T6[:i % 6])[:5 + (i % 2)] for i in range(n)]
+    batch.runPeriod(batch.preparePeriod([dev[0].ptr] * n, None, None, calculate_flow=False))
+    batch.runPeriod(batch.preparePeriod([dev[1].ptr] * n, None, None, calculate_flow=False))
+    batch.runPeriod(batch.preparePeriod([dev[2].ptr] * n, plans, optr, 2))           # flow (f1, f2); its outputs use the (zero) flow before it
+    batch.runPeriod(batch.preparePeriod([dev[3].ptr] * n, plans, optr, 2))           # deferred: warp (f1, f2; flow a) first, builds f2's plane
+    batch.sync()
+    names = g.frame_names(key)
+    n_checked = 0
+    for i, m in enumerate(members):
+        assert np.array_equal(m.readBlurredFlow(0), g.arr(key, "blur_a")), i
+        assert np.array_equal(m.readBlurredFlow(1), g.arr(key, "blur_b")), i
+        for j, t in enumerate(plans[i]):
+            fname = f"warp_m2_t{t}" + ("_lv16_235" if i % 4 == 3 else "")
+            if fname in names:
+                assert sha(outs[i][j].download(np.uint16)) == g.frame_sha(key, fname), (i, fname)
+                n_checked += 1
+    assert n_checked >= 20
+    batch.close()
+    for m in members:
+        m.close()
+    for b in dev + [x for o in outs for x in o]:
+        b.free()

@@ -1,0 +1,73 @@
+"""tools/attic/r04/whatif_warp.py -- STOPWATCH builds of the staged period warp (wrong results, never shipped, never in the product
+source): each variant removes ONE ingredient of warp_wg_body from a scratch copy of hf_kernels.hip and builds it into
+hopperrender_amd/lib/exp/<name>/ (git-ignored).  Timed with tools/ab_warp.sh / tools/ab_bench.sh on one box; the time a variant saves
+bounds what optimising that ingredient can buy.
+
+    python tools/attic/r04/whatif_warp.py [name ...]     (no names: all)
+"""
+import os, subprocess, sys, concurrent.futures as cf
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+SRC = open(os.path.join(R, "hopperrender_amd/csrc/hf_kernels.hip")).read()
+
+def sub(s, old, new, count=1):
+    assert s.count(old) >= 1, old[:60]
+    return s.replace(old, new) if count == 0 else s.replace(old, new, count)
+
+V = {}
+# phase C as a rolled loop over the outputs (CORRECT results): 1/5 of the code of the hot loop
+V["loop"] = lambda s: sub(s, """#pragma unroll
+    for (int j = 0; j < kMaxWarpOutputs; j++) {
+        if (j < n) {
+            Src S;
+            const uint2 d = sh.tab[j][ci];""", """#pragma unroll 1
+    for (int j = 0; j < n; j++) {
+        {
+            Src S;
+            const uint2 d = sh.tab[j][ci];""")
+# no blend arithmetic: both runs are read, the stored value is their XOR
+V["noblend"] = lambda s: sub(s, """                    float2v bl = __builtin_elementwise_fma(fa, s21, fb * s12);          // :176-177 as compiled on gfx950""",
+                             """                    if (true) { v[k * GROUP + i] = S.ra[r][k].v[i] ^ S.rb[r][k].v[i]; v[k * GROUP + i + 1] = S.ra[r][k].v[i + 1] ^ S.rb[r][k].v[i + 1]; continue; }
+                    float2v bl = __builtin_elementwise_fma(fa, s21, fb * s12);""")
+# source B's runs are not read from LDS (its window is still copied)
+V["nob"] = lambda s: sub(s, """                for (int r = 0; r < ROWS; r++) S.rb[r][0] = lds_run(p + (unsigned)r * rowb_b, off, odd);""",
+                         """                for (int r = 0; r < ROWS; r++) S.rb[r][0] = S.ra[r][0];   (void)p;""")
+# no window copy at all (LDS holds garbage)
+V["nocopy"] = lambda s: sub(sub(s, "    if (need_a) stage(A, cmin_a, ymin_a, C_a, R_a, lds);", "    if (need_a && n == 77) stage(A, cmin_a, ymin_a, C_a, R_a, lds);"),
+                            "    if (need_b) stage(B, cmin_b, ymin_b, C_b, R_b, lds + CHUNKS * 16);", "    if (need_b && n == 77) stage(B, cmin_b, ymin_b, C_b, R_b, lds + CHUNKS * 16);")
+# no output stores from the staged path
+V["nostore"] = lambda s: sub(s, """            E* __restrict__ out = (E*)a.outv[j] + out_off;
+            warp_finish<E, VEC, ROWS, MODE, CZ, 16>(S, a.s12v[j], a.s21v[j], out, So, ROWS, lv);
+        }
+    }
+}""", """            E* __restrict__ out = (E*)a.outv[j] + out_off;
+            warp_finish<E, VEC, ROWS, MODE, CZ, 16>(S, a.s12v[j], a.s21v[j], out, So, n == 77 ? ROWS : 0, lv);
+        }
+    }
+}""")
+# no flow lookups and no displacement arithmetic: zero displacement everywhere
+V["noA"] = lambda s: sub(sub(s, "            const uint32_t f12 = a.flow_xy[(size_t)ly * lw + lx];", "            const uint32_t f12 = n == 77 ? a.flow_xy[(size_t)ly * lw + lx] : 0u;"),
+                         "            const uint32_t f21 = a.flow_xy[(size_t)py * lw + px];", "            const uint32_t f21 = n == 77 ? a.flow_xy[(size_t)py * lw + px] : 0u;")
+# LDS run reads at conflict-free addresses (wrong data): lane-contiguous dwords
+V["noconf"] = lambda s: sub(s, """        const uint32_t* p = (const uint32_t*)p8;
+        uint32_t w[NDW + 1];
+#pragma unroll
+        for (int k = 0; k <= NDW; k++) w[k] = p[k];""", """        const uint32_t* p = (const uint32_t*)(lds + ((size_t)(p8 - lds) & 0x3000)) + lane;
+        uint32_t w[NDW + 1];
+#pragma unroll
+        for (int k = 0; k <= NDW; k++) w[k] = p[64 * k];""")
+
+def build(name):
+    d = os.path.join(R, "hopperrender_amd/lib/exp", "w_" + name); os.makedirs(d, exist_ok=True)
+    src = os.path.join(d, "hf_kernels.hip")
+    open(src, "w").write(V[name](SRC))
+    F = "--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-function".split()
+    subprocess.check_call(["/opt/rocm/bin/hipcc"] + F + ["-I", os.path.join(R, "include"), "-I", os.path.join(R, "hopperrender_amd/csrc"), "-c", src, "-o", src + ".o"], stderr=subprocess.DEVNULL)
+    L = os.path.join(R, "hopperrender_amd/lib")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", os.path.join(d, "libhopperflow.so"), src + ".o"] +
+                          [os.path.join(L, f) for f in ("hf_flow.hip.o", "hf_capi.hip.o", "hf_filter.cpp.o", "hf_hostio.cpp.o")] + ["-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined"])
+    os.remove(src + ".o"); os.remove(src)
+    return name
+
+names = sys.argv[1:] or list(V)
+with cf.ThreadPoolExecutor(4) as ex:
+    for n in ex.map(build, names): print("built w_" + n, flush=True)

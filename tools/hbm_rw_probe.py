@@ -20,5 +20,3 @@ r = t(lambda: x.sum())
 c = t(lambda: y.copy_(x))
 z = t(lambda: x.zero_())
 print(f"write-only fill_ {N / w / 1e12:.2f} TB/s   zero_ {N / z / 1e12:.2f} TB/s   read-only sum {N / r / 1e12:.2f} TB/s   copy {2 * N / c / 1e12:.2f} TB/s (read + write)")
-for frac_w in (5 / 7,):   # the period warp: 2 frames read, 5 written
-    pass
