@@ -21,7 +21,10 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
              "-Wall", "-Wno-unused-function"]
 
+FLOW_SOURCES = ("hf_kernels.hip", "hf_flow.hip", "hf_capi.hip", "hf_filter.cpp", "hf_hostio.cpp")
+FLOW_HEADERS = ("hf_kernels.h", "hf_phase_plane.h")
 LIB_FLOW = os.path.join(LIBDIR, "libhopperflow.so")
+LIB_FLOW_DEBUG = os.path.join(LIBDIR, "libhopperflow_dbg.so")   # --debug-bounds: -DHF_DEBUG_BOUNDS, every gather index checked on the device
 LIB_ADAPTER = os.path.join(LIBDIR, "libopticalflowcalc.so")
 
 
@@ -40,23 +43,33 @@ def _run(cmd):
     return r
 
 
-def build_flow(force=False):
+def build_flow(force=False, debug_bounds=False):
+    """libhopperflow.so, or -- debug_bounds -- libhopperflow_dbg.so: the same sources with -DHF_DEBUG_BOUNDS (csrc/hf_kernels.h
+    HF_DBG_CHECK: every gather index of the kernels checked against its buffer, trap on violation).  Select it with HF_LIB=<path>."""
     os.makedirs(LIBDIR, exist_ok=True)
     extra = os.environ.get("HF_CXXFLAGS", "").split()   # experiments only (e.g. -DHF_EXP=1)
     force = force or bool(extra)
-    srcs = [os.path.join(CSRC, f) for f in ("hf_kernels.hip", "hf_flow.hip", "hf_capi.hip", "hf_filter.cpp", "hf_hostio.cpp")]
-    deps = srcs + [os.path.join(CSRC, "hf_kernels.h"), os.path.join(CSRC, "hf_phase_plane.h"), os.path.join(INCLUDE, "hopperflow.h"), os.path.join(INCLUDE, "config.h")]
-    if force or _stale(LIB_FLOW, deps):
+    target, suffix = (LIB_FLOW_DEBUG, ".dbg.o") if debug_bounds else (LIB_FLOW, ".o")
+    if debug_bounds:
+        extra = extra + ["-DHF_DEBUG_BOUNDS"]
+    srcs = [os.path.join(CSRC, f) for f in FLOW_SOURCES]
+    deps = srcs + [os.path.join(CSRC, f) for f in FLOW_HEADERS] + [os.path.join(INCLUDE, "hopperflow.h"), os.path.join(INCLUDE, "config.h")]
+    if force or _stale(target, deps):
         objs = []
         hdrs = deps[len(srcs):]
+        todo = []
         for s in srcs:
-            o = os.path.join(LIBDIR, os.path.basename(s) + ".o")
+            o = os.path.join(LIBDIR, os.path.basename(s) + suffix)
             if force or _stale(o, [s] + hdrs):   # objects are git-ignored; only changed sources are recompiled
-                _run([HIPCC] + HIP_FLAGS + extra + ["-I", INCLUDE, "-c", s, "-o", o])
+                todo.append([HIPCC] + HIP_FLAGS + extra + ["-I", INCLUDE, "-c", s, "-o", o])
             objs.append(o)
-        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_FLOW] + objs +
+        if todo:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(min(4, len(todo))) as ex:   # (the translation units are independent; hipcc is single-threaded)
+                list(ex.map(_run, todo))
+        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", target] + objs +
              ["-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined"])
-    return LIB_FLOW
+    return target
 
 
 def build_adapter(force=False):
@@ -77,5 +90,8 @@ def build_all(force=False):
 
 
 if __name__ == "__main__":
-    build_all(force="--force" in sys.argv)
-    print(LIB_FLOW)
+    if "--debug-bounds" in sys.argv:
+        print(build_flow(force="--force" in sys.argv, debug_bounds=True))
+    else:
+        build_all(force="--force" in sys.argv)
+        print(LIB_FLOW)

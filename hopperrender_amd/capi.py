@@ -147,6 +147,8 @@ SIGNATURES = {
     "hf_host_malloc_pinned": (_i, [C.c_size_t, C.POINTER(_vp)]),
     "hf_host_free_pinned": (_i, [_vp]),
     "hf_filter_create": (_i, [C.POINTER(HfFilterConfig), C.POINTER(_vp)]),
+    "hf_debug_bounds_selftest": (_i, [_vp]),
+    "hf_debug_bounds_violations": (_i, [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _i]),
     "hf_filter_destroy": (None, [_vp]),
     "hf_filter_new_segment": (_i, [_vp, C.c_double]),
     "hf_filter_set_playback_frame_time": (_i, [_vp, C.c_int64]),

@@ -1453,6 +1453,34 @@ int hf_timer_end(hf_ctx* c, float* elapsed_ms) {
     return HF_OK;
 }
 
+int hf_debug_bounds_violations(hf_ctx* c, uint32_t* count, uint32_t first[4], int reset) {
+    if (!c || !count) return HF_ERR_INVALID_ARGUMENT;
+    if (int rc = set_device(c)) return rc;
+    if (hipDeviceSynchronize() != hipSuccess) return fail(c, HF_ERR_HIP, "hf_debug_bounds_violations: hipDeviceSynchronize failed");
+    unsigned rec[5] = {0, 0, 0, 0, 0};
+    const bool a = hf::dbg_bounds_read_kernels(rec, reset != 0), b = hf::dbg_bounds_read_flow(rec, reset != 0);
+    if (!a || !b) return fail(c, HF_ERR_STATE, "hf_debug_bounds_violations: this library was built without -DHF_DEBUG_BOUNDS (python -m hopperrender_amd.build --debug-bounds)");
+    *count = rec[0];
+    if (first) for (int i = 0; i < 4; i++) first[i] = rec[1 + i];
+    return HF_OK;
+}
+
+int hf_debug_bounds_selftest(hf_ctx* c) {
+    if (!c) return HF_ERR_INVALID_ARGUMENT;
+    uint32_t before = 0, after = 0, first[4] = {0, 0, 0, 0};
+    if (int rc = hf_debug_bounds_violations(c, &before, nullptr, 0)) return rc;
+    int* scratch = nullptr;
+    if (hipMalloc(&scratch, 80 * sizeof(int)) != hipSuccess) return fail(c, HF_ERR_OUT_OF_MEMORY, "hf_debug_bounds_selftest: hipMalloc failed");
+    hf::launch_bounds_selftest(scratch, c->stream);
+    const hipError_t e = hipStreamSynchronize(c->stream);
+    hipFree(scratch);
+    if (e != hipSuccess) return fail(c, HF_ERR_HIP, "hf_debug_bounds_selftest: launch failed");
+    if (int rc = hf_debug_bounds_violations(c, &after, first, 0)) return rc;
+    if (after - before != 64u || (before == 0 && first[0] != 999u))
+        return fail(c, HF_ERR_STATE, "hf_debug_bounds_selftest: 64 out-of-range indices were issued, %u recorded (first site %u)", after - before, first[0]);
+    return HF_OK;
+}
+
 int hf_device_rcp(hf_ctx* c, const float* host_in, float* host_out, int n) {
     HF_CHECK_CTX(c);
     if (!host_in || !host_out || n < 1 || n > 32) return fail(c, HF_ERR_INVALID_ARGUMENT, "hf_device_rcp: bad argument");

@@ -101,6 +101,7 @@ struct WinConst {
 };
 
 __device__ __forceinline__ int table_at(const int16_t* __restrict__ t, const FlowLevel& L, int px, int py) {
+    HF_DBG_CHECK(px >= 0 && py >= 0 && (px >> L.log2w) < L.nwx && (py >> L.log2w) < L.nwy, 100);
     return t[(py >> L.log2w) * L.nwx + (px >> L.log2w)];
 }
 
@@ -127,6 +128,7 @@ __device__ __forceinline__ WinConst load_win_const(const Geom& g, const FlowStep
             w.nbx[3] = table_at(a.prev.tx, a.prev, x0, yu); w.nby[3] = table_at(a.prev.ty, a.prev, x0, yu);
         }
     }
+    HF_DBG_CHECK(wx >= 0 && wy >= 0 && wx < a.cur.nwx && wy < a.cur.nwy, 101);
     if (use_cur_x) w.ox = a.cur.tx[wy * a.cur.nwx + wx];
     w.npix = (uint32_t)((min(g.lw, x0 + ws) - x0) * (min(g.lh, y0 + ws) - y0));
     return w;
@@ -178,6 +180,7 @@ __device__ __forceinline__ Strip<PX> load_strip(const Geom& g, const FlowStep& a
     if (s.any) {
         const PhaseLayout& pl = a.pl;
         const int sy = cy << g.rs;   // grid samples of frame N = phase 0 of its own plane (:98-100, frame2 operands)
+        HF_DBG_CHECK(cx0 >= 0 && sy >= 0 && ((size_t)sy * pl.nph2 * pl.lwp + pl.mx + cx0 + PX) * 4 <= pl.bytes, 102);
         const Elems<PX> e = load_elems<PX>(a.pp2 + (size_t)sy * pl.nph2 * pl.lwp + pl.mx + cx0);
 #pragma unroll
         for (int i = 0; i < PX; i++) s.ref[i] = e.d[i] & 0xFFFF00FFu & s.vm[i];
@@ -190,7 +193,8 @@ __device__ __forceinline__ Strip<PX> load_strip(const Geom& g, const FlowStep& a
 typedef unsigned flow_v2 __attribute__((ext_vector_type(2)));
 typedef unsigned flow_v4 __attribute__((ext_vector_type(4)));
 template <int PX>
-__device__ __forceinline__ Elems<PX> buffer_elems(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+__device__ __forceinline__ Elems<PX> buffer_elems(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, [[maybe_unused]] size_t plane_bytes) {
+    HF_DBG_CHECK((size_t)voff + soff + 4 * PX <= plane_bytes && ((voff + soff) & 3u) == 0, 103);   // (the hardware would return 0 beyond the plane)
     Elems<PX> r;
     if constexpr (PX == 4) {
         const flow_v4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
@@ -202,7 +206,7 @@ __device__ __forceinline__ Elems<PX> buffer_elems(__amdgpu_buffer_rsrc_t rsrc, u
     return r;
 }
 
-// sad[cz] = sum over the strip of |dY| + |dU| + |dV| for candidate cz of `axis` (0 for cz >= R).
+// sad[cz] += sum over the strip of |dY| + |dU| + |dV| for candidate cz of `axis` (cz < R; the caller zeroes sad[] before the first strip).
 // The plane offset of a candidate splits into a per-LANE part (the strip's own row / column) and a per-WINDOW part (what
 // the candidate offset adds): X step  lane: row(sy + oy) * row_el + mx + cx0      window: (ph >> 1) * lwp + (c >> rs)
 //                             Y step  lane: sy * row_el + (ph0 >> 1) * lwp + mx + j0   window: c * row_el
@@ -235,7 +239,7 @@ __device__ __forceinline__ void strip_sads(uint32_t* sad, const Geom& g, const F
                 const int c = searched0 + rel_offset(cz, R);
                 const int ph = c & (pl.nph - 1);
                 const unsigned coff = (unsigned)((ph >> 1) * pl.lwp + (c >> g.rs) + pl.mx) * 4u;
-                c1[cz] = UNI ? buffer_elems<PX>(rsrc, lane_off + 0u, coff) : buffer_elems<PX>(rsrc, lane_off + coff, 0u);
+                c1[cz] = UNI ? buffer_elems<PX>(rsrc, lane_off + 0u, coff, pl.bytes) : buffer_elems<PX>(rsrc, lane_off + coff, 0u, pl.bytes);
                 sel[cz] = 0x03020c00u | (unsigned)(ph & 1);           // v_perm_b32: luma byte of this phase, 0, U, V
             }
         }
@@ -252,7 +256,7 @@ __device__ __forceinline__ void strip_sads(uint32_t* sad, const Geom& g, const F
             for (int cz = 0; cz < 16; cz++) {
                 if (cz < R && any) {
                     const unsigned coff = __umul24((unsigned)(rel_offset(cz, R) - rel_offset(0, R)), row_el) * 4u;   // >= 0, wave-uniform
-                    c1[cz] = buffer_elems<PX>(rsrc, lane_off, coff);
+                    c1[cz] = buffer_elems<PX>(rsrc, lane_off, coff, pl.bytes);
                     sel[cz] = selc;
                 }
             }
@@ -261,7 +265,7 @@ __device__ __forceinline__ void strip_sads(uint32_t* sad, const Geom& g, const F
             for (int cz = 0; cz < 16; cz++) {
                 if (cz < R && any) {
                     const int ny = mirror_clamp(sy + searched0 + rel_offset(cz, R), g.H);
-                    c1[cz] = buffer_elems<PX>(rsrc, (__umul24((unsigned)ny, row_el) + col) * 4u, 0u);
+                    c1[cz] = buffer_elems<PX>(rsrc, (__umul24((unsigned)ny, row_el) + col) * 4u, 0u, pl.bytes);
                     sel[cz] = selc;
                 }
             }
@@ -269,7 +273,7 @@ __device__ __forceinline__ void strip_sads(uint32_t* sad, const Geom& g, const F
     }
 #pragma unroll
     for (int cz = 0; cz < 16; cz++) {
-        uint32_t t = 0u;
+        uint32_t t = sad[cz];
         if (cz < R && any) {
 #pragma unroll
             for (int i = 0; i < PX; i++) {
@@ -285,18 +289,45 @@ __device__ __forceinline__ void strip_sads(uint32_t* sad, const Geom& g, const F
 // ------------------------------------------------------------------------------------------
 // cross-lane reduction
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t shfl_xor_u32(uint32_t v, int m) { return (uint32_t)__shfl_xor((int)v, m, 64); }
+// Value of lane (l ^ M) -- on the vector ALU's own cross-lane paths, never through the LDS crossbar (__shfl_xor = ds_bpermute_b32: an LDS
+// instruction and ~100 cycles of dependent latency per exchange; a level launch made ~50 of them in a row, a good part of its skeleton):
+// M = 1, 2 DPP quad_perm; M = 4 two bank-masked DPP row shifts (lanes with bit 2 clear read lane + 4, the others lane - 4); M = 8 DPP
+// row_ror:8; M = 16 / 32 gfx950's v_permlane16_swap / v_permlane32_swap of the value with itself + one select.
+template <int CTRL, int BANKS>
+__device__ __forceinline__ uint32_t dpp_into(uint32_t old, uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, 0xF, BANKS, false);
+}
+template <int M>
+__device__ __forceinline__ uint32_t lane_xor(uint32_t v, int lane) {
+    static_assert(M == 1 || M == 2 || M == 4 || M == 8 || M == 16 || M == 32, "xor mask inside a wave");
+    if constexpr (M == 1) return dpp_into<0xB1, 0xF>(v, v);                     // quad_perm [1,0,3,2]
+    else if constexpr (M == 2) return dpp_into<0x4E, 0xF>(v, v);                // quad_perm [2,3,0,1]
+    else if constexpr (M == 4) return dpp_into<0x114, 0xA>(dpp_into<0x104, 0x5>(v, v), v);   // row_shl:4 into banks 0, 2; row_shr:4 into banks 1, 3
+    else if constexpr (M == 8) return dpp_into<0x128, 0xF>(v, v);               // row_ror:8
+    else if constexpr (M == 16) { const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false); return (lane & 16) ? r[0] : r[1]; }
+    else { const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false); return (lane & 32) ? r[0] : r[1]; }
+}
 
 // One butterfly level: lanes l and l^M exchange halves of their NV values; afterwards each lane
 // holds NV/2 values, each the pair-sum of one candidate.  Lanes with bit M set keep the upper half.
+// M = 16 / 32: the swap instructions ARE this exchange -- v_permlane32_swap(x, y) leaves x = [x.lo, y.lo], y = [x.hi, y.hi], so x + y is
+// x summed over the pair in the lower lanes and y summed over the pair in the upper ones: one swap + one add per value, no selects.
 template <int NV, int M>
 __device__ __forceinline__ void butterfly_level(uint32_t* v, int lane) {
-    const bool hi = (lane & M) != 0;
 #pragma unroll
     for (int k = 0; k < NV / 2; k++) {
-        const uint32_t send = hi ? v[k] : v[k + NV / 2];
-        const uint32_t keep = hi ? v[k + NV / 2] : v[k];
-        v[k] = keep + shfl_xor_u32(send, M);
+        if constexpr (M == 32) {
+            const auto r = __builtin_amdgcn_permlane32_swap(v[k], v[k + NV / 2], false, false);
+            v[k] = r[0] + r[1];
+        } else if constexpr (M == 16) {
+            const auto r = __builtin_amdgcn_permlane16_swap(v[k], v[k + NV / 2], false, false);
+            v[k] = r[0] + r[1];
+        } else {
+            const bool hi = (lane & M) != 0;
+            const uint32_t send = hi ? v[k] : v[k + NV / 2];
+            const uint32_t keep = hi ? v[k + NV / 2] : v[k];
+            v[k] = keep + lane_xor<M>(send, lane);
+        }
     }
 }
 
@@ -304,11 +335,14 @@ struct Best { uint32_t sum; int cz; };
 __device__ __forceinline__ void best_min(Best& b, uint32_t s, int cz) {   // first minimum wins (strict '<', determineLowestLayerKernelSDR.h:19-24)
     if (s < b.sum || (s == b.sum && cz < b.cz)) { b.sum = s; b.cz = cz; }
 }
-__device__ __forceinline__ void best_xor(Best& b, int m) {
-    const uint32_t s = shfl_xor_u32(b.sum, m);
-    const int c = __shfl_xor(b.cz, m, 64);
+template <int M>
+__device__ __forceinline__ void best_xor(Best& b, int lane) {
+    const uint32_t s = lane_xor<M>(b.sum, lane);
+    const int c = (int)lane_xor<M>((uint32_t)b.cz, lane);
     best_min(b, s, c);
 }
+template <int M>
+__device__ __forceinline__ uint32_t or_xor(uint32_t v, int lane) { return v | lane_xor<M>(v, lane); }
 
 // Reduces sad[16] over an aligned group of G lanes (G = 2, 4, 16, 64).  Afterwards each lane owns NOWN
 // consecutive candidates starting at `first` with their group totals in sad[0..NOWN).
@@ -317,33 +351,38 @@ template <> struct Owned<64> { static constexpr int n = 1; };
 template <> struct Owned<16> { static constexpr int n = 1; };
 template <> struct Owned<4> { static constexpr int n = 4; };
 template <> struct Owned<2> { static constexpr int n = 8; };
+template <> struct Owned<1> { static constexpr int n = 16; };
 
-template <int G>
+// XM (G == 2 only): the partner of a lane is lane ^ XM
+template <int G, int XM = 1>
 __device__ __forceinline__ int group_reduce(uint32_t* sad, int lane) {
-    if (G == 64) {
+    if constexpr (G == 1) {
+        return 0;
+    } else if constexpr (G == 2) {
+        butterfly_level<16, XM>(sad, lane);
+        return (lane & XM) ? 8 : 0;
+    } else if constexpr (G == 64) {
         butterfly_level<16, 32>(sad, lane); butterfly_level<8, 16>(sad, lane);
         butterfly_level<4, 8>(sad, lane);   butterfly_level<2, 4>(sad, lane);
-        sad[0] += shfl_xor_u32(sad[0], 2);
-        sad[0] += shfl_xor_u32(sad[0], 1);
+        sad[0] += lane_xor<2>(sad[0], lane);
+        sad[0] += lane_xor<1>(sad[0], lane);
         return ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
-    } else if (G == 16) {
+    } else if constexpr (G == 16) {
         butterfly_level<16, 8>(sad, lane); butterfly_level<8, 4>(sad, lane);
         butterfly_level<4, 2>(sad, lane);  butterfly_level<2, 1>(sad, lane);
         return ((lane >> 3) & 1) * 8 + ((lane >> 2) & 1) * 4 + ((lane >> 1) & 1) * 2 + (lane & 1);
-    } else if (G == 4) {
+    } else {
+        static_assert(G == 4, "lane groups of 1, 2, 4, 16 or 64");
         butterfly_level<16, 2>(sad, lane); butterfly_level<8, 1>(sad, lane);
         return ((lane >> 1) & 1) * 8 + (lane & 1) * 4;
-    } else {
-        butterfly_level<16, 1>(sad, lane);
-        return (lane & 1) * 8;
     }
 }
 
 // argmin over all candidates of the group; every lane of the group returns the same winner.
 // `captured` (optional) receives the full cost sum of candidate cap_cz.
-template <int G, bool FULL>
+template <int G, bool FULL, int XM = 1>
 __device__ __forceinline__ int group_argmin(const uint32_t* tot, int first, const FlowStep& a, int searched0,
-                                            const int* nb, uint32_t npix, int cap_cz, bool want_cap, uint32_t& captured) {
+                                            const int* nb, uint32_t npix, int cap_cz, bool want_cap, uint32_t& captured, int lane) {
     const int R = FULL ? 16 : a.R;
     Best b{0xFFFFFFFFu, 16};
     uint32_t cap = 0;
@@ -357,15 +396,15 @@ __device__ __forceinline__ int group_argmin(const uint32_t* tot, int first, cons
             if (cz == cap_cz) cap = sum;
         }
     }
-    if (G == 64) { best_xor(b, 4); best_xor(b, 8); best_xor(b, 16); best_xor(b, 32); }
-    else if (G == 16) { best_xor(b, 1); best_xor(b, 2); best_xor(b, 4); best_xor(b, 8); }
-    else if (G == 4) { best_xor(b, 1); best_xor(b, 2); }
-    else { best_xor(b, 1); }
+    if (G == 64) { best_xor<4>(b, lane); best_xor<8>(b, lane); best_xor<16>(b, lane); best_xor<32>(b, lane); }
+    else if (G == 16) { best_xor<1>(b, lane); best_xor<2>(b, lane); best_xor<4>(b, lane); best_xor<8>(b, lane); }
+    else if (G == 4) { best_xor<1>(b, lane); best_xor<2>(b, lane); }
+    else if (G == 2) { best_xor<XM>(b, lane); }
     if (want_cap) {
-        if (G == 64) { cap |= shfl_xor_u32(cap, 4); cap |= shfl_xor_u32(cap, 8); cap |= shfl_xor_u32(cap, 16); cap |= shfl_xor_u32(cap, 32); }
-        else if (G == 16) { cap |= shfl_xor_u32(cap, 1); cap |= shfl_xor_u32(cap, 2); cap |= shfl_xor_u32(cap, 4); cap |= shfl_xor_u32(cap, 8); }
-        else if (G == 4) { cap |= shfl_xor_u32(cap, 1); cap |= shfl_xor_u32(cap, 2); }
-        else { cap |= shfl_xor_u32(cap, 1); }
+        if (G == 64) { cap = or_xor<4>(cap, lane); cap = or_xor<8>(cap, lane); cap = or_xor<16>(cap, lane); cap = or_xor<32>(cap, lane); }
+        else if (G == 16) { cap = or_xor<1>(cap, lane); cap = or_xor<2>(cap, lane); cap = or_xor<4>(cap, lane); cap = or_xor<8>(cap, lane); }
+        else if (G == 4) { cap = or_xor<1>(cap, lane); cap = or_xor<2>(cap, lane); }
+        else if (G == 2) { cap = or_xor<XM>(cap, lane); }
         captured = cap;
     }
     return b.cz;
@@ -385,16 +424,17 @@ __device__ __forceinline__ int resolve_pending(const Geom& g, const FlowStep& a,
     const int cz = lane & 15;
     Best b{0xFFFFFFFFu, 16};
     uint32_t mine = 0;
+    HF_DBG_CHECK(wx >= 0 && wy >= 0 && wx < p.lvl.nwx && wy < p.lvl.nwy, 104);
     if (cz < a.R) {
         const int cand = (int)(int16_t)(searched0 + rel_offset(cz, a.R));
         mine = (p.sums[w * 16 + cz] << a.delta_scalar) + npix * ((uint32_t)(cand < 0 ? -cand : cand) & 0xFFFFu);  // no neighbour term (level < 4)
         b.sum = mine; b.cz = cz;
     }
-    best_xor(b, 1); best_xor(b, 2); best_xor(b, 4); best_xor(b, 8);
+    best_xor<1>(b, lane); best_xor<2>(b, lane); best_xor<4>(b, lane); best_xor<8>(b, lane);
     const int value = (int)(int16_t)(searched0 + rel_offset(b.cz, a.R));
     if (p.capture_delta && w == 0) {   // opticalFlowCalcSDR.cpp:91-94
         uint32_t cap = cz == (a.R >> 1) - 1 ? mine : 0u;
-        cap |= shfl_xor_u32(cap, 1); cap |= shfl_xor_u32(cap, 2); cap |= shfl_xor_u32(cap, 4); cap |= shfl_xor_u32(cap, 8);
+        cap = or_xor<1>(cap, lane); cap = or_xor<2>(cap, lane); cap = or_xor<4>(cap, lane); cap = or_xor<8>(cap, lane);
         if (origin_leader) *a.total_delta = cap / a.delta_divisor;
     }
     if (origin_leader) (p.axis ? p.lvl.ty : p.lvl.tx)[w] = (int16_t)value;
@@ -422,13 +462,15 @@ struct FlowPtrs {
 };
 struct FlowBatchArgs {
     int n;
+    FastDiv tiles, tiles_x;              // unit index -> (pair, tile row, tile column): scalar divisions (hf_kernels.h)
     FlowStep common;
     FlowPtrs m[kMaxFlowBatch];
 };
 static_assert(sizeof(FlowBatchArgs) + sizeof(Geom) <= 4096, "kernel arguments of a batched chain launch");
-static FlowBatchArgs pack_batch(const FlowBatch& b) {
+static FlowBatchArgs pack_batch(const FlowBatch& b, int tiles_x, int tiles_y) {
     FlowBatchArgs k;
     k.n = b.n;
+    k.tiles = make_fastdiv((uint32_t)(tiles_x * tiles_y)); k.tiles_x = make_fastdiv((uint32_t)tiles_x);   // (units x tiles < 2^32: grids up to 64 k tiles)
     k.common = b.s[0];
     for (int i = 0; i < b.n; i++) {
         const FlowStep& f = b.s[i];
@@ -449,18 +491,19 @@ __device__ __forceinline__ FlowStep member_step(const FlowBatchArgs& k, int i) {
 }
 
 struct TileId { int pair, tx, ty, wave; bool valid; };
-__device__ __forceinline__ TileId decode_tile(int tiles_x, int tiles_y, int waves_per_tile, int n_pairs) {
-    const int total = tiles_x * tiles_y * waves_per_tile * n_pairs;
+template <int WPT>   // waves per tile: 1, 2 or 4
+__device__ __forceinline__ TileId decode_tile(const FlowBatchArgs& k, int tiles_x, int tiles_y) {
+    const int n_tiles = tiles_x * tiles_y;
+    const int total = n_tiles * WPT * k.n;
     const int per = (total + 7) >> 3;                       // the grid is exactly 8 * per workgroups
     const int u = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
     TileId t;
     t.valid = u < total;
-    t.wave = u % waves_per_tile;
-    const int v = u / waves_per_tile;
-    const int n_tiles = tiles_x * tiles_y;
-    t.pair = min(v / n_tiles, n_pairs - 1);
-    const int tile = v % n_tiles;
-    t.ty = tile / tiles_x;
+    t.wave = u & (WPT - 1);
+    const int v = u / WPT;
+    t.pair = min((int)fastdiv((uint32_t)v, k.tiles), k.n - 1);
+    const int tile = v - t.pair * n_tiles;                  // (only meaningful for valid units)
+    t.ty = (int)fastdiv((uint32_t)max(tile, 0), k.tiles_x);
     t.tx = tile - t.ty * tiles_x;
     return t;
 }
@@ -471,37 +514,42 @@ inline int xcd_grid(int tiles_x, int tiles_y, int waves_per_tile, int n_pairs) {
 // ------------------------------------------------------------------------------------------
 // lane -> strip mapping: every window of size WS is an aligned, contiguous lane group
 // ------------------------------------------------------------------------------------------
+// PX consecutive grid pixels x NR consecutive grid rows per lane; G lanes per window (G == 2: the partner is lane ^ XM).
 template <int WS> struct Map;
 template <> struct Map<32> {   // workgroup tile 32x32 = one window; wave = 8 rows
-    static constexpr int PX = 4, G = 64, TW = 32, TH = 32;
+    static constexpr int PX = 4, NR = 1, G = 64, XM = 1, TW = 32, TH = 32, WAVES = 4;
     __device__ static void at(int tid, int& x, int& y) { x = (tid & 7) * 4; y = tid >> 3; }
 };
 template <> struct Map<16> {   // wave = one 16x16 window; workgroup = 2x2 windows
-    static constexpr int PX = 4, G = 64, TW = 32, TH = 32;
+    static constexpr int PX = 4, NR = 1, G = 64, XM = 1, TW = 32, TH = 32, WAVES = 4;
     __device__ static void at(int tid, int& x, int& y) {
         const int w = tid >> 6, l = tid & 63;
         x = (w & 1) * 16 + (l & 3) * 4; y = (w >> 1) * 16 + (l >> 2);
     }
 };
 template <> struct Map<8> {    // 16 lanes = one 8x8 window; wave = 2x2 windows
-    static constexpr int PX = 4, G = 16, TW = 32, TH = 32;
+    static constexpr int PX = 4, NR = 1, G = 16, XM = 1, TW = 32, TH = 32, WAVES = 4;
     __device__ static void at(int tid, int& x, int& y) {
         const int w = tid >> 6, l = tid & 63, gi = l >> 4, i = l & 15;
         x = (w & 1) * 16 + (gi & 1) * 8 + (i & 1) * 4; y = (w >> 1) * 16 + (gi >> 1) * 8 + (i >> 1);
     }
 };
-template <> struct Map<4> {    // 4 lanes = one 4x4 window; wave = 4x4 windows
-    static constexpr int PX = 4, G = 4, TW = 32, TH = 32;
+// The two finest levels: a lane owns a 4 x 2 / 2 x 2 BLOCK -- both rows' SADs add up in the lane's own registers.  (Round 3: one row per
+// lane, so a 2 x 2 window was two lanes with two pixels each -- twice the waves, each paying the full per-wave skeleton of window
+// constants, bias terms and argmin for half the pixels, plus a butterfly; the level-2 and level-4 launches were the two most expensive
+// of the chain.)
+template <> struct Map<4> {    // 2 lanes (l, l ^ 8) = one 4x4 window; wave = 8x4 windows = 32 px x 16 rows; a 32x32 tile is TWO waves
+    static constexpr int PX = 4, NR = 2, G = 2, XM = 8, TW = 32, TH = 32, WAVES = 2;
     __device__ static void at(int tid, int& x, int& y) {
-        const int w = tid >> 6, l = tid & 63, gi = l >> 2;
-        x = (w & 1) * 16 + (gi & 3) * 4; y = (w >> 1) * 16 + (gi >> 2) * 4 + (l & 3);
+        const int w = tid >> 6, l = tid & 63;
+        x = (l & 7) * 4; y = w * 16 + (l >> 4) * 4 + ((l >> 3) & 1) * 2;
     }
 };
-template <> struct Map<2> {    // 2 lanes = one 2x2 window; wave = 8x4 windows; workgroup tile 16x32
-    static constexpr int PX = 2, G = 2, TW = 16, TH = 32;
+template <> struct Map<2> {    // one lane = one 2x2 window; wave = 16x4 windows = 32 px x 8 rows; workgroup tile 32x32
+    static constexpr int PX = 2, NR = 2, G = 1, XM = 1, TW = 32, TH = 32, WAVES = 4;
     __device__ static void at(int tid, int& x, int& y) {
-        const int w = tid >> 6, l = tid & 63, gi = l >> 1;
-        x = (gi & 7) * 2; y = w * 8 + (gi >> 3) * 2 + (l & 1);
+        const int w = tid >> 6, l = tid & 63;
+        x = (l & 15) * 2; y = w * 8 + (l >> 4) * 2;
     }
 };
 
@@ -529,7 +577,9 @@ __device__ __forceinline__ void flow_level_small_body(const Geom& g, const FlowS
         const int v = resolve_pending(g, a, tx0, ty0, lane, leader);
         if (a.pend.axis) wc.oy = v; else wc.ox = v;
     }
-    const Strip<PX> strip = load_strip<PX, FULL>(g, a, cx0, cy);
+    Strip<PX> strip[M::NR];
+#pragma unroll
+    for (int r = 0; r < M::NR; r++) strip[r] = load_strip<PX, FULL>(g, a, cx0, cy + r);
     const int cap_cz = (R >> 1) - 1;
     uint32_t captured = 0;
     int off[2] = {wc.ox, wc.oy};
@@ -537,19 +587,23 @@ __device__ __forceinline__ void flow_level_small_body(const Geom& g, const FlowS
 #pragma unroll
     for (int axis = 0; axis < 2; axis++) {
         uint32_t sad[16];
-        strip_sads<PX, G == 64, FULL>(sad, g, a, strip, off[0], off[1], axis);
-        int first = group_reduce<G>(sad, lane);
+#pragma unroll
+        for (int cz = 0; cz < 16; cz++) sad[cz] = 0u;
+#pragma unroll
+        for (int r = 0; r < M::NR; r++) strip_sads<PX, G == 64, FULL>(sad, g, a, strip[r], off[0], off[1], axis);
+        int first = group_reduce<G, M::XM>(sad, lane);
         if constexpr (WS == 32) {   // four waves share the window
             if ((lane & 3) == 0) s_part[axis][wave][first] = sad[0];
             __syncthreads();
             sad[0] = s_part[axis][0][first] + s_part[axis][1][first] + s_part[axis][2][first] + s_part[axis][3][first];
         }
-        const int best = group_argmin<G, FULL>(sad, first, a, off[axis], axis ? wc.nby : wc.nbx, wc.npix, cap_cz,
-                                               axis == 0 && a.capture_delta, captured);
+        const int best = group_argmin<G, FULL, M::XM>(sad, first, a, off[axis], axis ? wc.nby : wc.nbx, wc.npix, cap_cz,
+                                                      axis == 0 && a.capture_delta, captured, lane);
         off[axis] = (int)(int16_t)(off[axis] + rel_offset(best, R));   // adjustOffsetArrayKernelSDR.h:13-19
     }
 
-    const bool leader = WS == 32 ? tid == 0 : (lane & (G - 1)) == 0;
+    const bool leader = WS == 32 ? tid == 0 : G == 2 ? (lane & M::XM) == 0 : (lane & (G - 1)) == 0;
+    HF_DBG_CHECK(!win_in || (wx >= 0 && wy >= 0 && wx < a.cur.nwx && wy < a.cur.nwy), 105);
     if (win_in && leader) {
         a.cur.tx[wy * a.cur.nwx + wx] = (int16_t)off[0];
         a.cur.ty[wy * a.cur.nwx + wx] = (int16_t)off[1];
@@ -560,7 +614,7 @@ __device__ __forceinline__ void flow_level_small_body(const Geom& g, const FlowS
 template <int WS, bool SPLIT>
 __global__ __launch_bounds__(SPLIT ? 64 : 256) void flow_level_small_kernel(const Geom g, const FlowBatchArgs batch) {
     using M = Map<WS>;
-    const TileId tile = decode_tile((g.lw + M::TW - 1) / M::TW, (g.lh + M::TH - 1) / M::TH, SPLIT ? 4 : 1, batch.n);
+    const TileId tile = decode_tile<SPLIT ? M::WAVES : 1>(batch, (g.lw + M::TW - 1) / M::TW, (g.lh + M::TH - 1) / M::TH);
     if (!tile.valid) return;
     const FlowStep a = member_step(batch, tile.pair);
     static_assert(!SPLIT || WS <= 16, "a 32x32 window is shared by the four waves of a workgroup");
@@ -601,8 +655,11 @@ __device__ __forceinline__ void flow_big_partial_body(const Geom& g, const FlowS
     }
     const Strip<4> strip = load_strip<4, FULL>(g, a, cx0, cy);
     uint32_t sad[16];
+#pragma unroll
+    for (int cz = 0; cz < 16; cz++) sad[cz] = 0u;
     strip_sads<4, true, FULL>(sad, g, a, strip, ox, oy, a.axis);
     const int first = group_reduce<64>(sad, lane);
+    HF_DBG_CHECK(wx >= 0 && wy >= 0 && wx < a.cur.nwx && wy < a.cur.nwy, 106);
     uint32_t* dst = &a.sums[(wy * a.cur.nwx + wx) * 16];
     if constexpr (WPB == 1) {
         if ((lane & 3) == 0 && first < R) atomicAdd(dst + first, sad[0]);
@@ -620,7 +677,7 @@ __device__ __forceinline__ void flow_big_partial_body(const Geom& g, const FlowS
 
 template <int WPB>
 __global__ __launch_bounds__(64 * WPB) void flow_big_partial_kernel(const Geom g, const FlowBatchArgs batch) {
-    const TileId tile = decode_tile((g.lw + 63) / 64, (g.lh + 4 * WPB - 1) / (4 * WPB), 1, batch.n);
+    const TileId tile = decode_tile<1>(batch, (g.lw + 63) / 64, (g.lh + 4 * WPB - 1) / (4 * WPB));
     if (!tile.valid) return;
     const FlowStep a = member_step(batch, tile.pair);
     __shared__ uint32_t s_part[WPB][16];
@@ -646,7 +703,8 @@ __global__ __launch_bounds__(256) void flow_big_argmin_kernel(const Geom g, cons
                    wc.npix * window_bias(cand, a.use_neighbors, a.axis ? wc.nby : wc.nbx, a.neighbor_scalar);
             b.sum = mine; b.cz = lane16;
         }
-        best_xor(b, 1); best_xor(b, 2); best_xor(b, 4); best_xor(b, 8);
+        const int lane = (int)(threadIdx.x & 63);
+        best_xor<1>(b, lane); best_xor<2>(b, lane); best_xor<4>(b, lane); best_xor<8>(b, lane);
         if (lane16 == 0) {
             int16_t* t = a.axis ? a.cur.ty : a.cur.tx;
             t[w] = (int16_t)(searched0 + rel_offset(b.cz, a.R));
@@ -715,6 +773,7 @@ __global__ __launch_bounds__(256) void prep_grid_kernel(const PrepBatch batch, i
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= lw) return;
     const int sy = (int)blockIdx.y << pl.rs, x = j << pl.rs;     // rs >= 1: x is even and x + 1 lies inside the row
+    HF_DBG_CHECK(sy < H && x + 1 < S && ((size_t)sy * pl.nph2 * pl.lwp + pl.mx + j + 1) * 4 <= pl.bytes, 107);
     const E* __restrict__ yr = f + (size_t)sy * S + x;
     const E* __restrict__ cr = f + (size_t)H * S + (size_t)(sy >> 1) * S + x;
     pp[(size_t)sy * pl.nph2 * pl.lwp + pl.mx + j] = pack_element(top8<E>(yr[0]), top8<E>(yr[1]), top8<E>(cr[0]), top8<E>(cr[1]));
@@ -733,30 +792,45 @@ void launch_prep_frame(const Geom& g, const PhaseLayout& pl, const void* frame, 
 }
 
 void launch_flow_level_small(const Geom& g, const FlowBatch& b, hipStream_t stream) {
-    const FlowBatchArgs kb = pack_batch(b);
     const int ws = b.s[0].cur.window;
-    const int tw = ws == 2 ? 16 : 32;
-    const int tiles_x = (g.lw + tw - 1) / tw, tiles_y = (g.lh + 31) / 32;
+    const int tiles_x = (g.lw + 31) / 32, tiles_y = (g.lh + 31) / 32;   // (Map<WS>: 32 x 32 tiles at every level)
+    const FlowBatchArgs kb = pack_batch(b, tiles_x, tiles_y);
     // windows <= 16 never span waves: one-wave workgroups (SPLIT), see flow_level_small_kernel
-    const dim3 grd(xcd_grid(tiles_x, tiles_y, 1, b.n)), sgrd(xcd_grid(tiles_x, tiles_y, 4, b.n));
+    const dim3 grd(xcd_grid(tiles_x, tiles_y, 1, b.n));
+    auto split = [&](int waves) { return dim3(xcd_grid(tiles_x, tiles_y, waves, b.n)); };
     switch (ws) {
         case 32: flow_level_small_kernel<32, false><<<grd, 256, 0, stream>>>(g, kb); break;
-        case 16: flow_level_small_kernel<16, true><<<sgrd, 64, 0, stream>>>(g, kb); break;
-        case 8: flow_level_small_kernel<8, true><<<sgrd, 64, 0, stream>>>(g, kb); break;
-        case 4: flow_level_small_kernel<4, true><<<sgrd, 64, 0, stream>>>(g, kb); break;
-        default: flow_level_small_kernel<2, true><<<sgrd, 64, 0, stream>>>(g, kb); break;
+        case 16: flow_level_small_kernel<16, true><<<split(Map<16>::WAVES), 64, 0, stream>>>(g, kb); break;
+        case 8: flow_level_small_kernel<8, true><<<split(Map<8>::WAVES), 64, 0, stream>>>(g, kb); break;
+        case 4: flow_level_small_kernel<4, true><<<split(Map<4>::WAVES), 64, 0, stream>>>(g, kb); break;
+        default: flow_level_small_kernel<2, true><<<split(Map<2>::WAVES), 64, 0, stream>>>(g, kb); break;
     }
 }
 
 constexpr int kBigWavesPerBlock = 4;   // measured on MI355X (2160p HDR chain): 4 waves per workgroup 108.2 us, 2: 109.0 us, 1: 111.9 us (more atomics)
 void launch_flow_big_partial(const Geom& g, const FlowBatch& b, hipStream_t stream) {
-    const dim3 grd(xcd_grid((g.lw + 63) / 64, (g.lh + 4 * kBigWavesPerBlock - 1) / (4 * kBigWavesPerBlock), 1, b.n));
-    flow_big_partial_kernel<kBigWavesPerBlock><<<grd, 64 * kBigWavesPerBlock, 0, stream>>>(g, pack_batch(b));
+    const int tiles_x = (g.lw + 63) / 64, tiles_y = (g.lh + 4 * kBigWavesPerBlock - 1) / (4 * kBigWavesPerBlock);
+    const dim3 grd(xcd_grid(tiles_x, tiles_y, 1, b.n));
+    flow_big_partial_kernel<kBigWavesPerBlock><<<grd, 64 * kBigWavesPerBlock, 0, stream>>>(g, pack_batch(b, tiles_x, tiles_y));
 }
 
 void launch_flow_big_argmin(const Geom& g, const FlowBatch& b, hipStream_t stream) {
     const int nwin = b.s[0].cur.nwx * b.s[0].cur.nwy;
-    flow_big_argmin_kernel<<<dim3((nwin + 15) / 16, b.n), 256, 0, stream>>>(g, pack_batch(b));
+    flow_big_argmin_kernel<<<dim3((nwin + 15) / 16, b.n), 256, 0, stream>>>(g, pack_batch(b, 1, 1));
+}
+
+bool dbg_bounds_read_flow(unsigned out[5], bool reset) {
+#ifdef HF_DEBUG_BOUNDS
+    unsigned rec[5] = {0, 0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(rec, HIP_SYMBOL(g_dbg_bounds), sizeof(rec)) != hipSuccess) return false;
+    if (rec[0] && !out[0]) for (int i = 1; i < 5; i++) out[i] = rec[i];
+    out[0] += rec[0];
+    if (reset) { const unsigned zero[5] = {0, 0, 0, 0, 0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_bounds), zero, sizeof(zero)); }
+    return true;
+#else
+    (void)out; (void)reset;
+    return false;
+#endif
 }
 
 void launch_expand_offsets(const Geom& g, const FlowLevel& last, int16_t* out, hipStream_t stream) {

@@ -8,19 +8,26 @@
 #include <stdint.h>
 
 // Device debug build (`python -m hopperrender_amd.build --debug-bounds` => -DHF_DEBUG_BOUNDS, library libhopperflow_dbg.so): every
-// gather index of the kernels (frame / phase-plane / flow-table / LDS-window reads) is checked against its buffer; a violation prints
-// its site and traps the kernel.  This replaces the GPU AddressSanitizer the pool cannot offer (the reference's
-// own out-of-range case is the single reflection of calcDeltaSumsKernelSDR.h:86-95).  The product build compiles the checks away.
+// gather index of the kernels (frame / phase-plane / flow-table / LDS-window reads) is checked against its buffer; a violation is
+// RECORDED -- count + site, block and thread of the first one, in a __device__ record of the translation unit -- and the kernel goes on
+// (a record the host reads with hf_debug_bounds_violations() is more robust than a trap: a trapped queue takes the device printf
+// buffer and the whole context with it).  This replaces the GPU AddressSanitizer the pool cannot offer (the
+// reference's own out-of-range case is the single reflection of calcDeltaSumsKernelSDR.h:86-95).  The product build compiles the
+// checks away.
 #ifdef HF_DEBUG_BOUNDS
-#include <stdio.h>
-#define HF_DBG_CHECK(cond, site)                                                                                                   \
-    do {                                                                                                                           \
-        if (!(cond)) {                                                                                                             \
-            printf("[hopperflow] bounds violation: site %d, block %u, thread %u (%s:%d)\n", (int)(site), (unsigned)blockIdx.x,      \
-                   (unsigned)threadIdx.x, __FILE__, __LINE__);                                                                     \
-            __builtin_trap();                                                                                                      \
-        }                                                                                                                          \
-    } while (0)
+#ifdef __HIPCC__
+namespace hf { namespace {
+__device__ unsigned int g_dbg_bounds[5];   // [0] violations, [1..4] site / block / thread / line of the first one (one record per translation unit)
+__device__ __forceinline__ void dbg_bounds_record(int site, int line) {
+    if (atomicAdd(&g_dbg_bounds[0], 1u) == 0u) {
+        g_dbg_bounds[1] = (unsigned)site; g_dbg_bounds[2] = (unsigned)blockIdx.x; g_dbg_bounds[3] = (unsigned)threadIdx.x; g_dbg_bounds[4] = (unsigned)line;
+    }
+}
+} }
+#define HF_DBG_CHECK(cond, site) do { if (!(cond)) ::hf::dbg_bounds_record((site), __LINE__); } while (0)
+#else
+#define HF_DBG_CHECK(cond, site) do { } while (0)
+#endif
 #else
 #define HF_DBG_CHECK(cond, site) do { } while (0)
 #endif
@@ -36,6 +43,16 @@ struct Geom {
     int rs;              // resolution scalar
     int lw, lh;          // low-res grid
 };
+
+// Division of a wave-uniform index by a launch constant on the SCALAR unit: u / d == mulhi(u, ceil(2^32 / d)) while u * d < 2^32 (the
+// launchers check it).  Left to the compiler a uniform u / d is ~25 VECTOR instructions (v_rcp_iflag_f32, v_mul_hi_u32 ...) and every
+// workgroup of the batched kernels decodes its unit index with three of them before it can start.
+struct FastDiv { uint32_t d, magic; };
+inline FastDiv make_fastdiv(uint32_t d) { return FastDiv{d, d > 1 ? (uint32_t)(((1ull << 32) + d - 1) / d) : 0u}; }
+inline bool fastdiv_exact(uint64_t max_u, uint32_t d) { return max_u * d < (1ull << 32); }
+#ifdef __HIPCC__
+__device__ __forceinline__ uint32_t fastdiv(uint32_t u, const FastDiv f) { return f.magic ? __umulhi(u, f.magic) : u; }
+#endif
 
 constexpr int kMaxFlowBatch = 32;      // contexts per hf_batch (FlowBatch below)
 constexpr int kMaxWarpBatch = 16;      // members per fused warp launch (its per-member arguments are 168 bytes; a launch carries 4 KB)
@@ -168,6 +185,12 @@ void launch_warp(const Geom& g, const void* frame12, const void* frame21, const 
                  hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);  // events: timestamps of the dispatch itself
 // copyFrameKernel, both planes in one launch.
 void launch_copy(const Geom& g, const void* src, void* out, float black, float white, hipStream_t stream);
+// Debug-bounds records of the two kernel translation units (hf_kernels.hip / hf_flow.hip): out[0] += violations, out[1..4] = the first
+// one's site / block / thread / source line; reset: zero the records.  Return false in a build without HF_DEBUG_BOUNDS.
+bool dbg_bounds_read_kernels(unsigned out[5], bool reset);
+bool dbg_bounds_read_flow(unsigned out[5], bool reset);
+// Self-test: a kernel with 64 out-of-range "indices" (scratch: >= 65 ints of device memory): a checking build records 64 violations of site 999.
+void launch_bounds_selftest(int* scratch, hipStream_t stream);
 // v_rcp_f32 of the device (parity tooling: the reference's levels use it through OpenCL's fdiv).
 void launch_rcp_probe(const float* in, float* out, int n, hipStream_t stream);
 

@@ -90,6 +90,7 @@ __global__ __launch_bounds__(256) void blur_flow_kernel(const BlurBatch batch, i
         const int wrow = (mirror_flow(y0 + py, lh) >> L.log2w) * L.nwx;
         for (int px = tx; px < T; px += 16) {
             const int w = wrow + (mirror_flow(x0 + px, lw) >> L.log2w);
+            HF_DBG_CHECK(w >= 0 && w < L.nwx * L.nwy && py * T + px < T * T, 200);
             const uint32_t ox = L.tx ? (uint32_t)(uint16_t)L.tx[w] : 0u, oy = L.ty ? (uint32_t)(uint16_t)L.ty[w] : 0u;
             tile[py * T + px] = ox | (oy << 16);
         }
@@ -252,6 +253,7 @@ __device__ __forceinline__ unsigned warp_element(const Geom& g, const WarpArgs& 
     const size_t N = (size_t)lw * lh;
     const int lx = cz ? ((ax >> rs) & ~1) : (ax >> rs);   // :153-154
     const int ly = cz ? ((ay >> rs) << 1) : (ay >> rs);
+    HF_DBG_CHECK(lx >= 0 && ly >= 0 && lx < lw && ly < lh, 201);
     const int ox12 = a.flow[(size_t)ly * lw + lx];
     const int oy12 = a.flow[N + (size_t)ly * lw + lx];
     const int py = clampi(ly - (oy12 >> rs), 0, lh - 1);  // arithmetic shift, :157-158
@@ -272,6 +274,7 @@ __device__ __forceinline__ unsigned warp_element(const Geom& g, const WarpArgs& 
     const int par = cz ? (cx & 1) : 0;
     if (mode == 0) return A[plane + (size_t)y12 * Si + (cz ? (x12 & ~1) : x12) + par];
     if (mode == 1) return B[plane + (size_t)y21 * Si + (cz ? (x21 & ~1) : x21) + par];
+    HF_DBG_CHECK(x12 >= 0 && x21 >= 0 && y12 >= 0 && y21 >= 0 && y12 < dim_y && y21 < dim_y && (cz ? (x12 & ~1) + 1 : x12) < W && (cz ? (x21 & ~1) + 1 : x21) < W, 202);
     const float fa = (float)A[plane + (size_t)y12 * Si + (cz ? (x12 & ~1) : x12) + par];
     const float fb = (float)B[plane + (size_t)y21 * Si + (cz ? (x21 & ~1) : x21) + par];
     unsigned blended = (unsigned)__builtin_fmaf(fa, a.s21, fb * a.s12) & 0xFFFFu;     // :176-177 as compiled on gfx950
@@ -431,9 +434,10 @@ __device__ __forceinline__ Run<E, G> run_from_dwords(const uint32_t* w, unsigned
     return r;
 }
 template <typename E, int G, int CZ>
-__device__ __forceinline__ Run<E, G> get_run_buf(__amdgpu_buffer_rsrc_t rsrc, unsigned off, unsigned odd) {
+__device__ __forceinline__ Run<E, G> get_run_buf(__amdgpu_buffer_rsrc_t rsrc, unsigned off, unsigned odd, [[maybe_unused]] unsigned plane_bytes) {
     constexpr int NDW = G * (int)sizeof(E) / 4;
     const unsigned base = off & ~3u;
+    HF_DBG_CHECK((size_t)base + 4 * (NDW + 1) <= (size_t)plane_bytes + 4, 204);   // (the last dword of a run at the very end of the plane holds no needed byte and reads as 0)
     uint32_t w[NDW + 1];
     buffer_load_dwords<NDW>(w, rsrc, base);
     w[NDW] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, base + 4u * NDW, 0, 0);
@@ -464,19 +468,15 @@ template <int VB> struct StoreVec;
 template <> struct StoreVec<16> { using type = uint4; };
 template <> struct StoreVec<8> { using type = uint2; };
 
-#ifndef HF_WARP_NT_STORE
-#define HF_WARP_NT_STORE 1   // streaming stores of the output frames.  (Non-temporal LOADS of frame N-2, whose last use this is,
-                             // were much slower: 76 vs 52 us -- the outputs of a period re-read its rows through L2.)
-#endif
 // Blend + levels + store of one output: ROWS rows x VEC elements per thread from the source runs S (MODE 0 / 1: the run itself).
 template <typename E, int GROUP, int ROWS, int NG>
 struct WarpSrc { Run<E, GROUP> ra[ROWS][NG], rb[ROWS][NG]; };
 
-template <typename E, int GROUP, int ROWS, int MODE, int CZ, int VB>
-__device__ __forceinline__ void warp_finish(const WarpSrc<E, GROUP, ROWS, (VB / (int)sizeof(E)) / GROUP>& S, const float s12t, const float s21t,
-                                            E* __restrict__ out, const int So, const int nrows, const Levels& lv) {
+// `store(r, v)`: writes the VB bytes v of row r (one wide streaming store).
+template <typename E, int GROUP, int ROWS, int MODE, int CZ, int VB, typename Store>
+__device__ __forceinline__ void warp_finish_to(const WarpSrc<E, GROUP, ROWS, (VB / (int)sizeof(E)) / GROUP>& S, const float s12t, const float s21t,
+                                               const int nrows, const Levels& lv, const Store& store) {
     using T = ElemTraits<E>;
-    using SV = typename StoreVec<VB>::type;
     constexpr int VEC = VB / sizeof(E);
     constexpr int NG = VEC / GROUP;
 #pragma unroll
@@ -525,14 +525,18 @@ __device__ __forceinline__ void warp_finish(const WarpSrc<E, GROUP, ROWS, (VB / 
                 }
             }
         }
-#if HF_WARP_NT_STORE
-        typedef unsigned nt_vec __attribute__((ext_vector_type(VB / 4)));
-        __builtin_nontemporal_store(*(const nt_vec*)v, (nt_vec*)(out + (size_t)r * So));   // output frames are not read back on the GPU
-#else
-        *(SV*)(out + (size_t)r * So) = *(const SV*)v;
-#endif
+        store(r, v);
     }
-  }
+}
+// ... through a flat pointer: output frames are not read back on the GPU, so the stores are streaming (non-temporal) ones.  (Non-temporal
+// LOADS of frame N-2, whose last use this is, were much slower: 76 vs 52 us -- the outputs of a period re-read its rows through L2.)
+template <typename E, int GROUP, int ROWS, int MODE, int CZ, int VB>
+__device__ __forceinline__ void warp_finish(const WarpSrc<E, GROUP, ROWS, (VB / (int)sizeof(E)) / GROUP>& S, const float s12t, const float s21t,
+                                            E* __restrict__ out, const int So, const int nrows, const Levels& lv) {
+    typedef unsigned nt_vec __attribute__((ext_vector_type(VB / 4)));
+    warp_finish_to<E, GROUP, ROWS, MODE, CZ, VB>(S, s12t, s21t, nrows, lv,
+                                                 [&](const int r, const E* v) { __builtin_nontemporal_store(*(const nt_vec*)v, (nt_vec*)(out + (size_t)r * So)); });
+}
 
 template <typename E, int GROUP, int ROWS, int MODE, int CZ, int VB, bool DW>
 __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a, int cy0, int cx0, int ti0, int ti1) {
@@ -572,6 +576,7 @@ __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a,
     for (int k = 0; k < NG; k++) {
         const int cx = cx0 + k * GROUP;
         const int lx = CZ ? ((cx >> rs) & ~1) : (cx >> rs);
+        HF_DBG_CHECK(lx >= 0 && ly >= 0 && lx < lw && ly < lh, 203);
         const uint32_t f12 = a.flow_xy[(size_t)ly * lw + lx];
         ox12[k] = (int)(int16_t)(f12 & 0xFFFFu); oy12[k] = (int)(int16_t)(f12 >> 16);
         const int py = clampi(ly - (oy12[k] >> rs), 0, lh - 1);
@@ -637,14 +642,14 @@ __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a,
 #pragma unroll
             for (int r = 0; r < ROWS; r++) {
                 if (need_a) {
-                    const Run<E, VEC> w = get_run_buf<E, VEC, CZ>(rsrcA, oa + (r ? row1 : 0u), (unsigned)xa[0] & 1u);
+                    const Run<E, VEC> w = get_run_buf<E, VEC, CZ>(rsrcA, oa + (r ? row1 : 0u), (unsigned)xa[0] & 1u, plane_bytes);
 #pragma unroll
                     for (int k = 0; k < NG; k++)
 #pragma unroll
                         for (int i = 0; i < GROUP; i++) S.ra[r][k].v[i] = w.v[k * GROUP + i];
                 }
                 if (need_b) {
-                    const Run<E, VEC> w = get_run_buf<E, VEC, CZ>(rsrcB, ob + (r ? row1 : 0u), (unsigned)xb[0] & 1u);
+                    const Run<E, VEC> w = get_run_buf<E, VEC, CZ>(rsrcB, ob + (r ? row1 : 0u), (unsigned)xb[0] & 1u, plane_bytes);
 #pragma unroll
                     for (int k = 0; k < NG; k++)
 #pragma unroll
@@ -658,8 +663,8 @@ __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a,
                 const unsigned ob = __umul24((unsigned)(cy0 + dyb[k]), pitch_b) + (unsigned)(CZ ? (xb[k] & ~1) : xb[k]) * (unsigned)sizeof(E);
 #pragma unroll
                 for (int r = 0; r < ROWS; r++) {
-                    if (need_a) S.ra[r][k] = get_run_buf<E, GROUP, CZ>(rsrcA, oa + (r ? row1 : 0u), (unsigned)xa[k] & 1u);
-                    if (need_b) S.rb[r][k] = get_run_buf<E, GROUP, CZ>(rsrcB, ob + (r ? row1 : 0u), (unsigned)xb[k] & 1u);
+                    if (need_a) S.ra[r][k] = get_run_buf<E, GROUP, CZ>(rsrcA, oa + (r ? row1 : 0u), (unsigned)xa[k] & 1u, plane_bytes);
+                    if (need_b) S.rb[r][k] = get_run_buf<E, GROUP, CZ>(rsrcB, ob + (r ? row1 : 0u), (unsigned)xb[k] & 1u, plane_bytes);
                 }
             }
         }
@@ -914,6 +919,7 @@ __device__ __forceinline__ void warp_wg_body(const Geom& g, const WarpArgs& a, c
         if (it_ok && cell_x0 < W && cell_y0 < dim_y) {                          // (cells past the plane's end belong to waves without a tile)
             const int ly = min(CZ ? ((cell_y0 >> rs) << 1) : (cell_y0 >> rs), lh - 1);
             const int lx = min(CZ ? ((cell_x0 >> rs) & ~1) : (cell_x0 >> rs), lw - 1);
+            HF_DBG_CHECK(lx >= 0 && ly >= 0 && cell < kWgCells, 210);
             const uint32_t f12 = a.flow_xy[(size_t)ly * lw + lx];
             const int ox12 = (int)(int16_t)(f12 & 0xFFFFu), oy12 = (int)(int16_t)(f12 >> 16);
             const int py = clampi(ly - (oy12 >> rs), 0, lh - 1), px = clampi(lx - (ox12 >> rs), 0, lw - 1);
@@ -991,6 +997,7 @@ __device__ __forceinline__ void warp_wg_body(const Geom& g, const WarpArgs& a, c
     // this lane's own word and cell: run of output j in source A = base + tab[j][ci].x (row << 16 | byte offset, biased; chroma: bit 0 = dx odd)
     const uint32_t base = ((uint32_t)(cy0 + kExtY) << 16) | (uint32_t)((cx0 + kExtX) * SZ);
     const int ci = (((cy0 - ty0) >> rs) << lgx) | ((cx0 - tx0) >> lcw);
+    HF_DBG_CHECK(!wg_ok || (ci >= 0 && ci < kWgCells), 211);
     if (!wg_ok) {   // workgroup-uniform: no barrier follows
         if (runs_ok && wg_in && full) {
             // every run of the workgroup is interior, only its window does not fit (fast or diverging motion): the global path straight
@@ -1009,14 +1016,14 @@ __device__ __forceinline__ void warp_wg_body(const Geom& g, const WarpArgs& a, c
                     const unsigned o = __umul24((w >> 16) - kExtY, pitch_g) + (CZ ? (wb & ~1u) : wb) - (unsigned)(kExtX * SZ);
                     HF_DBG_CHECK((o & ~3u) + 4u * (NDW + 1) + (ROWS - 1) * pitch_g <= plane_g, 10);
 #pragma unroll
-                    for (int r = 0; r < ROWS; r++) S.ra[r][0] = get_run_buf<E, VEC, CZ>(rsrcA, o + (unsigned)r * pitch_g, odd);
+                    for (int r = 0; r < ROWS; r++) S.ra[r][0] = get_run_buf<E, VEC, CZ>(rsrcA, o + (unsigned)r * pitch_g, odd, plane_g);
                 }
                 if (need_b) {
                     const uint32_t w = base + d.y, wb = w & 0xFFFFu, odd = CZ ? (wb & 1u) : 0u;
                     const unsigned o = __umul24((w >> 16) - kExtY, pitch_g) + (CZ ? (wb & ~1u) : wb) - (unsigned)(kExtX * SZ);
                     HF_DBG_CHECK((o & ~3u) + 4u * (NDW + 1) + (ROWS - 1) * pitch_g <= plane_g, 11);
 #pragma unroll
-                    for (int r = 0; r < ROWS; r++) S.rb[r][0] = get_run_buf<E, VEC, CZ>(rsrcB, o + (unsigned)r * pitch_g, odd);
+                    for (int r = 0; r < ROWS; r++) S.rb[r][0] = get_run_buf<E, VEC, CZ>(rsrcB, o + (unsigned)r * pitch_g, odd, plane_g);
                 }
                 warp_finish<E, VEC, ROWS, MODE, CZ, 16>(S, a.s12v[j], a.s21v[j], (E*)a.outv[j] + out_g, So, ROWS, lvg);
             }
@@ -1047,6 +1054,7 @@ __device__ __forceinline__ void warp_wg_body(const Geom& g, const WarpArgs& a, c
                 // (chunks past the window's end land behind it inside the window's LDS share; reads past the plane return 0)
                 if (wg_in) {   // the window lies where mirrorCoordinate is the identity: a rectangle of the plane
                     const unsigned off = __umul24((unsigned)(ymin - kExtY) + row, pitch_b) + ((unsigned)cmin + col) * 16u - (unsigned)(kExtX * SZ);
+                    HF_DBG_CHECK(q >= (unsigned)nq || (size_t)off + 16 <= (size_t)plane_bytes, 212);   // (only the padding chunks behind the window may lie past the plane: they read as 0)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(win + (size_t)q0 * 16), 16, off, 0, 0, 0);
                 } else {       // a tile at the frame edge: rows fold back as whole rows; a chunk that touches the left / right mirror zone is
                                // gathered element by element (a reflected run is reversed) -- once per period, not once per output and row
@@ -1055,6 +1063,7 @@ __device__ __forceinline__ void warp_wg_body(const Geom& g, const WarpArgs& a, c
                     const unsigned rowoff = __umul24((unsigned)y, pitch_b);
                     const bool zone = x0 < 1 || (!CZ && x0 + VEC - 1 > W - 2);  // (chroma: only runs left of the right zone are staged)
                     if (!zone) {
+                        HF_DBG_CHECK(q >= (unsigned)nq || (size_t)rowoff + (size_t)(x0 * SZ) + 16 <= (size_t)plane_bytes, 213);
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(win + (size_t)q0 * 16), 16, rowoff + (unsigned)(x0 * SZ), 0, 0, 0);
                     } else {
                         __attribute__((aligned(16))) E v[VEC];
@@ -1095,10 +1104,16 @@ __device__ __forceinline__ void warp_wg_body(const Geom& g, const WarpArgs& a, c
     const unsigned rowb_a = (unsigned)C_a * 16u, rowb_b = (unsigned)C_b * 16u;
     const unsigned char* const win_a = lds - (unsigned)(ymin_a * C_a + cmin_a) * 16u;           // (pointer arithmetic only: never dereferenced below lds)
     const unsigned char* const win_b = lds + CHUNKS * 16 - (unsigned)(ymin_b * C_b + cmin_b) * 16u;
-    const size_t out_off = (size_t)CZ * H * So + (size_t)cy0 * So + cx0;
-#pragma unroll
-    for (int j = 0; j < kMaxWarpOutputs; j++) {
-        if (j < n) {
+    // Output stores: BUFFER stores -- the frame's descriptor in scalar registers, ONE 32-bit offset per lane for all outputs and rows (the
+    // row pitch rides in the scalar offset) -- instead of 64-bit flat addresses rebuilt on the vector ALU for every store.  The loop over
+    // the outputs is NOT unrolled: the run table in LDS made the loop body independent of j (round 3 indexed register arrays with it), and
+    // five copies of it were most of the kernel's 60 KB of code.
+    const unsigned out_off = (unsigned)(((size_t)CZ * H * So + (size_t)cy0 * So + cx0) * SZ);
+    const unsigned out_pitch = (unsigned)So * (unsigned)SZ;
+    const int out_bytes = (int)((size_t)(H + (H >> 1)) * So * SZ);
+#pragma unroll 1
+    for (int j = 0; j < n; j++) {
+        {
             Src S;
             const uint2 d = sh.tab[j][ci];
             if (need_a) {
@@ -1115,8 +1130,10 @@ __device__ __forceinline__ void warp_wg_body(const Geom& g, const WarpArgs& a, c
 #pragma unroll
                 for (int r = 0; r < ROWS; r++) S.rb[r][0] = lds_run(p + (unsigned)r * rowb_b, off, odd);
             }
-            E* __restrict__ out = (E*)a.outv[j] + out_off;
-            warp_finish<E, VEC, ROWS, MODE, CZ, 16>(S, a.s12v[j], a.s21v[j], out, So, ROWS, lv);
+            const __amdgpu_buffer_rsrc_t rsrc_out = __builtin_amdgcn_make_buffer_rsrc(a.outv[j], 0, out_bytes, 0x00020000);
+            warp_finish_to<E, VEC, ROWS, MODE, CZ, 16>(S, a.s12v[j], a.s21v[j], ROWS, lv, [&](const int r, const E* v) {
+                __builtin_amdgcn_raw_buffer_store_b128(*(const buf_v4*)v, rsrc_out, out_off, (unsigned)r * out_pitch, 2 /* nt: streaming */);
+            });
         }
     }
 }
@@ -1126,7 +1143,11 @@ __device__ __forceinline__ void warp_wg_body(const Geom& g, const WarpArgs& a, c
 // 16-byte loads and stores) for every member that asks (WarpArgs::plane21), placed right in front of the warp workgroups of the same
 // picture rows: the frame's rows are fetched from HBM once for both, and the stand-alone plane kernel with its 25 MB re-read of the
 // frame is not launched (prep_grid_kernel supplies the grid samples the chain of THIS period needs).
-struct PlaneOut { PhaseLayout pl; int blocks; };   // blocks: plane-building workgroups per super row (0: the launch builds no planes)
+struct PlaneOut {
+    PhaseLayout pl;
+    int blocks;                          // plane-building workgroups per super row (0: the launch builds no planes)
+    FastDiv per_member, per_sr, wpr;     // unit index -> (member, super row, block): scalar divisions (hf_kernels.h)
+};
 
 // Block order per member: "super rows" = [plane-building blocks,] two luma block rows, then the chroma block row of the same
 // picture region (a chroma block of NW stacked tiles spans twice the picture rows of a luma block), so that a region's luma and
@@ -1156,11 +1177,11 @@ __global__ __launch_bounds__(64 * NW) HF_WG_OCC void warp_wg_kernel(const Geom g
     const int n_blocks = wg_blocks_per_member(wpr, yb, ub, po.blocks);
     const int total = n_blocks * batch.n;
     const int per_band = (total + 7) >> 3;                                     // contiguous bands of units per XCD, as in warp_fast_kernel
-    const int u = (blockIdx.x & 7) * per_band + (blockIdx.x >> 3);
+    const int u = (int)(blockIdx.x & 7) * per_band + (int)(blockIdx.x >> 3);
     if (u >= total) return;
-    const int member = u / n_blocks, blk = u - member * n_blocks;
+    const int member = (int)fastdiv((uint32_t)u, po.per_member), blk = u - member * n_blocks;
     const WarpArgs& a = batch.s[member];
-    const int srow = blk / per_sr;
+    const int srow = (int)fastdiv((uint32_t)blk, po.per_sr);
     int r = blk - srow * per_sr;
     if (r < po.blocks) {   // plane-building block: the chroma rows (= luma row pairs) of this super row x groups of 4 grid columns
         if (!a.plane21) return;
@@ -1175,7 +1196,7 @@ __global__ __launch_bounds__(64 * NW) HF_WG_OCC void warp_wg_kernel(const Geom g
         return;
     }
     r -= po.blocks;
-    const int k = r / wpr, tcol = r - k * wpr;
+    const int k = (int)fastdiv((uint32_t)r, po.wpr), tcol = r - k * wpr;
     const bool chroma = k == 2;
     const int brow = chroma ? srow : 2 * srow + k;
     if (brow >= (chroma ? ub : yb)) return;
@@ -1211,6 +1232,13 @@ __global__ __launch_bounds__(256) void copy_kernel(const Geom g, const E* __rest
         for (int i = 0; i < VEC && cx0 + i < g.W; i++)
             d[i] = (E)(cz ? levels_uv<E>((float)s[i], lv) : levels_y<E>((float)s[i], lv));
     }
+}
+
+// hf_debug_bounds_selftest: one deliberately out-of-range "index" -- the debug build must trap on it, the product build compiles the check away
+__global__ void bounds_selftest_kernel(const int* limit, int* out) {
+    const int i = (int)threadIdx.x + 64;
+    HF_DBG_CHECK(i < *limit, 999);
+    out[threadIdx.x] = i;
 }
 
 __global__ void rcp_probe_kernel(const float* in, float* out, int n) {
@@ -1311,10 +1339,14 @@ static bool launch_warp_fast(const Geom& g, const WarpBatchArgs& b, hipStream_t 
 #ifndef HF_WARP_WG_MIN_WAVES
 #define HF_WARP_WG_MIN_WAVES (4 * 8192)
 #endif
-    if constexpr (VB == 16) if (group == VEC && dw && out_chunk > 1 && max_out >= 2 && (long)n_tiles * b.n >= HF_WARP_WG_MIN_WAVES) {
-        constexpr int WR = HF_WARP_WG_ROWS, NW = HF_WARP_WG * 2 / WR;          // rows per thread, waves per workgroup (tile height HF_WARP_WG x 8 rows)
-        const int y_groups_w = (g.H + WR - 1) / WR, uv_groups_w = ((g.H >> 1) + WR - 1) / WR;
-        const int y_tiles_ = (y_groups_w + kWarpTY - 1) / kWarpTY, uv_tiles_ = (uv_groups_w + kWarpTY - 1) / kWarpTY;
+    constexpr int WR = HF_WARP_WG_ROWS, NW = HF_WARP_WG * 2 / WR;              // rows per thread, waves per workgroup (tile height HF_WARP_WG x 8 rows)
+    const int y_tiles_ = (((g.H + WR - 1) / WR) + kWarpTY - 1) / kWarpTY, uv_tiles_ = ((((g.H >> 1) + WR - 1) / WR) + kWarpTY - 1) / kWarpTY;
+    const int plane_blocks = ((g.lw >> 2) * (2 * NW * kWarpTY * WR) + 64 * NW - 1) / (64 * NW);   // (groups of 4 columns) x (luma rows of a super row) tasks
+    // (its workgroups decode their unit index with scalar multiply-high divisions, exact while units x blocks per member < 2^32: frames
+    //  far beyond 8K take the generic launch below)
+    const uint32_t nb_max = (uint32_t)wg_blocks_per_member(wpr, (y_tiles_ + NW - 1) / NW, (uv_tiles_ + NW - 1) / NW, plane_blocks);
+    if constexpr (VB == 16) if (group == VEC && dw && out_chunk > 1 && max_out >= 2 && (long)n_tiles * b.n >= HF_WARP_WG_MIN_WAVES &&
+                                fastdiv_exact((uint64_t)nb_max * b.n + 8, nb_max)) {
         // deferred phase planes: members that ask for one (plane21) get it from this launch if geometry and alignment allow
         WarpBatchArgs bb = b;
         PlaneOut po{};
@@ -1326,9 +1358,10 @@ static bool launch_warp_fast(const Geom& g, const WarpBatchArgs& b, hipStream_t 
         if (planes_built) for (int m = 0; m < bb.n; m++) planes_built[m] = bb.s[m].plane21 != nullptr;
         if (emit) {
             po.pl = *pl;
-            po.blocks = ((g.lw >> 2) * (2 * NW * kWarpTY * WR) + 64 * NW - 1) / (64 * NW);   // (groups of 4 columns) x (luma rows of a super row) tasks
+            po.blocks = plane_blocks;
         }
         const int nb = wg_blocks_per_member(wpr, (y_tiles_ + NW - 1) / NW, (uv_tiles_ + NW - 1) / NW, po.blocks);
+        po.per_member = make_fastdiv((uint32_t)nb); po.per_sr = make_fastdiv((uint32_t)(wpr * 3 + po.blocks)); po.wpr = make_fastdiv((uint32_t)wpr);
         const dim3 wg(((nb * b.n + 7) / 8) * 8), wb(64 * NW);
         const size_t lds_bytes = (size_t)2 * wg_chunks(NW * WR / 2) * 16;
 #define HF_WARP_WG_LAUNCH(M)                                                                                                                  \
@@ -1472,6 +1505,26 @@ static void launch_copy_t(const Geom& g, const void* src, void* out, float black
 void launch_copy(const Geom& g, const void* src, void* out, float black, float white, hipStream_t stream) {
     if (g.hdr) launch_copy_t<uint16_t>(g, src, out, black, white, stream);
     else launch_copy_t<uint8_t>(g, src, out, black, white, stream);
+}
+
+void launch_bounds_selftest(int* scratch, hipStream_t stream) {
+    const int limit = 64;                            // lanes hold 64 .. 127: every one violates "i < 64"
+    if (hipMemcpyAsync(scratch, &limit, sizeof(int), hipMemcpyHostToDevice, stream) != hipSuccess) return;
+    bounds_selftest_kernel<<<1, 64, 0, stream>>>(scratch, scratch + 1);
+}
+
+bool dbg_bounds_read_kernels(unsigned out[5], bool reset) {
+#ifdef HF_DEBUG_BOUNDS
+    unsigned rec[5] = {0, 0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(rec, HIP_SYMBOL(g_dbg_bounds), sizeof(rec)) != hipSuccess) return false;
+    if (rec[0] && !out[0]) for (int i = 1; i < 5; i++) out[i] = rec[i];
+    out[0] += rec[0];
+    if (reset) { const unsigned zero[5] = {0, 0, 0, 0, 0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_bounds), zero, sizeof(zero)); }
+    return true;
+#else
+    (void)out; (void)reset;
+    return false;
+#endif
 }
 
 void launch_rcp_probe(const float* in, float* out, int n, hipStream_t stream) {

@@ -34,6 +34,7 @@ __device__ __forceinline__ void plane_fast_task(const E* __restrict__ f, uint32_
     constexpr int NPH2 = NPH > 1 ? NPH / 2 : 1;
     const int lw = W >> RS;
     if (4 * t >= lw) return;
+    HF_DBG_CHECK(2 * m + z0 + NZ <= H && 2 * m < H && (size_t)(t + 1) * NE <= (size_t)S && ((size_t)(2 * m + z0 + NZ) * NPH2 * pl.lwp) * 4 <= pl.bytes, 120);
     __attribute__((aligned(16))) E e[NZ + 1][NE];            // luma row(s) 2m + z0 .., chroma row m (last)
 #pragma unroll
     for (int z = 0; z <= NZ; z++) {

@@ -261,6 +261,15 @@ int hf_write_blurred_flow(hf_ctx* ctx, int idx, const int16_t* host_in);
  * plane holds only its grid samples so far (deferred build, hf_batch_run_period). */
 int hf_read_phase_plane(hf_ctx* ctx, int ring_slot, void* host_out, int* complete);
 
+/* Device debug build (`python -m hopperrender_amd.build --debug-bounds` -> libhopperflow_dbg.so, -DHF_DEBUG_BOUNDS): every gather index of
+ * the kernels -- frame, phase-plane, flow-table and LDS-window reads -- is checked against its buffer and violations are recorded on the
+ * device (the only device-side memory check there can be where GPU AddressSanitizer is unavailable; the reference's own out-of-range
+ * case is the single reflection of calcDeltaSumsKernelSDR.h:86-95).  hf_debug_bounds_violations synchronises the device and returns the
+ * number of violations since the last reset and site / block / thread / source line of the first; hf_debug_bounds_selftest issues 64
+ * out-of-range indices (site 999) and checks that exactly those were recorded.  Both return HF_ERR_STATE in the product build, which
+ * compiles the checks away. */
+int hf_debug_bounds_violations(hf_ctx* ctx, uint32_t* count, uint32_t first[4], int reset);
+int hf_debug_bounds_selftest(hf_ctx* ctx);
 /* v_rcp_f32 of the device for n <= 32 values.  The reference's apply_levels* divide through it when
  * built by AMD OpenCL (x / y -> x * rcp(y)); CPU checkers use this to reproduce levels bit-exactly. */
 int hf_device_rcp(hf_ctx* ctx, const float* host_in, float* host_out, int n);

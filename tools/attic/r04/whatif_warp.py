@@ -56,6 +56,20 @@ V["noconf"] = lambda s: sub(s, """        const uint32_t* p = (const uint32_t*)p
 #pragma unroll
         for (int k = 0; k <= NDW; k++) w[k] = p[64 * k];""")
 
+# ONE flow round trip: the second (dependent) lookup takes the value of the first
+V["f21"] = lambda s: sub(s, "            const uint32_t f21 = a.flow_xy[(size_t)py * lw + px];", "            const uint32_t f21 = n == 77 ? a.flow_xy[(size_t)py * lw + px] : f12 ^ (uint32_t)(px + py);")
+# both lookups made, displacements forced to zero (windows = the tile, no motion)
+V["zero"] = lambda s: sub(sub(s, "            const int ox12 = (int)(int16_t)(f12 & 0xFFFFu), oy12 = (int)(int16_t)(f12 >> 16);\n            const int py = clampi(ly - (oy12 >> rs), 0, lh - 1), px",
+                                 "            const int keep = n == 77 ? 1 : 0;\n            const int ox12 = keep * (int)(int16_t)(f12 & 0xFFFFu), oy12 = keep * (int)(int16_t)(f12 >> 16);\n            const int py = clampi(ly - ((int)(int16_t)(f12 >> 16) >> rs), 0, lh - 1), px"),
+                          "            const int ox21 = (int)(int16_t)(f21 & 0xFFFFu), oy21 = (int)(int16_t)(f21 >> 16);", "            const int ox21 = keep * (int)(int16_t)(f21 & 0xFFFFu), oy21 = keep * (int)(int16_t)(f21 >> 16);")
+# every output store goes to one 1 MB window of its frame (L2-resident): the store INSTRUCTIONS without the HBM writes
+V["st1m"] = lambda s: sub(s, "    const size_t out_off = (size_t)CZ * H * So + (size_t)cy0 * So + cx0;\n#pragma unroll\n    for (int j = 0; j < kMaxWarpOutputs; j++) {",
+                          "    const size_t out_off = ((size_t)CZ * H * So + (size_t)cy0 * So + cx0) & (size_t)0x7FFF8;\n#pragma unroll\n    for (int j = 0; j < kMaxWarpOutputs; j++) {")
+
+# the blend is computed but (almost) no store executes: the predicate depends on the blended data (v2 kernel: buffer stores)
+V["stpred"] = lambda s: sub(s, "                __builtin_amdgcn_raw_buffer_store_b128(*(const buf_v4*)v, rsrc_out, out_off, (unsigned)r * out_pitch, 2 /* nt: streaming */);",
+                            "                if (((const uint32_t*)v)[0] == 0x12345679u && ((const uint32_t*)v)[3] == 0x9abcdef1u) __builtin_amdgcn_raw_buffer_store_b128(*(const buf_v4*)v, rsrc_out, out_off, (unsigned)r * out_pitch, 2);")
+# the stores execute, the blend does not (XOR of the two runs), LDS reads kept -- with "noblend" this separates arithmetic from stores
 def build(name):
     d = os.path.join(R, "hopperrender_amd/lib/exp", "w_" + name); os.makedirs(d, exist_ok=True)
     src = os.path.join(d, "hf_kernels.hip")

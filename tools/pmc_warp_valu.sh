@@ -13,7 +13,7 @@ import sys
 d={}
 for l in sys.stdin:
     p=l.split()
-    if len(p)>=3 and p[-1].startswith('mean='): d[p[0]]=float(p[-1][5:])
+    if len(p)>=3 and "mean=" in l: d[p[0]]=float(l.split("mean=")[1])
 w=d.get('SQ_WAVES',1)
 print('  waves %d  per wave: VALU %.0f SALU %.0f LDS %.1f VMEM_RD %.1f VMEM_WR %.1f   VALU busy %.0f %% of the launch (4 cycles per instruction, 1024 SIMDs, GRBM_GUI_ACTIVE summed over 8 XCDs)' % (w, d.get('SQ_INSTS_VALU',0)/w, d.get('SQ_INSTS_SALU',0)/w, d.get('SQ_INSTS_LDS',0)/w, d.get('SQ_INSTS_VMEM_RD',0)/w, d.get('SQ_INSTS_VMEM_WR',0)/w, 100*d.get('SQ_ACTIVE_INST_VALU',0)*4/1024/(d.get('GRBM_GUI_ACTIVE',1)/8)))"
 done
