@@ -21,8 +21,8 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
              "-Wall", "-Wno-unused-function"]
 
-FLOW_SOURCES = ("hf_kernels.hip", "hf_flow.hip", "hf_capi.hip", "hf_filter.cpp", "hf_hostio.cpp")
-FLOW_HEADERS = ("hf_kernels.h", "hf_phase_plane.h")
+FLOW_SOURCES = ("hf_kernels.hip", "hf_flow.hip", "hf_context.hip", "hf_calc.hip", "hf_batch.hip", "hf_async_io.hip", "hf_filter.cpp", "hf_hostio.cpp")
+FLOW_HEADERS = ("hf_kernels.h", "hf_phase_plane.h", "hf_ctx.h")
 LIB_FLOW = os.path.join(LIBDIR, "libhopperflow.so")
 LIB_FLOW_DEBUG = os.path.join(LIBDIR, "libhopperflow_dbg.so")   # --debug-bounds: -DHF_DEBUG_BOUNDS, every gather index checked on the device
 LIB_ADAPTER = os.path.join(LIBDIR, "libopticalflowcalc.so")

@@ -94,9 +94,18 @@ __global__ __launch_bounds__(128) void prep_phase_fast_kernel(const PrepBatch ba
 // ------------------------------------------------------------------------------------------
 // per-window constants
 // ------------------------------------------------------------------------------------------
+// The four neighbour offsets of a window as two packed pairs of 16-bit values biased by 0x8000 (unsigned order = signed order), so that
+// the neighbour term of a candidate -- four |neighbour - candidate| -- is two v_sad_u16 against the packed candidate.
+struct NbPacked { uint32_t n01, n23; };
+__device__ __forceinline__ NbPacked pack_nb(const int* nb) {
+    NbPacked p;
+    p.n01 = (((uint32_t)nb[0] + 0x8000u) & 0xFFFFu) | (((uint32_t)nb[1] + 0x8000u) << 16);
+    p.n23 = (((uint32_t)nb[2] + 0x8000u) & 0xFFFFu) | (((uint32_t)nb[3] + 0x8000u) << 16);
+    return p;
+}
 struct WinConst {
     int ox, oy;                 // offsets of this window before the level's update
-    int nbx[4], nby[4];         // neighbour offsets (previous level) for the X and the Y step
+    NbPacked nbx, nby;          // neighbour offsets (previous level) for the X and the Y step
     uint32_t npix;              // grid pixels of the window that lie inside the grid
 };
 
@@ -112,8 +121,7 @@ __device__ __forceinline__ WinConst load_win_const(const Geom& g, const FlowStep
     const int ws = a.cur.window;
     const int x0 = wx << a.cur.log2w, y0 = wy << a.cur.log2w;
     w.ox = w.oy = 0;
-#pragma unroll
-    for (int i = 0; i < 4; i++) { w.nbx[i] = 0; w.nby[i] = 0; }
+    int nbx[4] = {0, 0, 0, 0}, nby[4] = {0, 0, 0, 0};
     if (a.prev.tx) {
         w.ox = table_at(a.prev.tx, a.prev, x0, y0);
         w.oy = table_at(a.prev.ty, a.prev, x0, y0);
@@ -122,25 +130,26 @@ __device__ __forceinline__ WinConst load_win_const(const Geom& g, const FlowStep
             const int d = 2 * ws;
             const int xl = max(x0 - d, 0), xr = min(x0 + d, g.lw - 1);
             const int yu = max(y0 - d, 0), yd = min(y0 + d, g.lh - 1);
-            w.nbx[0] = table_at(a.prev.tx, a.prev, x0, yd); w.nby[0] = table_at(a.prev.ty, a.prev, x0, yd);
-            w.nbx[1] = table_at(a.prev.tx, a.prev, xr, y0); w.nby[1] = table_at(a.prev.ty, a.prev, xr, y0);
-            w.nbx[2] = table_at(a.prev.tx, a.prev, xl, y0); w.nby[2] = table_at(a.prev.ty, a.prev, xl, y0);
-            w.nbx[3] = table_at(a.prev.tx, a.prev, x0, yu); w.nby[3] = table_at(a.prev.ty, a.prev, x0, yu);
+            nbx[0] = table_at(a.prev.tx, a.prev, x0, yd); nby[0] = table_at(a.prev.ty, a.prev, x0, yd);
+            nbx[1] = table_at(a.prev.tx, a.prev, xr, y0); nby[1] = table_at(a.prev.ty, a.prev, xr, y0);
+            nbx[2] = table_at(a.prev.tx, a.prev, xl, y0); nby[2] = table_at(a.prev.ty, a.prev, xl, y0);
+            nbx[3] = table_at(a.prev.tx, a.prev, x0, yu); nby[3] = table_at(a.prev.ty, a.prev, x0, yu);
         }
     }
+    w.nbx = pack_nb(nbx); w.nby = pack_nb(nby);
     HF_DBG_CHECK(wx >= 0 && wy >= 0 && wx < a.cur.nwx && wy < a.cur.nwy, 101);
     if (use_cur_x) w.ox = a.cur.tx[wy * a.cur.nwx + wx];
     w.npix = (uint32_t)((min(g.lw, x0 + ws) - x0) * (min(g.lh, y0 + ws) - y0));
     return w;
 }
 
-// Per-window constant part of the cost of candidate offset `cand` (short arithmetic as in the reference).
-__device__ __forceinline__ uint32_t window_bias(int cand, bool use_nb, const int* nb, int nshift) {
+// Per-window constant part of the cost of candidate offset `cand` (short arithmetic as in the reference; |neighbour - candidate| of two
+// int16 values never exceeds 16 bits, so the packed unsigned form is exact).
+__device__ __forceinline__ uint32_t window_bias(int cand, bool use_nb, const NbPacked& nb, int nshift) {
     uint32_t c = (uint32_t)(cand < 0 ? -cand : cand) & 0xFFFFu;                   // offsetBias, :105-109
     if (use_nb) {
-        const uint32_t nbias = ((uint32_t)abs(nb[0] - cand) & 0xFFFFu) + ((uint32_t)abs(nb[1] - cand) & 0xFFFFu) +
-                               ((uint32_t)abs(nb[2] - cand) & 0xFFFFu) + ((uint32_t)abs(nb[3] - cand) & 0xFFFFu);
-        c += nbias << nshift;                                                     // :143
+        const uint32_t cu = ((uint32_t)cand + 0x8000u) & 0xFFFFu, cc = cu | (cu << 16);
+        c += __builtin_amdgcn_sad_u16(nb.n01, cc, __builtin_amdgcn_sad_u16(nb.n23, cc, 0u)) << nshift;   // :112-143
     }
     return c;
 }
@@ -216,9 +225,14 @@ __device__ __forceinline__ Elems<PX> buffer_elems(__amdgpu_buffer_rsrc_t rsrc, u
 // on the vector ALU at all (round 1: ~13 of the ~36 VALU instructions per candidate).  Otherwise it is per lane.
 // (The reference does this arithmetic in 16-bit, calcDeltaSumsKernelSDR.h:75-76; offsets are bounded by
 //  iterations * 64 + 64 < 2^15, so nothing ever wraps.)
+// CH: candidates whose loads are in flight together.  All 16 (64 registers of load data per lane) is what a chain that has the GPU to
+// itself wants; 8 lets a chain wave fit into the registers the period warp's five waves per SIMD leave free (72 of 512 per lane), so that
+// chain and warp launches of the two batch streams truly run side by side instead of taking turns at the wave slots.
+constexpr int kCandChunk = 8;
 template <int PX, bool UNI, bool FULL>
 __device__ __forceinline__ void strip_sads(uint32_t* sad, const Geom& g, const FlowStep& a, const Strip<PX>& s,
                                            int ox, int oy, int axis) {
+    constexpr int CH = kCandChunk;
     const PhaseLayout& pl = a.pl;
     const int sy = s.cy << g.rs;
     const bool ragged = !FULL && (g.lw & (PX - 1)) != 0;              // kernel-uniform: some strip hangs over the right grid edge
@@ -228,21 +242,42 @@ __device__ __forceinline__ void strip_sads(uint32_t* sad, const Geom& g, const F
     if (UNI) { ox = __builtin_amdgcn_readfirstlane(ox); oy = __builtin_amdgcn_readfirstlane(oy); }
     const int searched0 = axis ? oy : ox;
     const unsigned row_el = (unsigned)(pl.nph2 * pl.lwp);             // elements per full-res row
-    Elems<PX> c1[16];
-    uint32_t sel[16];
+    // One chunk of candidates: `fetch(cz, sel)` loads candidate cz's elements and names its byte selector; then the SADs.
+    auto run = [&](auto&& fetch) {
+#pragma unroll
+        for (int c0 = 0; c0 < 16; c0 += CH) {
+            Elems<PX> c1[CH];
+            uint32_t sel[CH];
+#pragma unroll
+            for (int k = 0; k < CH; k++) {
+                sel[k] = 0u;
+                if (c0 + k < R && any) c1[k] = fetch(c0 + k, sel[k]);     // R is uniform
+            }
+#pragma unroll
+            for (int k = 0; k < CH; k++) {
+                uint32_t t = sad[c0 + k];
+                if (c0 + k < R && any) {
+#pragma unroll
+                    for (int i = 0; i < PX; i++) {
+                        uint32_t v = __builtin_amdgcn_perm(c1[k].d[i], c1[k].d[i], sel[k]);
+                        if (ragged) v &= s.vm[i];
+                        t = __builtin_amdgcn_sad_u8(v, s.ref[i], t);
+                    }
+                }
+                sad[c0 + k] = t;
+            }
+        }
+    };
     if (!axis) {
         // (the margin mx goes into the window part: it keeps that part >= 0, as a scalar buffer offset has to be)
         const unsigned lane_off = (__umul24((unsigned)mirror_clamp(sy + oy, g.H), row_el) + (unsigned)s.cx0) * 4u;
-#pragma unroll
-        for (int cz = 0; cz < 16; cz++) {
-            if (cz < R && any) {                                  // R is uniform
-                const int c = searched0 + rel_offset(cz, R);
-                const int ph = c & (pl.nph - 1);
-                const unsigned coff = (unsigned)((ph >> 1) * pl.lwp + (c >> g.rs) + pl.mx) * 4u;
-                c1[cz] = UNI ? buffer_elems<PX>(rsrc, lane_off + 0u, coff, pl.bytes) : buffer_elems<PX>(rsrc, lane_off + coff, 0u, pl.bytes);
-                sel[cz] = 0x03020c00u | (unsigned)(ph & 1);           // v_perm_b32: luma byte of this phase, 0, U, V
-            }
-        }
+        run([&](const int cz, uint32_t& sel) {
+            const int c = searched0 + rel_offset(cz, R);
+            const int ph = c & (pl.nph - 1);
+            const unsigned coff = (unsigned)((ph >> 1) * pl.lwp + (c >> g.rs) + pl.mx) * 4u;
+            sel = 0x03020c00u | (unsigned)(ph & 1);                   // v_perm_b32: luma byte of this phase, 0, U, V
+            return UNI ? buffer_elems<PX>(rsrc, lane_off + 0u, coff, pl.bytes) : buffer_elems<PX>(rsrc, lane_off + coff, 0u, pl.bytes);
+        });
     } else {
         const int ph0 = ox & (pl.nph - 1);
         const unsigned col = (unsigned)((ph0 >> 1) * pl.lwp + pl.mx + s.cx0 + (ox >> g.rs));
@@ -252,37 +287,18 @@ __device__ __forceinline__ void strip_sads(uint32_t* sad, const Geom& g, const F
         const bool inside = !any || (sy + cmin >= 0 && sy + cmax <= g.H - 1);
         if (__builtin_amdgcn_ballot_w64(!inside) == 0) {
             const unsigned lane_off = (__umul24((unsigned)(sy + cmin), row_el) + col) * 4u;   // row of the lowest candidate
-#pragma unroll
-            for (int cz = 0; cz < 16; cz++) {
-                if (cz < R && any) {
-                    const unsigned coff = __umul24((unsigned)(rel_offset(cz, R) - rel_offset(0, R)), row_el) * 4u;   // >= 0, wave-uniform
-                    c1[cz] = buffer_elems<PX>(rsrc, lane_off, coff, pl.bytes);
-                    sel[cz] = selc;
-                }
-            }
+            run([&](const int cz, uint32_t& sel) {
+                const unsigned coff = __umul24((unsigned)(rel_offset(cz, R) - rel_offset(0, R)), row_el) * 4u;   // >= 0, wave-uniform
+                sel = selc;
+                return buffer_elems<PX>(rsrc, lane_off, coff, pl.bytes);
+            });
         } else {
-#pragma unroll
-            for (int cz = 0; cz < 16; cz++) {
-                if (cz < R && any) {
-                    const int ny = mirror_clamp(sy + searched0 + rel_offset(cz, R), g.H);
-                    c1[cz] = buffer_elems<PX>(rsrc, (__umul24((unsigned)ny, row_el) + col) * 4u, 0u, pl.bytes);
-                    sel[cz] = selc;
-                }
-            }
+            run([&](const int cz, uint32_t& sel) {
+                const int ny = mirror_clamp(sy + searched0 + rel_offset(cz, R), g.H);
+                sel = selc;
+                return buffer_elems<PX>(rsrc, (__umul24((unsigned)ny, row_el) + col) * 4u, 0u, pl.bytes);
+            });
         }
-    }
-#pragma unroll
-    for (int cz = 0; cz < 16; cz++) {
-        uint32_t t = sad[cz];
-        if (cz < R && any) {
-#pragma unroll
-            for (int i = 0; i < PX; i++) {
-                uint32_t v = __builtin_amdgcn_perm(c1[cz].d[i], c1[cz].d[i], sel[cz]);
-                if (ragged) v &= s.vm[i];
-                t = __builtin_amdgcn_sad_u8(v, s.ref[i], t);
-            }
-        }
-        sad[cz] = t;
     }
 }
 
@@ -382,7 +398,7 @@ __device__ __forceinline__ int group_reduce(uint32_t* sad, int lane) {
 // `captured` (optional) receives the full cost sum of candidate cap_cz.
 template <int G, bool FULL, int XM = 1>
 __device__ __forceinline__ int group_argmin(const uint32_t* tot, int first, const FlowStep& a, int searched0,
-                                            const int* nb, uint32_t npix, int cap_cz, bool want_cap, uint32_t& captured, int lane) {
+                                            const NbPacked& nb, uint32_t npix, int cap_cz, bool want_cap, uint32_t& captured, int lane) {
     const int R = FULL ? 16 : a.R;
     Best b{0xFFFFFFFFu, 16};
     uint32_t cap = 0;
@@ -392,7 +408,7 @@ __device__ __forceinline__ int group_argmin(const uint32_t* tot, int first, cons
         if (cz < R) {
             const int cand = (int)(int16_t)(searched0 + rel_offset(cz, R));
             const uint32_t sum = (tot[k] << a.delta_scalar) + npix * window_bias(cand, a.use_neighbors, nb, a.neighbor_scalar);
-            best_min(b, sum, cz);
+            if (k == 0 || sum < b.sum) { b.sum = sum; b.cz = cz; }   // ascending cz inside the lane: strict '<' keeps the first minimum (:19-24)
             if (cz == cap_cz) cap = sum;
         }
     }

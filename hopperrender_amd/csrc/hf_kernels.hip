@@ -165,48 +165,50 @@ __device__ __forceinline__ int mirror_warp(int pos, int dim) {  // warpFrameKern
     return min(max(res, 1), dim - 2);
 }
 
-// warpFrameKernelSDR.h:23-113 / HDR :23-113 -- diagnostic HSV visualisation (mode 3)
+// Diagnostic HSV view of the flow (output mode 3; semantics of warpFrameKernelSDR.h:23-113 / HDR :23-113): the direction of the
+// offset picks a fully saturated hue, its magnitude the brightness, and the result is mixed half-and-half with the blended luma.
+// A saturated hue wheel is one six-step ramp read at three rotations: at sextant k of the wheel a channel is
+//     wheel(k) = 255, falling, 0, 0, rising, 255        (k = 0 .. 5)
+// with red = wheel(k), green = wheel(k + 4), blue = wheel(k + 2) -- so the sextant is never branched on.
+__device__ __forceinline__ unsigned hue_wheel(int k, unsigned rising, unsigned falling) {
+    k = k >= 6 ? k - 6 : k;
+    return (k == 0 || k == 5) ? 255u : k == 1 ? falling : k == 4 ? rising : 0u;
+}
+__device__ __forceinline__ unsigned to_byte(float v) { return (unsigned)fmaxf(fminf(v, 255.0f), 0.0f) & 0xFFu; }
+
 template <typename E>
-__device__ unsigned visualize_flow(int ox_in, int oy_in, unsigned curr, int channel, int res_impact) {
+__device__ unsigned visualize_flow(int flow_x, int flow_y, unsigned blended, int channel, int gain) {
     using T = ElemTraits<E>;
-    const int16_t ox = (int16_t)ox_in, oy = (int16_t)oy_in;
-    unsigned r = 0, gch = 0, b = 0;
-    const unsigned ax = (unsigned)(ox < 0 ? -ox : ox) & 0xFFFFu, ay = (unsigned)(oy < 0 ? -oy : oy) & 0xFFFFu;
-    if (!((float)ax < 1.0f && (float)ay < 1.0f)) {
-        const float angle_rad = atan2f((float)oy, (float)ox);
-        float angle_deg = angle_rad * (180.0f / 3.14159274101257f);
-        if (angle_deg < 0) angle_deg += 360.0f;
-        angle_deg = fmodf(angle_deg, 360.0f);
-        if (angle_deg < 0) angle_deg += 360.0f;
-        const float hue = angle_deg / 360.0f;
-        const int h_i = (int)(hue * 6.0f);
-        const float f = hue * 6.0f - (float)h_i;
-        const float q = 1.0f - f;
-        switch (h_i % 6) {
-            case 0: r = 255; gch = (unsigned)(f * 255.0f) & 0xFFu; b = 0; break;
-            case 1: r = (unsigned)(q * 255.0f) & 0xFFu; gch = 255; b = 0; break;
-            case 2: r = 0; gch = 255; b = (unsigned)(f * 255.0f) & 0xFFu; break;
-            case 3: r = 0; gch = (unsigned)(q * 255.0f) & 0xFFu; b = 255; break;
-            case 4: r = (unsigned)(f * 255.0f) & 0xFFu; gch = 0; b = 255; break;
-            case 5: r = 255; gch = 0; b = (unsigned)(q * 255.0f) & 0xFFu; break;
-            default: break;
-        }
-        const int mag = (int)ax + (int)ay;
-        r = (unsigned)fmaxf(fminf((float)r / 255.0f * (float)mag * (float)res_impact, 255.0f), 0.0f) & 0xFFu;
-        gch = (unsigned)fmaxf(fminf((float)gch / 255.0f * (float)ay * 2.0f * (float)res_impact, 255.0f), 0.0f) & 0xFFu;
-        b = (unsigned)fmaxf(fminf((float)b / 255.0f * (float)mag * (float)res_impact, 255.0f), 0.0f) & 0xFFu;
+    const int16_t vx = (int16_t)flow_x, vy = (int16_t)flow_y;
+    const unsigned mag_x = (unsigned)(vx < 0 ? -vx : vx) & 0xFFFFu, mag_y = (unsigned)(vy < 0 ? -vy : vy) & 0xFFFFu;
+    unsigned rgb[3] = {0u, 0u, 0u};
+    if (mag_x != 0u || mag_y != 0u) {                         // (a zero offset stays black)
+        float deg = atan2f((float)vy, (float)vx) * (180.0f / 3.14159274101257f);
+        if (deg < 0) deg += 360.0f;
+        deg = fmodf(deg, 360.0f);
+        if (deg < 0) deg += 360.0f;
+        const float wheel_pos = deg / 360.0f * 6.0f;          // 0 .. 6 around the hue wheel
+        const int sextant = (int)wheel_pos;
+        const float frac = wheel_pos - (float)sextant;
+        const unsigned rising = (unsigned)(frac * 255.0f) & 0xFFu, falling = (unsigned)((1.0f - frac) * 255.0f) & 0xFFu;
+        const int k = sextant % 6;
+        // brightness: red and blue scale with |x| + |y|, green with twice |y| (the reference's weights)
+        const float scale[3] = {(float)((int)mag_x + (int)mag_y), (float)mag_y * 2.0f, (float)((int)mag_x + (int)mag_y)};
+        const int rot[3] = {0, 4, 2};
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+            rgb[c] = to_byte((float)hue_wheel(k + rot[c], rising, falling) / 255.0f * scale[c] * (float)gain);
     }
-    const float fr = (float)r, fg = (float)gch, fb = (float)b;
-    if (channel == 0) {
+    const float fr = (float)rgb[0], fg = (float)rgb[1], fb = (float)rgb[2];
+    if (channel == 0) {                                       // BT.601 luma of the colour, averaged with the blended picture
         const unsigned y = (unsigned)fmaxf(fminf(fr * 0.299f + fg * 0.587f + fb * 0.114f, 255.0f), 0.0f);
-        if (T::hdr) return (((y & 0xFFFFu) << 7) + (curr >> 1)) & 0xFFFFu;
-        return (((y & 0xFFu) >> 1) + ((curr & 0xFFu) >> 1)) & 0xFFu;
+        if (T::hdr) return (((y & 0xFFFFu) << 7) + (blended >> 1)) & 0xFFFFu;
+        return (((y & 0xFFu) >> 1) + ((blended & 0xFFu) >> 1)) & 0xFFu;
     }
-    float c;
-    if (channel == 1) c = fmaxf(fminf(fr * -0.168736f + fg * -0.331264f + fb * 0.5f + 128.0f, 255.0f), 0.0f);
-    else c = fmaxf(fminf(fr * 0.5f + fg * -0.418688f + fb * -0.081312f + 128.0f, 255.0f), 0.0f);
-    if (T::hdr) return (((unsigned)c & 0xFFFFu) << 8) & 0xFFFFu;
-    return (unsigned)c & 0xFFu;
+    const float chroma = channel == 1 ? fr * -0.168736f + fg * -0.331264f + fb * 0.5f + 128.0f
+                                      : fr * 0.5f + fg * -0.418688f + fb * -0.081312f + 128.0f;
+    const unsigned cb = (unsigned)fmaxf(fminf(chroma, 255.0f), 0.0f);
+    return T::hdr ? ((cb & 0xFFFFu) << 8) & 0xFFFFu : cb & 0xFFu;
 }
 
 struct WarpArgs {
@@ -829,19 +831,16 @@ __global__ __launch_bounds__(64 * warp_max_waves(sizeof(E), GROUP, VB)) void war
 // (per wave: 1.55 x).  The window is found per workgroup (per-wave min / max over lanes and outputs of the runs' 16-byte chunks
 // and rows -- packed 16-bit DPP butterfly -- combined through LDS); workgroups whose runs do not fit the LDS budget (fast or
 // diverging motion), touch the mirror zone or contain a partial wave take the global path (warp_fast_body): same results.
-#ifndef HF_WARP_WG
-#define HF_WARP_WG 4   // waves (= vertically stacked wave tiles) per workgroup; 0 = off.  Measured, 2160p HDR pipeline (2 batch streams of
-                       // 16), k frames/s: 68.8-70.0 off, 71.9-72.5 / 72.9-73.4 / 73.9-74.1 / 66.7-67.8 / 61.3 with 2 / 3 / 4 / 6 / 16 waves
-#endif
-#ifndef HF_WARP_WG_CPW
-#define HF_WARP_WG_CPW 192
-#endif
-#ifndef HF_WARP_WG_ROWS
-#define HF_WARP_WG_ROWS 2   // rows per thread in the staged kernel (4: half the waves, HF_WARP_WG / 2 waves per workgroup, same tile; bit-exact,
-                            // alone 672 vs 663 us per 16 members, pipeline 69.4 vs 72.4 k frames/s: the other stream's chain waits longer
-                            // for the fewer, longer waves -- 52 vs 37 us per pair)
-#endif
-constexpr int wg_chunks(int nw) { return nw >= 16 ? nw * 160 : nw * HF_WARP_WG_CPW; }   // 16-byte chunks per source window (12 KB for 4 waves)
+// Shape of the staged kernel (all measured on the 2160p HDR pipeline, 2 batch streams of 16, k frames/s -- DESIGN.md appendix C):
+//   waves (= vertically stacked wave tiles) per workgroup: 68.8-70.0 without staging, 71.9-72.5 / 72.9-73.4 / 73.9-74.1 / 66.7-67.8 / 61.3
+//   with 2 / 3 / 4 / 6 / 16 waves;  rows per thread: 2 (4 rows = half the waves: alone 672 vs 663 us per 16 members, pipeline 69.4 vs
+//   72.4: the other stream's chain waits longer for the fewer, longer waves);  window budget 160 / 176 / 192 / 224 / 256 chunks per wave:
+//   192 best (smaller: more fallbacks; larger: one workgroup per CU less)
+constexpr int kWgWaves = 4, kWgRows = 2, kWgChunksPerWave = 192;
+constexpr long kWgMinWaves = 4 * 8192;            // the staged kernel only for launches of several rounds of waves (batched periods): ONE
+                                                  // member's period alone is 12 % slower that way (two barriers and a serial prologue per
+                                                  // workgroup with nothing to overlap them), so single launches keep the global path
+constexpr int wg_chunks(int nw) { return nw * kWgChunksPerWave; }   // 16-byte chunks per source window (12 KB for 4 waves)
 
 typedef unsigned short ushort2w __attribute__((ext_vector_type(2)));
 // min / max of both unsigned 16-bit halves (v_pk_min_u16 / v_pk_max_u16)
@@ -1158,13 +1157,8 @@ __host__ __device__ __forceinline__ int wg_blocks_per_member(int wpr, int yb, in
 }
 
 // (88 VGPRs = 5 waves per SIMD; amdgpu_waves_per_eu(6) = 80 VGPRs + 16 spilled: 77.4-77.8 vs 78.0-78.2 k frames/s -- not kept)
-#ifdef HF_WARP_WG_WPE   // experiment: force the occupancy (the plane-building and the generic-fallback code need more registers than the staged path)
-#define HF_WG_OCC __attribute__((amdgpu_waves_per_eu(HF_WARP_WG_WPE, HF_WARP_WG_WPE)))
-#else
-#define HF_WG_OCC
-#endif
 template <typename E, int MODE, int NW, int ROWS>
-__global__ __launch_bounds__(64 * NW) HF_WG_OCC void warp_wg_kernel(const Geom g, const WarpBatchArgs batch, const PlaneOut po) {
+__global__ __launch_bounds__(64 * NW) void warp_wg_kernel(const Geom g, const WarpBatchArgs batch, const PlaneOut po) {
     constexpr int VEC = 16 / (int)sizeof(E);
     const int y_groups = (g.H + ROWS - 1) / ROWS;
     extern __shared__ __attribute__((aligned(16))) unsigned char wg_windows[];   // 2 x wg_chunks(NW) x 16 bytes
@@ -1329,23 +1323,16 @@ static bool launch_warp_fast(const Geom& g, const WarpBatchArgs& b, hipStream_t 
     const int out_chunk = small_frame && (long)n_tiles * b.n < 4 * 8192 ? 1 : kMaxWarpOutputs;
     const int n_chunks = (max_out + out_chunk - 1) / out_chunk;
     // large workgroups only where the launch keeps every CU supplied with them (>= 4 rounds of 8,192 resident waves)
-#if HF_WARP_WG
-    // one LDS window per workgroup of HF_WARP_WG stacked wave tiles (warp_wg_kernel): one flow cell per 16-byte thread, all outputs
-    // of the period per thread, dword-aligned frames
-    // ... for launches that keep the device busy for several rounds of waves (batched periods): there the staged kernel's launch is
-    // 10 % shorter inside the pipeline (1,385 vs 1,545-1,595 us per 16 members; + 6.5 % frames/s) and as fast alone (39.5 vs 39.0 us
-    // per member); ONE member's period alone is 12 % slower that way (49.9 vs 44.3 us: two barriers and a serial prologue per
-    // workgroup with nothing to overlap them), so single launches keep the global path.
-#ifndef HF_WARP_WG_MIN_WAVES
-#define HF_WARP_WG_MIN_WAVES (4 * 8192)
-#endif
-    constexpr int WR = HF_WARP_WG_ROWS, NW = HF_WARP_WG * 2 / WR;              // rows per thread, waves per workgroup (tile height HF_WARP_WG x 8 rows)
+    // one LDS window per workgroup of kWgWaves stacked wave tiles (warp_wg_kernel): one flow cell per 16-byte thread, all outputs of the
+    // period per thread, dword-aligned frames, launches of several rounds of waves (inside the pipeline the staged launch is 10 % shorter
+    // than the global path -- 1,385 vs 1,545-1,595 us per 16 members, round 3)
+    constexpr int WR = kWgRows, NW = kWgWaves * 2 / WR;                        // rows per thread, waves per workgroup (tile height kWgWaves x 8 rows)
     const int y_tiles_ = (((g.H + WR - 1) / WR) + kWarpTY - 1) / kWarpTY, uv_tiles_ = ((((g.H >> 1) + WR - 1) / WR) + kWarpTY - 1) / kWarpTY;
     const int plane_blocks = ((g.lw >> 2) * (2 * NW * kWarpTY * WR) + 64 * NW - 1) / (64 * NW);   // (groups of 4 columns) x (luma rows of a super row) tasks
     // (its workgroups decode their unit index with scalar multiply-high divisions, exact while units x blocks per member < 2^32: frames
     //  far beyond 8K take the generic launch below)
     const uint32_t nb_max = (uint32_t)wg_blocks_per_member(wpr, (y_tiles_ + NW - 1) / NW, (uv_tiles_ + NW - 1) / NW, plane_blocks);
-    if constexpr (VB == 16) if (group == VEC && dw && out_chunk > 1 && max_out >= 2 && (long)n_tiles * b.n >= HF_WARP_WG_MIN_WAVES &&
+    if constexpr (VB == 16) if (group == VEC && dw && out_chunk > 1 && max_out >= 2 && (long)n_tiles * b.n >= kWgMinWaves &&
                                 fastdiv_exact((uint64_t)nb_max * b.n + 8, nb_max)) {
         // deferred phase planes: members that ask for one (plane21) get it from this launch if geometry and alignment allow
         WarpBatchArgs bb = b;
@@ -1376,7 +1363,6 @@ static bool launch_warp_fast(const Geom& g, const WarpBatchArgs& b, hipStream_t 
 #undef HF_WARP_WG_LAUNCH
         return true;
     }
-#endif
     // large workgroups only where the launch keeps every CU supplied with them (>= 4 rounds of 8,192 resident waves)
     const int wpb = out_chunk > 1 && (long)n_tiles * n_chunks * b.n >= 4 * 8192 ? warp_max_waves(sizeof(E), group, VB) : kWarpWavesSmall;
     const int n_blocks = (n_tiles + wpb - 1) / wpb;
@@ -1477,7 +1463,6 @@ bool launch_warp_periods(const Geom& g, int n, const WarpPeriod* periods, int mo
 }
 
 bool warp_period_can_build_planes(const Geom& g, const PhaseLayout& pl, int n_members) {
-#if HF_WARP_WG
     const size_t esz = g.hdr ? 2 : 1;
     const int VEC = (int)(16 / esz), cell = 1 << g.rs;
     if (cell < VEC || (size_t)g.W * g.H * esz <= (size_t)1920 * 1088) return false;     // one flow cell per 16-byte thread, no 8-byte threads
@@ -1485,11 +1470,7 @@ bool warp_period_can_build_planes(const Geom& g, const PhaseLayout& pl, int n_me
     const int wpr = (g.W + kWarpTX * VEC - 1) / (kWarpTX * VEC);
     const long n_tiles = (long)wpr * ((y_groups + kWarpTY - 1) / kWarpTY + (uv_groups + kWarpTY - 1) / kWarpTY);
     const int per_launch = n_members < kMaxWarpBatch ? n_members : kMaxWarpBatch;
-    return n_tiles * per_launch >= HF_WARP_WG_MIN_WAVES && g.H == (g.lh << g.rs) && plane_emission_geometry(g, pl);
-#else
-    (void)g; (void)pl; (void)n_members;
-    return false;
-#endif
+    return n_tiles * per_launch >= kWgMinWaves && g.H == (g.lh << g.rs) && plane_emission_geometry(g, pl);
 }
 
 template <typename E>

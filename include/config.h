@@ -4,7 +4,7 @@
 // values and MAX_CALC_RES (HopperRender.cpp:180-183,1445-1454,1529-1569), so the drop-in header chain has to provide
 // the same macro names with the same values.  When this directory precedes the filter's own on the include path this
 // file IS that config.h; when the filter's own copy is found first, the `#ifndef` guards below keep its values.
-// libhopperflow.so is built against these values as well (hf_capi.hip, hf_filter.cpp).
+// libhopperflow.so is built against these values as well (hf_context.hip ..., hf_filter.cpp).
 #pragma once
 
 // Quality

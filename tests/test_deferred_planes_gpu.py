@@ -198,7 +198,7 @@ def test_error_behaviour_is_that_of_the_three_calls(native_lib):
 
 
 def test_a_refused_flow_calculation_leaves_the_outputs_untouched(native_lib):
-    """Members whose flow parameters differ make hf_batch_calculate_optical_flow fail (hf_capi: "members differ ...").  With the three
+    """Members whose flow parameters differ make hf_batch_calculate_optical_flow fail (hf_batch.hip: "members differ ...").  With the three
     separate calls nothing is warped in that period; a plane-deferring hf_batch_run_period issues its warps BEFORE the chain, so it has
     to make the chain's argument checks first: the caller's output buffers keep their contents."""
     from hopperrender_amd import capi, synth

@@ -78,7 +78,7 @@ def build(name):
     subprocess.check_call(["/opt/rocm/bin/hipcc"] + F + ["-I", os.path.join(R, "include"), "-I", os.path.join(R, "hopperrender_amd/csrc"), "-c", src, "-o", src + ".o"], stderr=subprocess.DEVNULL)
     L = os.path.join(R, "hopperrender_amd/lib")
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", os.path.join(d, "libhopperflow.so"), src + ".o"] +
-                          [os.path.join(L, f) for f in ("hf_flow.hip.o", "hf_capi.hip.o", "hf_filter.cpp.o", "hf_hostio.cpp.o")] + ["-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined"])
+                          [os.path.join(L, f) for f in ("hf_flow.hip.o", "hf_context.hip.o", "hf_calc.hip.o", "hf_batch.hip.o", "hf_async_io.hip.o", "hf_filter.cpp.o", "hf_hostio.cpp.o")] + ["-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined"])
     os.remove(src + ".o"); os.remove(src)
     return name
 
