@@ -225,14 +225,9 @@ __device__ __forceinline__ Elems<PX> buffer_elems(__amdgpu_buffer_rsrc_t rsrc, u
 // on the vector ALU at all (round 1: ~13 of the ~36 VALU instructions per candidate).  Otherwise it is per lane.
 // (The reference does this arithmetic in 16-bit, calcDeltaSumsKernelSDR.h:75-76; offsets are bounded by
 //  iterations * 64 + 64 < 2^15, so nothing ever wraps.)
-// CH: candidates whose loads are in flight together.  All 16 (64 registers of load data per lane) is what a chain that has the GPU to
-// itself wants; 8 lets a chain wave fit into the registers the period warp's five waves per SIMD leave free (72 of 512 per lane), so that
-// chain and warp launches of the two batch streams truly run side by side instead of taking turns at the wave slots.
-constexpr int kCandChunk = 8;
 template <int PX, bool UNI, bool FULL>
 __device__ __forceinline__ void strip_sads(uint32_t* sad, const Geom& g, const FlowStep& a, const Strip<PX>& s,
                                            int ox, int oy, int axis) {
-    constexpr int CH = kCandChunk;
     const PhaseLayout& pl = a.pl;
     const int sy = s.cy << g.rs;
     const bool ragged = !FULL && (g.lw & (PX - 1)) != 0;              // kernel-uniform: some strip hangs over the right grid edge
@@ -242,42 +237,21 @@ __device__ __forceinline__ void strip_sads(uint32_t* sad, const Geom& g, const F
     if (UNI) { ox = __builtin_amdgcn_readfirstlane(ox); oy = __builtin_amdgcn_readfirstlane(oy); }
     const int searched0 = axis ? oy : ox;
     const unsigned row_el = (unsigned)(pl.nph2 * pl.lwp);             // elements per full-res row
-    // One chunk of candidates: `fetch(cz, sel)` loads candidate cz's elements and names its byte selector; then the SADs.
-    auto run = [&](auto&& fetch) {
-#pragma unroll
-        for (int c0 = 0; c0 < 16; c0 += CH) {
-            Elems<PX> c1[CH];
-            uint32_t sel[CH];
-#pragma unroll
-            for (int k = 0; k < CH; k++) {
-                sel[k] = 0u;
-                if (c0 + k < R && any) c1[k] = fetch(c0 + k, sel[k]);     // R is uniform
-            }
-#pragma unroll
-            for (int k = 0; k < CH; k++) {
-                uint32_t t = sad[c0 + k];
-                if (c0 + k < R && any) {
-#pragma unroll
-                    for (int i = 0; i < PX; i++) {
-                        uint32_t v = __builtin_amdgcn_perm(c1[k].d[i], c1[k].d[i], sel[k]);
-                        if (ragged) v &= s.vm[i];
-                        t = __builtin_amdgcn_sad_u8(v, s.ref[i], t);
-                    }
-                }
-                sad[c0 + k] = t;
-            }
-        }
-    };
+    Elems<PX> c1[16];
+    uint32_t sel[16];
     if (!axis) {
         // (the margin mx goes into the window part: it keeps that part >= 0, as a scalar buffer offset has to be)
         const unsigned lane_off = (__umul24((unsigned)mirror_clamp(sy + oy, g.H), row_el) + (unsigned)s.cx0) * 4u;
-        run([&](const int cz, uint32_t& sel) {
-            const int c = searched0 + rel_offset(cz, R);
-            const int ph = c & (pl.nph - 1);
-            const unsigned coff = (unsigned)((ph >> 1) * pl.lwp + (c >> g.rs) + pl.mx) * 4u;
-            sel = 0x03020c00u | (unsigned)(ph & 1);                   // v_perm_b32: luma byte of this phase, 0, U, V
-            return UNI ? buffer_elems<PX>(rsrc, lane_off + 0u, coff, pl.bytes) : buffer_elems<PX>(rsrc, lane_off + coff, 0u, pl.bytes);
-        });
+#pragma unroll
+        for (int cz = 0; cz < 16; cz++) {
+            if (cz < R && any) {                                  // R is uniform
+                const int c = searched0 + rel_offset(cz, R);
+                const int ph = c & (pl.nph - 1);
+                const unsigned coff = (unsigned)((ph >> 1) * pl.lwp + (c >> g.rs) + pl.mx) * 4u;
+                c1[cz] = UNI ? buffer_elems<PX>(rsrc, lane_off + 0u, coff, pl.bytes) : buffer_elems<PX>(rsrc, lane_off + coff, 0u, pl.bytes);
+                sel[cz] = 0x03020c00u | (unsigned)(ph & 1);           // v_perm_b32: luma byte of this phase, 0, U, V
+            }
+        }
     } else {
         const int ph0 = ox & (pl.nph - 1);
         const unsigned col = (unsigned)((ph0 >> 1) * pl.lwp + pl.mx + s.cx0 + (ox >> g.rs));
@@ -287,18 +261,37 @@ __device__ __forceinline__ void strip_sads(uint32_t* sad, const Geom& g, const F
         const bool inside = !any || (sy + cmin >= 0 && sy + cmax <= g.H - 1);
         if (__builtin_amdgcn_ballot_w64(!inside) == 0) {
             const unsigned lane_off = (__umul24((unsigned)(sy + cmin), row_el) + col) * 4u;   // row of the lowest candidate
-            run([&](const int cz, uint32_t& sel) {
-                const unsigned coff = __umul24((unsigned)(rel_offset(cz, R) - rel_offset(0, R)), row_el) * 4u;   // >= 0, wave-uniform
-                sel = selc;
-                return buffer_elems<PX>(rsrc, lane_off, coff, pl.bytes);
-            });
+#pragma unroll
+            for (int cz = 0; cz < 16; cz++) {
+                if (cz < R && any) {
+                    const unsigned coff = __umul24((unsigned)(rel_offset(cz, R) - rel_offset(0, R)), row_el) * 4u;   // >= 0, wave-uniform
+                    c1[cz] = buffer_elems<PX>(rsrc, lane_off, coff, pl.bytes);
+                    sel[cz] = selc;
+                }
+            }
         } else {
-            run([&](const int cz, uint32_t& sel) {
-                const int ny = mirror_clamp(sy + searched0 + rel_offset(cz, R), g.H);
-                sel = selc;
-                return buffer_elems<PX>(rsrc, (__umul24((unsigned)ny, row_el) + col) * 4u, 0u, pl.bytes);
-            });
+#pragma unroll
+            for (int cz = 0; cz < 16; cz++) {
+                if (cz < R && any) {
+                    const int ny = mirror_clamp(sy + searched0 + rel_offset(cz, R), g.H);
+                    c1[cz] = buffer_elems<PX>(rsrc, (__umul24((unsigned)ny, row_el) + col) * 4u, 0u, pl.bytes);
+                    sel[cz] = selc;
+                }
+            }
         }
+    }
+#pragma unroll
+    for (int cz = 0; cz < 16; cz++) {
+        uint32_t t = sad[cz];
+        if (cz < R && any) {
+#pragma unroll
+            for (int i = 0; i < PX; i++) {
+                uint32_t v = __builtin_amdgcn_perm(c1[cz].d[i], c1[cz].d[i], sel[cz]);
+                if (ragged) v &= s.vm[i];
+                t = __builtin_amdgcn_sad_u8(v, s.ref[i], t);
+            }
+        }
+        sad[cz] = t;
     }
 }
 
@@ -636,9 +629,10 @@ __global__ __launch_bounds__(SPLIT ? 64 : 256) void flow_level_small_kernel(cons
     static_assert(!SPLIT || WS <= 16, "a 32x32 window is shared by the four waves of a workgroup");
     __shared__ uint32_t s_part[SPLIT ? 1 : 2][4][16];
     // Workgroup-uniform choice: tiles that lie inside the grid with the full search radius (all but the last tile row /
-    // column once the governor has settled at 16) run a body without validity masks and per-candidate tests -- a level
-    // launch is mostly instruction issue (vector + scalar), not loads: without ANY memory access it still takes 60-70 %
-    // of its time (what-if builds).
+    // column once the governor has settled at 16) run a body without validity masks and per-candidate tests.
+    // (Registers: 16 candidates x 16 bytes in flight per row = ~100 per lane for the one-row levels, 140-170 for the block levels.  Capping
+    //  the one-row levels and the partial kernel at 72 -- 8 candidates in flight -- lets a chain wave fit beside the period warp's five waves
+    //  per SIMD: inside the pipeline the warp launch then got 11 % shorter and the chain 39 % longer, the same frames/s; DESIGN.md appendix D.)
     const bool full = a.R == 16 && (tile.tx + 1) * M::TW <= g.lw && (tile.ty + 1) * M::TH <= g.lh;
     if (full) flow_level_small_body<WS, SPLIT, true>(g, a, tile, s_part);
     else flow_level_small_body<WS, SPLIT, false>(g, a, tile, s_part);
