@@ -52,9 +52,12 @@ WORKLOADS = {
     "sdr1080_64pairs": (0, 1080, 1920, 166667, "1920x1080 SDR, 64 independent frame pairs sharded across the GPUs, 24->60 fps (BASELINE config 4)"),
     "hdr2160_nb10_blur32": (1, 2160, 3840, 83333, "3840x2160 HDR, neighbor scalar 10, blurFlow radius 32, 24->120 fps (BASELINE config 5)"),
 }
-# per workload: (pair streams per GPU, pairs per flow batch) -- measured operating points, DESIGN.md section 5
-OPERATING_POINT = {"hdr2160_24to120": (32, 16), "hdr2160_24to60": (32, 16), "sdr1080_24to60": (32, 16), "sdr1080_24to120": (32, 16),
-                   "sdr360_24to60": (32, 16), "hdr2160_nb10_blur32": (32, 16)}
+# per workload: (pair streams per GPU, pairs per flow batch) -- measured operating points (tools/scan_op.sh).  Round 4:
+# FOUR batch streams of 12 instead of two of 16 at 2160p (+ 6.5 %: 84.8-85.4 k against 79.4-80.2 k frames/s on one box; 3 x 12 + 4.3 %, 4 x 16
+# + 2.3 %, 5 or 6 streams and batches of 13-14 lose), three of 12 at 1080p (+ 4 %) -- with the faster chain and warp launches of this round
+# more, smaller batches in flight fill the device better; four is also the number of hardware queues the batch streams can have.
+OPERATING_POINT = {"hdr2160_24to120": (48, 12), "hdr2160_24to60": (48, 12), "sdr1080_24to60": (36, 12), "sdr1080_24to120": (36, 12),
+                   "sdr360_24to60": (32, 16), "hdr2160_nb10_blur32": (48, 12)}
 WORKLOAD_PARAMS = {"hdr2160_nb10_blur32": {"neighbor": 10, "blur_radius": 32}}   # overrides of --neighbor / --blur-radius
 TOTAL_PAIRS = {"sdr1080_64pairs": 64}                                            # pair streams of the whole JOB (strong-scaled over ranks)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
@@ -277,7 +280,7 @@ def main():
         setattr(a, k, v)
     if a.workload in TOTAL_PAIRS:
         per_rank = max(1, TOTAL_PAIRS[a.workload] // world)
-        op_streams, op_batch = per_rank, min(per_rank, 32)
+        op_streams, op_batch = per_rank, min(per_rank, 16)     # (64 pairs on one GPU: 4 batch streams of 16 -- 126 k against 121.5 k frames/s as 2 x 32)
     else:
         op_streams, op_batch = OPERATING_POINT[a.workload]
     if a.streams <= 0:

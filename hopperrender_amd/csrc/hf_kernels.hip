@@ -61,31 +61,36 @@ __device__ __forceinline__ int mirror_flow(int pos, int dim) {  // blurFlowKerne
     return clampi(pos, 0, dim - 1);
 }
 
-// One workgroup = 16 x 16 outputs, both planes: the offsets of the (16 + 2r)^2 neighbourhood go through LDS once as
+// One workgroup = TS x TS outputs, both planes: the offsets of the (TS + 2r)^2 neighbourhood go through LDS once as
 // packed x | y << 16 words, then a horizontal and a vertical pass of 2r taps each (blurFlowKernelSDR.h:79-91 sums
 // the same (2r)^2 taps in one double loop; integer sums are order-independent).  The kernel also emits the packed
-// copy of the blurred flow that warp_fast_kernel reads with one load, and re-zeroes the window sums of the chain.
+// copy of the blurred flow that the warp kernels read with one load, and re-zeroes the window sums of the chain.
+// TS = 32 with the radius fixed at compile time (RFIX = 4, the reference's) is the chain's launch: a quarter of the workgroups of the
+// 16 x 16 version (one round of waves instead of four for a batch of 16), 1.56 instead of 2.25 gathered offsets per output, unrolled taps;
+// TS = 16 with a runtime radius (RFIX = 0) serves every other radius (up to 64: 101 KB of LDS).
 __device__ __forceinline__ int div_trunc(int s, int d, int log2d) {   // C division (truncation toward zero), :89-90
     return log2d >= 0 ? (s + ((s >> 31) & (d - 1))) >> log2d : s / d;
 }
-__global__ __launch_bounds__(256) void blur_flow_kernel(const BlurBatch batch, int lw, int lh, int r, int zero_count) {
+template <int TS, int RFIX>
+__global__ __launch_bounds__(256) void blur_flow_kernel(const BlurBatch batch, int lw, int lh, int r_arg, int zero_count) {
     const BlurItem& it = batch.s[blockIdx.z];   // blockIdx.z: pair of the batch
     const FlowLevel& L = it.last;
     int16_t* __restrict__ blurred = it.blurred;
     uint32_t* __restrict__ packed = it.packed;
     uint32_t* __restrict__ zero = it.zero;
+    const int r = RFIX ? RFIX : r_arg;
     if (zero) {   // the refinement steps are done with the window sums: clear them for the next chain
         const int nthreads = gridDim.x * gridDim.y * 256;
         for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < zero_count; i += nthreads) zero[i] = 0u;
     }
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int T = 16 + 2 * r;                     // tile edge
+    const int T = TS + 2 * r;                     // tile edge
     uint32_t* tile = (uint32_t*)smem;             // [T][T] packed offsets
-    int* hx = (int*)(tile + T * T);               // [T][16] horizontal sums of x
-    int* hy = hx + T * 16;                        // [T][16] ... of y
+    int* hx = (int*)(tile + T * T);               // [T][TS] horizontal sums of x
+    int* hy = hx + T * TS;                        // [T][TS] ... of y
     const int tid = threadIdx.x;
     const int tx = tid & 15, ty = tid >> 4;
-    const int x0 = blockIdx.x * 16 - r, y0 = blockIdx.y * 16 - r;
+    const int x0 = blockIdx.x * TS - r, y0 = blockIdx.y * TS - r;
     for (int py = ty; py < T; py += 16) {         // offsets are stored per window of the last level
         const int wrow = (mirror_flow(y0 + py, lh) >> L.log2w) * L.nwx;
         for (int px = tx; px < T; px += 16) {
@@ -96,31 +101,40 @@ __global__ __launch_bounds__(256) void blur_flow_kernel(const BlurBatch batch, i
         }
     }
     __syncthreads();
-    for (int row = ty; row < T; row += 16) {      // taps -r .. r-1 (blurFlowKernelSDR.h:82-83)
-        const uint32_t* p = tile + row * T + tx;
+    for (int idx = tid; idx < T * TS; idx += 256) {   // taps -r .. r-1 (blurFlowKernelSDR.h:82-83)
+        const int row = idx / TS, col = idx - row * TS;    // (TS is a power of two)
+        const uint32_t* p = tile + row * T + col;
         int sx = 0, sy = 0;
-        for (int k = 0; k < 2 * r; k++) {
-            const uint32_t w = p[k];
-            sx += (int)(int16_t)(w & 0xFFFFu);
-            sy += (int)w >> 16;
+#pragma unroll
+        for (int k = 0; k < (RFIX ? 2 * RFIX : 1); k++) {
+            if (RFIX) { const uint32_t w = p[k]; sx += (int)(int16_t)(w & 0xFFFFu); sy += (int)w >> 16; }
         }
-        hx[row * 16 + tx] = sx;
-        hy[row * 16 + tx] = sy;
+        if (!RFIX) for (int k = 0; k < 2 * r; k++) { const uint32_t w = p[k]; sx += (int)(int16_t)(w & 0xFFFFu); sy += (int)w >> 16; }
+        hx[idx] = sx;
+        hy[idx] = sy;
     }
     __syncthreads();
-    int sx = 0, sy = 0;
-    for (int k = 0; k < 2 * r; k++) {
-        sx += hx[(ty + k) * 16 + tx];
-        sy += hy[(ty + k) * 16 + tx];
-    }
     const int d = 4 * r * r, log2d = (r & (r - 1)) == 0 ? 2 + 2 * (31 - __builtin_clz(r)) : -1;
-    const int rx = (int)(int16_t)div_trunc(sx, d, log2d), ry = (int)(int16_t)div_trunc(sy, d, log2d);
-    const int gx = blockIdx.x * 16 + tx, gy = blockIdx.y * 16 + ty;
-    if (gx < lw && gy < lh) {
-        const size_t q = (size_t)gy * lw + gx;
-        blurred[q] = (int16_t)rx;
-        blurred[(size_t)lw * lh + q] = (int16_t)ry;
-        packed[q] = ((uint32_t)rx & 0xFFFFu) | ((uint32_t)ry << 16);
+#pragma unroll
+    for (int oy = 0; oy < TS; oy += 16) {
+#pragma unroll
+        for (int ox = 0; ox < TS; ox += 16) {
+            const int cx = ox + tx, cy = oy + ty;
+            int sx = 0, sy = 0;
+#pragma unroll
+            for (int k = 0; k < (RFIX ? 2 * RFIX : 1); k++) {
+                if (RFIX) { sx += hx[(cy + k) * TS + cx]; sy += hy[(cy + k) * TS + cx]; }
+            }
+            if (!RFIX) for (int k = 0; k < 2 * r; k++) { sx += hx[(cy + k) * TS + cx]; sy += hy[(cy + k) * TS + cx]; }
+            const int rx = (int)(int16_t)div_trunc(sx, d, log2d), ry = (int)(int16_t)div_trunc(sy, d, log2d);
+            const int gx = blockIdx.x * TS + cx, gy = blockIdx.y * TS + cy;
+            if (gx < lw && gy < lh) {
+                const size_t q = (size_t)gy * lw + gx;
+                blurred[q] = (int16_t)rx;
+                blurred[(size_t)lw * lh + q] = (int16_t)ry;
+                packed[q] = ((uint32_t)rx & 0xFFFFu) | ((uint32_t)ry << 16);
+            }
+        }
     }
 }
 
@@ -1147,6 +1161,8 @@ struct PlaneOut {
     int blocks;                          // plane-building workgroups per super row (0: the launch builds no planes)
     FastDiv per_member, per_sr, wpr;     // unit index -> (member, super row, block): scalar divisions (hf_kernels.h)
 };
+static_assert(sizeof(Geom) + sizeof(WarpBatchArgs) + sizeof(PlaneOut) <= 4096, "kernel arguments of warp_wg_kernel (a launch carries at most 4 KB)");
+static_assert(sizeof(WarpArgs) == 168, "hf_kernels.h kMaxWarpBatch is sized for 168-byte members");
 
 // Block order per member: "super rows" = [plane-building blocks,] two luma block rows, then the chroma block row of the same
 // picture region (a chroma block of NW stacked tiles spans twice the picture rows of a luma block), so that a region's luma and
@@ -1246,12 +1262,19 @@ __global__ void rcp_probe_kernel(const float* in, float* out, int n) {
 // launchers
 // ------------------------------------------------------------------------------------------
 void launch_blur_flow(const Geom& g, const BlurBatch& b, int radius, int zero_count, hipStream_t stream) {
+    if (radius == 4) {   // the reference's radius: 32 x 32 outputs per workgroup, taps unrolled
+        const dim3 grd((g.lw + 31) / 32, (g.lh + 31) / 32, b.n);
+        const int T = 32 + 8;
+        const size_t smem = (size_t)T * T * sizeof(uint32_t) + 2 * (size_t)T * 32 * sizeof(int);   // 16.6 KB
+        blur_flow_kernel<32, 4><<<grd, 256, smem, stream>>>(b, g.lw, g.lh, radius, zero_count);
+        return;
+    }
     const dim3 grd((g.lw + 15) / 16, (g.lh + 15) / 16, b.n);
     const int T = 16 + 2 * radius;
     const size_t smem = (size_t)T * T * sizeof(uint32_t) + 2 * (size_t)T * 16 * sizeof(int);
     if (smem > 48 * 1024)     // large radii (up to 64: 101 KB of the CU's 160 KB LDS) need the opt-in; the attribute is per device
-        (void)hipFuncSetAttribute((const void*)blur_flow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    blur_flow_kernel<<<grd, 256, smem, stream>>>(b, g.lw, g.lh, radius, zero_count);
+        (void)hipFuncSetAttribute((const void*)blur_flow_kernel<16, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    blur_flow_kernel<16, 0><<<grd, 256, smem, stream>>>(b, g.lw, g.lh, radius, zero_count);
 }
 
 void launch_pack_flow(const Geom& g, const int16_t* flow, uint32_t* packed, hipStream_t stream) {

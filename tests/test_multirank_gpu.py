@@ -53,7 +53,7 @@ def test_named_baseline_configs_4_and_5():
     """BASELINE.json configs 4 and 5 by name: `sdr1080_64pairs` (64 independent 1080p SDR pairs in flight, split over the
     ranks: strong scaling) and `hdr2160_nb10_blur32` (neighbour scalar 10, blurFlow radius 32)."""
     one = run_bench([], 1, "sdr1080_64pairs")
-    assert one["config"]["pair_streams_per_gpu"] == 64 and one["config"]["flow_batch"] == 32 and one["scaling"] == "strong"
+    assert one["config"]["pair_streams_per_gpu"] == 64 and one["config"]["flow_batch"] == 16 and one["scaling"] == "strong"
     two = run_bench([], 2, "sdr1080_64pairs")
     assert two["config"]["pair_streams_per_gpu"] == 32 and two["config"]["pair_streams_total"] == 64
     assert two["config"]["output_frames_total"] == one["config"]["output_frames_total"]        # the job is the same 64 pairs
@@ -96,5 +96,5 @@ def test_default_line_carries_the_other_baseline_configs():
     for name, w in o.items():
         assert "error" not in w, (name, w)
         assert w["value"] > 0 and 0 < w["frac"] < 1 and w["frac_algorithmic"] > 0 and w["timed_region_s"] > 0.3, (name, w)
-    assert o["sdr1080_64pairs"]["pair_streams"] == 64 and o["sdr1080_64pairs"]["flow_batch"] == 32
+    assert o["sdr1080_64pairs"]["pair_streams"] == 64 and o["sdr1080_64pairs"]["flow_batch"] == 16
     assert d["roofline"]["kernel"].startswith("warp_wg_kernel<unsigned short, 2,")

@@ -10,7 +10,8 @@ pairs = [("bench_default.json", "bench_default.json"), ("bench_sdr1080.json", "b
          ("bench_default_under_rocprof.json", "bench_default_under_rocprof.json"), ("bench_sdr1080_under_rocprof.json", "bench_sdr1080_under_rocprof.json"),
          ("microbench.txt", "microbench.txt"), ("stats_default/p_kernel_stats.csv", "bench_default_kernel_stats.csv"),
          ("stats_sdr1080/p_kernel_stats.csv", "bench_sdr1080_kernel_stats.csv"), ("stats_streams1/p_kernel_stats.csv", "bench_streams1_kernel_stats.csv"),
-         ("stats_chain16/p_kernel_stats.csv", "chain_batch16_kernel_stats.csv")]
+         ("stats_chain16/p_kernel_stats.csv", "chain_batch16_kernel_stats.csv"), ("pmc_warp_valu.txt", "pmc_warp_instructions.txt"),
+         ("pmc_warp_wg_kernel.txt", "pmc_warp_wg_kernel.txt")]
 for a, b in pairs:
     if os.path.exists(os.path.join(src, a)):
         shutil.copyfile(os.path.join(src, a), os.path.join(dst, f"{rnd}_{b}")); print("copied", b)
@@ -20,6 +21,16 @@ frame_bytes = {"hdr2160_24to120": 3840 * 2160 * 3, "sdr1080_24to60": 1920 * 1080
 outputs_per_period = {"hdr2160_24to120": 417083 / 83333, "sdr1080_24to60": 417083 / 166667}     # source / target frame time (HopperRender.cpp:162-163)
 
 
+# pairs per batch at the bench's operating point (the PMC passes over the pipeline run the same default command)
+import json
+flow_batch = {}
+for wl, f in (("hdr2160_24to120", "bench_default.json"), ("sdr1080_24to60", "bench_sdr1080.json")):
+    try:
+        flow_batch[wl] = json.loads([l for l in open(os.path.join(src, f)) if l.startswith("{")][-1])["config"]["flow_batch"]
+    except Exception:
+        flow_batch[wl] = 16
+
+
 def reduce_rows(path, counter, keep):
     rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter and keep(r["Kernel_Name"])]
     return rows
@@ -27,7 +38,7 @@ def reduce_rows(path, counter, keep):
 
 for wl in ("hdr2160_24to120", "sdr1080_24to60"):
     for kind, prefix, keep, extra in (("warp_period", "pmc", lambda n: "::warp_" in n, []),
-                                      ("pipeline", "pmcpipe", lambda n: "hf::" in n, ["--pipeline", "--batch", "16", "--outputs-per-period", "%.5f" % outputs_per_period[wl]])):
+                                      ("pipeline", "pmcpipe", lambda n: "hf::" in n, ["--pipeline", "--batch", str(flow_batch[wl]), "--outputs-per-period", "%.5f" % outputs_per_period[wl]])):
         files = []
         for c in ("FETCH_SIZE", "WRITE_SIZE"):
             p = os.path.join(src, f"{prefix}_{wl}_{c}", "p_counter_collection.csv")

@@ -4,7 +4,7 @@
 #   default bench lines (HDR 2160p, SDR 1080p, BASELINE configs 4 and 5), rocprofv3 kernel stats of the same commands and of one
 #   stream alone, PMC FETCH_SIZE / WRITE_SIZE passes of the fused period warp alone (one launch at a time) AND of the whole
 #   batched pipeline at the bench's operating point, stand-alone kernel times.
-TAG=${1:-r03}
+TAG=${1:-r04}
 export TMPDIR=/tmp; R=$PWD; O=$R/gpurun_out/$TAG; rm -rf $O; mkdir -p $O
 python bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -c 300 $O/bench_default.json; echo
 python bench.py --workload sdr1080_24to60 --no-reference > $O/bench_sdr1080.json 2> $O/bench_sdr1080.err
@@ -16,7 +16,7 @@ python tools/chain_time.py --batch 1 2 4 8 16 >> $O/microbench.txt 2>&1
 python tools/chain_time.py --batch 1 8 16 --hdr 0 --H 1080 --W 1920 >> $O/microbench.txt 2>&1
 python tools/warp_ab.py >> $O/microbench.txt 2>&1
 cd /tmp
-Q="--no-cpu-baseline --no-reference --no-host-io"
+Q="--no-cpu-baseline --no-reference --no-host-io --no-other-workloads"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_default -o p -- python3 $R/bench.py $Q > $O/bench_default_under_rocprof.json 2>/dev/null
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_sdr1080 -o p -- python3 $R/bench.py --workload sdr1080_24to60 $Q > $O/bench_sdr1080_under_rocprof.json 2>/dev/null
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_streams1 -o p -- python3 $R/bench.py --streams 1 --batch 1 --steps 2 --periods-per-step 20 $Q > /dev/null 2>&1
@@ -29,4 +29,8 @@ for wl in hdr2160_24to120 sdr1080_24to60; do for c in FETCH_SIZE WRITE_SIZE; do
   timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmcpipe_${wl}_$c -o p -- python3 $R/bench.py --workload $wl --steps 2 --warmup 1 --periods-per-step 8 --no-profile $Q > /dev/null 2>&1
   echo "pmc pipeline $wl $c rc=$?"
 done; done
+cd $R
+# instructions per wave of the staged period warp (16-member launches) and its SQ / TD / TA / TCP / TCC counters
+bash tools/pmc_warp_valu.sh product > $O/pmc_warp_valu.txt 2>&1
+bash tools/pmc_warp_batch.sh 16 > $O/pmc_warp_wg_kernel.txt 2>&1
 ls $O
