@@ -562,13 +562,34 @@ template <> struct Map<2> {    // one lane = one 2x2 window; wave = 16x4 windows
     }
 };
 
+// The same two levels with ONE ROW per lane (round 3's mapping): twice the waves for the same pixels.  A batch of many pairs pays for the
+// extra per-wave skeleton; a single pair (the reference's own operating mode: one live stream) leaves most of the device idle, and there
+// twice the waves finish sooner -- 8.7 / 7.8 us instead of 12.4 / 10.2 us for the level-2 / level-4 launch of one 480 x 270 pair.
+template <int WS> struct MapRow : Map<WS> {};
+template <> struct MapRow<4> {   // 4 lanes = one 4x4 window; wave = 4x4 windows
+    static constexpr int PX = 4, NR = 1, G = 4, XM = 1, TW = 32, TH = 32, WAVES = 4;
+    __device__ static void at(int tid, int& x, int& y) {
+        const int w = tid >> 6, l = tid & 63, gi = l >> 2;
+        x = (w & 1) * 16 + (gi & 3) * 4; y = (w >> 1) * 16 + (gi >> 2) * 4 + (l & 3);
+    }
+};
+template <> struct MapRow<2> {   // 2 lanes (l, l ^ 1) = one 2x2 window; wave = 8x4 windows; workgroup tile 16x32
+    static constexpr int PX = 2, NR = 1, G = 2, XM = 1, TW = 16, TH = 32, WAVES = 4;
+    __device__ static void at(int tid, int& x, int& y) {
+        const int w = tid >> 6, l = tid & 63, gi = l >> 1;
+        x = (gi & 7) * 2; y = w * 8 + (gi >> 3) * 2 + (l & 1);
+    }
+};
+template <int WS, bool ROWS1> struct MapSel { using type = Map<WS>; };
+template <int WS> struct MapSel<WS, true> { using type = MapRow<WS>; };
+
 // One level, X step then Y step, windows <= 32.
 // SPLIT (windows <= 16, where a window never spans waves): the four waves of a tile are four one-wave workgroups
 // (TileId::wave).  A 480x270 grid has only 135 tiles for 256 CUs; split, every CU's L1 takes a share of the
 // candidate rows' cache lines (a Y step pulls ~16 x 8 row segments per wave, 32 useful bytes per 128-byte line).
-template <int WS, bool SPLIT, bool FULL>
+template <int WS, bool SPLIT, bool FULL, bool ROWS1>
 __device__ __forceinline__ void flow_level_small_body(const Geom& g, const FlowStep& a, const TileId& tile, uint32_t (*s_part)[4][16]) {
-    using M = Map<WS>;
+    using M = typename MapSel<WS, ROWS1>::type;
     constexpr int PX = M::PX, G = M::G;
     const int R = FULL ? 16 : a.R;
     const int tid = SPLIT ? (int)(tile.wave * 64 + threadIdx.x) : (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -620,9 +641,9 @@ __device__ __forceinline__ void flow_level_small_body(const Geom& g, const FlowS
     }
 }
 
-template <int WS, bool SPLIT>
+template <int WS, bool SPLIT, bool ROWS1 = false>
 __global__ __launch_bounds__(SPLIT ? 64 : 256) void flow_level_small_kernel(const Geom g, const FlowBatchArgs batch) {
-    using M = Map<WS>;
+    using M = typename MapSel<WS, ROWS1>::type;
     const TileId tile = decode_tile<SPLIT ? M::WAVES : 1>(batch, (g.lw + M::TW - 1) / M::TW, (g.lh + M::TH - 1) / M::TH);
     if (!tile.valid) return;
     const FlowStep a = member_step(batch, tile.pair);
@@ -634,8 +655,8 @@ __global__ __launch_bounds__(SPLIT ? 64 : 256) void flow_level_small_kernel(cons
     //  the one-row levels and the partial kernel at 72 -- 8 candidates in flight -- lets a chain wave fit beside the period warp's five waves
     //  per SIMD: inside the pipeline the warp launch then got 11 % shorter and the chain 39 % longer, the same frames/s; DESIGN.md appendix D.)
     const bool full = a.R == 16 && (tile.tx + 1) * M::TW <= g.lw && (tile.ty + 1) * M::TH <= g.lh;
-    if (full) flow_level_small_body<WS, SPLIT, true>(g, a, tile, s_part);
-    else flow_level_small_body<WS, SPLIT, false>(g, a, tile, s_part);
+    if (full) flow_level_small_body<WS, SPLIT, true, ROWS1>(g, a, tile, s_part);
+    else flow_level_small_body<WS, SPLIT, false, ROWS1>(g, a, tile, s_part);
 }
 
 // Windows > 32, one axis: raw SAD sums of a 32 x (8 * WPB) tile -> one atomic per candidate.
@@ -801,9 +822,14 @@ void launch_prep_frame(const Geom& g, const PhaseLayout& pl, const void* frame, 
     launch_prep_frames(g, pl, b, stream);
 }
 
+// Batches up to this size run the two finest levels with one row per lane (MapRow).  Chain alone, us per batched chain with a block /
+// a row per lane: 1 pair 79.5 / 71.3, 2 pairs 94.6 / 86.8, 4 pairs 122.4 / 119.2, 8 pairs 169.3 / 173.8.
+constexpr int kRowPerLaneMaxBatch = 4;
 void launch_flow_level_small(const Geom& g, const FlowBatch& b, hipStream_t stream) {
     const int ws = b.s[0].cur.window;
-    const int tiles_x = (g.lw + 31) / 32, tiles_y = (g.lh + 31) / 32;   // (Map<WS>: 32 x 32 tiles at every level)
+    const bool rows1 = b.n <= kRowPerLaneMaxBatch && ws <= 4;
+    const int tw = rows1 && ws == 2 ? MapRow<2>::TW : 32;
+    const int tiles_x = (g.lw + tw - 1) / tw, tiles_y = (g.lh + 31) / 32;   // (32 x 32 tiles at every level but MapRow<2>: 16 x 32)
     const FlowBatchArgs kb = pack_batch(b, tiles_x, tiles_y);
     // windows <= 16 never span waves: one-wave workgroups (SPLIT), see flow_level_small_kernel
     const dim3 grd(xcd_grid(tiles_x, tiles_y, 1, b.n));
@@ -812,8 +838,14 @@ void launch_flow_level_small(const Geom& g, const FlowBatch& b, hipStream_t stre
         case 32: flow_level_small_kernel<32, false><<<grd, 256, 0, stream>>>(g, kb); break;
         case 16: flow_level_small_kernel<16, true><<<split(Map<16>::WAVES), 64, 0, stream>>>(g, kb); break;
         case 8: flow_level_small_kernel<8, true><<<split(Map<8>::WAVES), 64, 0, stream>>>(g, kb); break;
-        case 4: flow_level_small_kernel<4, true><<<split(Map<4>::WAVES), 64, 0, stream>>>(g, kb); break;
-        default: flow_level_small_kernel<2, true><<<split(Map<2>::WAVES), 64, 0, stream>>>(g, kb); break;
+        case 4:
+            if (rows1) flow_level_small_kernel<4, true, true><<<split(MapRow<4>::WAVES), 64, 0, stream>>>(g, kb);
+            else flow_level_small_kernel<4, true><<<split(Map<4>::WAVES), 64, 0, stream>>>(g, kb);
+            break;
+        default:
+            if (rows1) flow_level_small_kernel<2, true, true><<<split(MapRow<2>::WAVES), 64, 0, stream>>>(g, kb);
+            else flow_level_small_kernel<2, true><<<split(Map<2>::WAVES), 64, 0, stream>>>(g, kb);
+            break;
     }
 }
 

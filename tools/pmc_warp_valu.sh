@@ -8,12 +8,5 @@ for v in "$@"; do
   if [ "$v" = product ]; then export HF_LIB=""; else export HF_LIB=$R/hopperrender_amd/lib/exp/$v/libhopperflow.so; fi
   timeout 180 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d $O/$v.a -o p -- python3 $R/tools/warp_ab.py --members 16 --n 6 > $O/$v.a.log 2>&1
   timeout 180 rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d $O/$v.b -o p -- python3 $R/tools/warp_ab.py --members 16 --n 6 > $O/$v.b.log 2>&1
-  echo "== $v"; (python3 $R/tools/pmc_summary.py $O/$v.a "warp_wg"; python3 $R/tools/pmc_summary.py $O/$v.b "warp_wg") | grep -v "^void\|^hf" | python3 -c "
-import sys
-d={}
-for l in sys.stdin:
-    p=l.split()
-    if len(p)>=3 and "mean=" in l: d[p[0]]=float(l.split("mean=")[1])
-w=d.get('SQ_WAVES',1)
-print('  waves %d  per wave: VALU %.0f SALU %.0f LDS %.1f VMEM_RD %.1f VMEM_WR %.1f   VALU busy %.0f %% of the launch (4 cycles per instruction, 1024 SIMDs, GRBM_GUI_ACTIVE summed over 8 XCDs)' % (w, d.get('SQ_INSTS_VALU',0)/w, d.get('SQ_INSTS_SALU',0)/w, d.get('SQ_INSTS_LDS',0)/w, d.get('SQ_INSTS_VMEM_RD',0)/w, d.get('SQ_INSTS_VMEM_WR',0)/w, 100*d.get('SQ_ACTIVE_INST_VALU',0)*4/1024/(d.get('GRBM_GUI_ACTIVE',1)/8)))"
+  echo "== $v"; python3 $R/tools/pmc_instr_per_wave.py $O/$v.a $O/$v.b warp_wg
 done
