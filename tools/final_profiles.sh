@@ -4,12 +4,17 @@
 #   default bench lines (HDR 2160p, SDR 1080p, BASELINE configs 4 and 5), rocprofv3 kernel stats of the same commands and of one
 #   stream alone, PMC FETCH_SIZE / WRITE_SIZE passes of the fused period warp alone (one launch at a time) AND of the whole
 #   batched pipeline at the bench's operating point, stand-alone kernel times.
+#   `tools/final_profiles.sh TAG bench` re-runs only the four bench lines -- after `copy_profiles.py` has regenerated
+#   profiles/roofline_traffic.json from the PMC passes, so that the committed lines price their bytes with THIS round's traffic record.
 TAG=${1:-r04}
-export TMPDIR=/tmp; R=$PWD; O=$R/gpurun_out/$TAG; rm -rf $O; mkdir -p $O
+export TMPDIR=/tmp; R=$PWD; O=$R/gpurun_out/$TAG
+if [ "$2" != bench ]; then rm -rf $O; fi
+mkdir -p $O
 python bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -c 300 $O/bench_default.json; echo
 python bench.py --workload sdr1080_24to60 --no-reference > $O/bench_sdr1080.json 2> $O/bench_sdr1080.err
 python bench.py --workload sdr1080_64pairs --no-reference --no-cpu-baseline --no-host-io > $O/bench_sdr1080_64pairs.json 2> $O/bench_cfg4.err
 python bench.py --workload hdr2160_nb10_blur32 --no-reference --no-cpu-baseline --no-host-io > $O/bench_hdr2160_nb10_blur32.json 2> $O/bench_cfg5.err
+if [ "$2" = bench ]; then ls $O; exit 0; fi
 python tools/microbench.py > $O/microbench.txt 2>&1
 python tools/microbench.py --hdr 0 --H 1080 --W 1920 >> $O/microbench.txt 2>&1
 python tools/chain_time.py --batch 1 2 4 8 16 >> $O/microbench.txt 2>&1
