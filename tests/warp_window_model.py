@@ -1,12 +1,13 @@
-"""tools/warp_window_model.py -- CPU model of the window decision of warp_wg_kernel (hf_warp_staged.hip) on the bench scene.
+"""tests/warp_window_model.py -- CPU model of the window decision of warp_wg_kernel (csrc/hf_kernels.hip warp_wg_body) on the bench scene.
 
 For every workgroup tile of the staged period warp (2160p HDR: 128 x 32 luma pixels / 128 x 32 chroma elements) it computes,
 from the blurred flow of the oracle on the bench's synthetic scene, the source windows the five outputs of a 24 -> 120 period
 need (exactly the kernel's arithmetic: runs as (row, byte offset), window = 16-byte chunk columns x rows) and prints how many
 workgroups stage under a given policy.  No GPU needed: this is how the LDS budget / tile shape / per-source policies are chosen
-before they are built.  (Uses oracle/ for the flow: a design tool, not part of the product.)
+before they are built.  It takes its flow fields from the oracle, so it lives with the tests (only tests/ may use oracle/);
+tests/test_window_model.py pins the design assumption it was written to check.
 
-    python tools/warp_window_model.py [--seed 1234] [--frames 3]
+    python tests/warp_window_model.py [--seed 1234] [--frames 3]
 """
 import argparse, os, sys
 import numpy as np
@@ -18,7 +19,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--seed", type=int, default=1234)
 ap.add_argument("--frames", type=int, default=3, help="consecutive source periods to average over")
 ap.add_argument("--speed", type=int, default=48)
-a = ap.parse_args()
+a = ap.parse_args([] if __name__ != "__main__" else None)
 
 H, W, SZ, RS = 2160, 3840, 2, 3
 g = oracle.make_geom(1, H, W)
@@ -94,26 +95,39 @@ def policy_per_source(w, budget):  # fraction of SOURCE windows staged when each
     return (ok & (ra <= budget)).mean() * 0.5 + (ok & (rb <= budget)).mean() * 0.5
 
 
-flows = []
-for k in range(a.frames):
-    _, blur, _, _ = oracle.calculate_optical_flow(fr[k], fr[k + 1], g, 16, 0, 8, 6, 4)
-    flows.append(blur)
+def flows_of(n_frames):
+    out = []
+    for k in range(n_frames):
+        _, blur, _, _ = oracle.calculate_optical_flow(fr[k], fr[k + 1], g, 16, 0, 8, 6, 4)
+        out.append(blur)
+    return out
 
-for tw, th in ((128, 32), (128, 16), (256, 16), (64, 32), (128, 64), (256, 32)):
+
+def tile_table(flows, tw, th):
     rows = []
     for cz in (0, 1):
         ws = [windows(f, TS[i % 2], cz, tw, th) for i, f in enumerate(flows)]
         rows.append(np.concatenate([w.reshape(-1, 5) for w in ws]))
-    w = np.concatenate(rows)           # luma blocks are 2/3 of all blocks automatically (twice as many rows)
-    tile_chunks = tw * SZ // 16 * th
-    line = f"tile {tw:3d}x{th:2d} ({tile_chunks:4d} chunks)  interior {w[:, 4].mean():.3f} "
-    for mult in (1.5, 2.0, 2.5, 3.0):
-        b = int(tile_chunks * mult) & ~63
-        line += f"| x{mult}: fixed {policy_fixed(w, b).mean():.3f} pool {policy_pool(w, 2 * b).mean():.3f} persrc {policy_per_source(w, b):.3f} "
-    print(line, flush=True)
-    if (tw, th) == (128, 32):
-        ok = w[:, 4] == 1
-        need = np.maximum(w[:, 0] * w[:, 1], w[:, 2] * w[:, 3])[ok]
-        print("   chunks needed per source window (interior tiles), percentiles 50/70/80/90/95/99:",
-              [int(np.percentile(need, p)) for p in (50, 70, 80, 90, 95, 99)], " fetched/tile at 768:",
-              round(float((w[:, 0] * w[:, 1] + w[:, 2] * w[:, 3])[policy_fixed(w, 768)].mean() / (2 * tile_chunks)), 3))
+    return np.concatenate(rows)           # luma blocks are 2/3 of all blocks automatically (twice as many rows)
+
+
+def main():
+    flows = flows_of(a.frames)
+    for tw, th in ((128, 32), (128, 16), (256, 16), (64, 32), (128, 64), (256, 32)):
+        w = tile_table(flows, tw, th)
+        tile_chunks = tw * SZ // 16 * th
+        line = f"tile {tw:3d}x{th:2d} ({tile_chunks:4d} chunks)  interior {w[:, 4].mean():.3f} "
+        for mult in (1.5, 2.0, 2.5, 3.0):
+            b = int(tile_chunks * mult) & ~63
+            line += f"| x{mult}: fixed {policy_fixed(w, b).mean():.3f} pool {policy_pool(w, 2 * b).mean():.3f} persrc {policy_per_source(w, b):.3f} "
+        print(line, flush=True)
+        if (tw, th) == (128, 32):
+            ok = w[:, 4] == 1
+            need = np.maximum(w[:, 0] * w[:, 1], w[:, 2] * w[:, 3])[ok]
+            print("   chunks needed per source window (interior tiles), percentiles 50/70/80/90/95/99:",
+                  [int(np.percentile(need, p)) for p in (50, 70, 80, 90, 95, 99)], " fetched/tile at 768:",
+                  round(float((w[:, 0] * w[:, 1] + w[:, 2] * w[:, 3])[policy_fixed(w, 768)].mean() / (2 * tile_chunks)), 3))
+
+
+if __name__ == "__main__":
+    main()

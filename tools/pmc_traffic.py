@@ -65,6 +65,9 @@ def pipeline_entry(a):
         wr = sum(wb.get(name, [])) * 1024 / periods_w
         if rd + wr < 1:
             continue
+        # kernels that only the single-member priming calls launch (e.g. the row-per-lane level kernels of batches <= 4) are not the pipeline
+        if len(wb.get(name, [])) < 0.5 * len(wb[warp]) and len(fb.get(name, [])) < 0.5 * len(fb[warp]):
+            continue
         k = short(name)
         assert k not in per_kernel_bytes, k
         per_kernel_bytes[k] = {"read": int(rd), "write": int(wr), "dispatches_per_pair_period": round(len(wb.get(name, [])) / periods_w * a.batch, 2)}
