@@ -258,10 +258,12 @@ __device__ __forceinline__ unsigned warp_element(const Geom& g, const WarpArgs& 
     const size_t plane = (size_t)cz * H * Si;
     int ax = cx, ay = cy;
     const int mode = a.mode;
+    HF_DBG_CHECK(cx >= 0 && cx < W && cy >= 0 && cy < (cz ? (H >> 1) : H), 205);
     if (mode == 5 && cx < (W >> 1)) return A[plane + (size_t)cy * Si + cx];  // :133-135
     if (mode == 6) {                                                          // :136-150
         const int vo = (H >> 2) >> cz;
         const bool in_rows = cy >= vo && cy < vo + (H >> (1 + cz));
+        HF_DBG_CHECK(!(in_rows && cx < (W >> 1)) || (((cy - vo) << 1) < (cz ? (H >> 1) : H) && (cx << 1) + 1 < W), 206);
         if (in_rows && cx < (W >> 1)) return A[plane + (size_t)((cy - vo) << 1) * Si + (cx << 1) + (cz ? (cx & 1) : 0)];
         if (in_rows && cx < W) { ax = (cx - (W >> 1)) << 1; ay = (cy - vo) << 1; }
         else return cz ? T::midu : 0u;
@@ -468,7 +470,8 @@ __device__ __forceinline__ int mirror_warp_bl(int pos, int dim) {
 
 // GROUP elements of a plane row starting at element x (luma) / the chroma run for x_first = x
 template <typename E, int G, int CZ, bool DW>
-__device__ __forceinline__ Run<E, G> get_run(const E* __restrict__ rowp, int x) {
+__device__ __forceinline__ Run<E, G> get_run(const E* __restrict__ rowp, int x, [[maybe_unused]] int W = 1 << 30) {
+    HF_DBG_CHECK(x >= 0 && (CZ ? (x & ~1) : x) + G + (CZ ? 2 : 0) <= W + (CZ ? 2 : 0), 209);   // (a chroma run reads the pair behind it: still inside the row for interior runs)
     if constexpr (DW && G * sizeof(E) >= 4) {   // (smaller groups are never launched on the fast path)
         return CZ ? load_run_uv_dw<E, G>((const unsigned char*)rowp, x) : load_run_dw<E, G>((const unsigned char*)rowp, x);
     } else {
@@ -693,7 +696,7 @@ __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a,
             const int cy = min(cy0 + r, dim_y - 1);
             if (need_a) {
                 const E* rowp = A + (size_t)row_of(cy + dya[0]) * Si;
-                const Run<E, VEC> w = get_run<E, VEC, CZ, DW>(rowp, xa[0]);
+                const Run<E, VEC> w = get_run<E, VEC, CZ, DW>(rowp, xa[0], W);
 #pragma unroll
                 for (int k = 0; k < NG; k++)
 #pragma unroll
@@ -701,7 +704,7 @@ __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a,
             }
             if (need_b) {
                 const E* rowp = B + (size_t)row_of(cy + dyb[0]) * Si;
-                const Run<E, VEC> w = get_run<E, VEC, CZ, DW>(rowp, xb[0]);
+                const Run<E, VEC> w = get_run<E, VEC, CZ, DW>(rowp, xb[0], W);
 #pragma unroll
                 for (int k = 0; k < NG; k++)
 #pragma unroll
@@ -716,11 +719,11 @@ __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a,
             for (int k = 0; k < NG; k++) {
                 if (need_a) {
                     const E* rowp = A + (size_t)row_of(cy + dya[k]) * Si;
-                    S.ra[r][k] = get_run<E, GROUP, CZ, DW>(rowp, xa[k]);
+                    S.ra[r][k] = get_run<E, GROUP, CZ, DW>(rowp, xa[k], W);
                 }
                 if (need_b) {
                     const E* rowp = B + (size_t)row_of(cy + dyb[k]) * Si;
-                    S.rb[r][k] = get_run<E, GROUP, CZ, DW>(rowp, xb[k]);
+                    S.rb[r][k] = get_run<E, GROUP, CZ, DW>(rowp, xb[k], W);
                 }
             }
         }
@@ -734,11 +737,12 @@ __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a,
                 if (need_a) {
                     const E* rowp = A + (size_t)row_of(cy + dya[k]) * Si;
                     if (xa[k] >= 1 && xa[k] + GROUP - 1 <= W - 2) {
-                        S.ra[r][k] = get_run<E, GROUP, CZ, DW>(rowp, xa[k]);
+                        S.ra[r][k] = get_run<E, GROUP, CZ, DW>(rowp, xa[k], W);
                     } else {
 #pragma unroll
                         for (int i = 0; i < GROUP; i++) {
                             const int x = mirror_warp(xa[k] + i, W);
+                            HF_DBG_CHECK(x >= 0 && (CZ ? (x & ~1) + 1 : x) < W && rowp >= A && rowp < A + (size_t)dim_y * Si, 207);
                             S.ra[r][k].v[i] = rowp[CZ ? (x & ~1) + (i & 1) : x];
                         }
                     }
@@ -746,11 +750,12 @@ __device__ __forceinline__ void warp_fast_body(const Geom& g, const WarpArgs& a,
                 if (need_b) {
                     const E* rowp = B + (size_t)row_of(cy + dyb[k]) * Si;
                     if (xb[k] >= 1 && xb[k] + GROUP - 1 <= W - 2) {
-                        S.rb[r][k] = get_run<E, GROUP, CZ, DW>(rowp, xb[k]);
+                        S.rb[r][k] = get_run<E, GROUP, CZ, DW>(rowp, xb[k], W);
                     } else {
 #pragma unroll
                         for (int i = 0; i < GROUP; i++) {
                             const int x = mirror_warp(xb[k] + i, W);
+                            HF_DBG_CHECK(x >= 0 && (CZ ? (x & ~1) + 1 : x) < W && rowp >= B && rowp < B + (size_t)dim_y * Si, 208);
                             S.rb[r][k].v[i] = rowp[CZ ? (x & ~1) + (i & 1) : x];
                         }
                     }
