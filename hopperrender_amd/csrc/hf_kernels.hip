@@ -959,7 +959,7 @@ __device__ __forceinline__ void warp_wg_body(const Geom& g, const WarpArgs& a, c
                     lo = pk_mm_u16<false>(lo, ((uint32_t)by_lo << 16) | (uint32_t)bx_lo);
                     hi = pk_mm_u16<true>(hi, ((uint32_t)by_hi << 16) | (uint32_t)bx_hi);
                 }
-                return (uint32_t)(dy * 65536 + dxe * SZ + (CZ ? (dx & 1) : 0));
+                return (uint32_t)dy * 65536u + (uint32_t)(dxe * SZ + (CZ ? (dx & 1) : 0));   // (unsigned: extreme offsets wrap instead of overflowing; they are not stageable anyway)
             };
             for (int j = (int)tid >> lg; j < n; j += NT >> lg) {
                 float s12t = a.s12v[0], s21t = a.s21v[0];                      // (j differs between the lanes of a wave when the tile has < 64 cells)

@@ -70,6 +70,12 @@ V["st1m"] = lambda s: sub(s, "    const size_t out_off = (size_t)CZ * H * So + (
 V["stpred"] = lambda s: sub(s, "                __builtin_amdgcn_raw_buffer_store_b128(*(const buf_v4*)v, rsrc_out, out_off, (unsigned)r * out_pitch, 2 /* nt: streaming */);",
                             "                if (((const uint32_t*)v)[0] == 0x12345679u && ((const uint32_t*)v)[3] == 0x9abcdef1u) __builtin_amdgcn_raw_buffer_store_b128(*(const buf_v4*)v, rsrc_out, out_off, (unsigned)r * out_pitch, 2);")
 # the stores execute, the blend does not (XOR of the two runs), LDS reads kept -- with "noblend" this separates arithmetic from stores
+# windows as real motion makes them, but phase C reads its runs with ZERO displacement (aligned, inside the window: the tile itself lies in
+# the union of the runs' extents only if some output has no displacement -- t = 0 for source A; so: source A only, B reads A's window)
+V["czero"] = lambda s: sub(sub(s, "                const uint32_t w = base + d.x, wb = w & 0xFFFFu, odd = CZ ? (wb & 1u) : 0u, off = CZ ? (wb & ~1u) : wb;\n                const unsigned char* p = win_a +",
+                                  "                const uint32_t w = base + (n == 77 ? d.x : sh.tab[0][ci].x), wb = w & 0xFFFFu, odd = CZ ? (wb & 1u) : 0u, off = CZ ? (wb & ~1u) : wb;\n                const unsigned char* p = win_a +"),
+                           "                const uint32_t w = base + d.y, wb = w & 0xFFFFu, odd = CZ ? (wb & 1u) : 0u, off = CZ ? (wb & ~1u) : wb;\n                const unsigned char* p = win_b +",
+                           "                const uint32_t w = base + (n == 77 ? d.y : sh.tab[0][ci].y), wb = w & 0xFFFFu, odd = CZ ? (wb & 1u) : 0u, off = CZ ? (wb & ~1u) : wb;\n                const unsigned char* p = win_b +")
 def build(name):
     d = os.path.join(R, "hopperrender_amd/lib/exp", "w_" + name); os.makedirs(d, exist_ok=True)
     src = os.path.join(d, "hf_kernels.hip")
