@@ -105,9 +105,11 @@ def test_batch_of_16_strided_levels_and_a_misaligned_member(native_lib):
             b.free()
 
 
-def test_deferred_run_period_matches_the_reference_frames(native_lib):
-    """hf_batch_run_period with frames AND outputs on a plane-deferring batch -- the exact call of bench.py -- compared DIRECTLY
-    with the reference's golden frames (SHA-256), not through the eager order."""
+@pytest.mark.parametrize("n,n_batches", [(16, 1), (12, 4)])
+def test_deferred_run_period_matches_the_reference_frames(native_lib, n, n_batches):
+    """hf_batch_run_period with frames AND outputs on plane-deferring batches -- the exact call of bench.py, (12, 4) = its operating point:
+    four batch streams of 12 in flight at once -- compared DIRECTLY with the reference's golden frames (SHA-256), not through the eager
+    order."""
     from hopperrender_amd import capi
     from hopperrender_amd.calc import DeviceBuffer, FlowBatch, OpticalFlowCalcHDR
     g = Golden("hdr_2160p")
@@ -117,20 +119,24 @@ def test_deferred_run_period_matches_the_reference_frames(native_lib):
     dev = []
     for f in frames:
         b = DeviceBuffer(f.nbytes); b.upload(f); dev.append(b)
-    n = 16
+    N = n * n_batches
     lv = lambda i: (16.0, 235.0) if i % 4 == 3 else (0.0, 255.0)      # the golden file also holds warp_m2_t0.5_lv16_235
     members = [OpticalFlowCalcHDR(g.case["H"], g.case["W"], g.case["si"], g.case["so"], delta, nb, *lv(i), g.case.get("max_res", 270),
-                                  search_radius=R, flags=capi.HF_FLAG_ASYNC | capi.HF_FLAG_NO_TIMING) for i in range(n)]
-    batch = FlowBatch(members)
-    assert batch.defersPlanes()
-    outs = [[DeviceBuffer(members[0].output_frame_bytes) for _ in range(6)] for _ in range(n)]
+                                  search_radius=R, flags=capi.HF_FLAG_ASYNC | capi.HF_FLAG_NO_TIMING) for i in range(N)]
+    batches = [FlowBatch(members[k * n:(k + 1) * n]) for k in range(n_batches)]
+    assert all(b.defersPlanes() for b in batches)
+    outs = [[DeviceBuffer(members[0].output_frame_bytes) for _ in range(6)] for _ in range(N)]
     optr = [[b.ptr for b in o] for o in outs]
-    plans = [[0.5, 0.25, 0.75] if i % 4 == 3 else (T6[i % 6:] + T6[:i % 6])[:5 + (i % 2)] for i in range(n)]
-    batch.runPeriod(batch.preparePeriod([dev[0].ptr] * n, None, None, calculate_flow=False))
-    batch.runPeriod(batch.preparePeriod([dev[1].ptr] * n, None, None, calculate_flow=False))
-    batch.runPeriod(batch.preparePeriod([dev[2].ptr] * n, plans, optr, 2))           # flow (f1, f2); its outputs use the (zero) flow before it
-    batch.runPeriod(batch.preparePeriod([dev[3].ptr] * n, plans, optr, 2))           # deferred: warp (f1, f2; flow a) first, builds f2's plane
-    batch.sync()
+    plans = [[0.5, 0.25, 0.75] if i % 4 == 3 else (T6[i % 6:] + T6[:i % 6])[:5 + (i % 2)] for i in range(N)]
+    for k in range(4):                                   # period by period over all batches, nothing in between (as bench.py issues them)
+        for bi, b in enumerate(batches):
+            lo, hi = bi * n, (bi + 1) * n
+            if k < 2:
+                b.runPeriod(b.preparePeriod([dev[k].ptr] * n, None, None, calculate_flow=False))
+            else:   # k = 2: flow (f1, f2), outputs from the (zero) flow before it; k = 3: deferred -- warp (f1, f2; flow a) first, builds f2's plane
+                b.runPeriod(b.preparePeriod([dev[k].ptr] * n, plans[lo:hi], optr[lo:hi], 2))
+    for b in batches:
+        b.sync()
     names = g.frame_names(key)
     n_checked = 0
     for i, m in enumerate(members):
@@ -141,8 +147,9 @@ def test_deferred_run_period_matches_the_reference_frames(native_lib):
             if fname in names:
                 assert sha(outs[i][j].download(np.uint16)) == g.frame_sha(key, fname), (i, fname)
                 n_checked += 1
-    assert n_checked >= 20
-    batch.close()
+    assert n_checked >= N
+    for b in batches:
+        b.close()
     for m in members:
         m.close()
     for b in dev + [x for o in outs for x in o]:
