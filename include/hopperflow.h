@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HF_ABI_VERSION 3
+#define HF_ABI_VERSION 4
 
 typedef struct hf_ctx hf_ctx;
 
