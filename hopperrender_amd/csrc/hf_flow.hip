@@ -22,6 +22,7 @@
 //     level only needs the window's own new X offset plus LAST level's Y offsets of its neighbours, so X
 //     and Y of a level run in ONE launch (5 launches for levels 32..2).  Larger windows take two
 //     launches per axis (partial sums with one atomic per candidate per workgroup, then a tiny argmin).
+#include <utility>
 #include "hf_kernels.h"
 #include "hf_phase_plane.h"
 
@@ -293,6 +294,170 @@ __device__ __forceinline__ void strip_sads(uint32_t* sad, const Geom& g, const F
         }
         sad[cz] = t;
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Y step of a tile that lies in ONE window, out of LDS
+// ------------------------------------------------------------------------------------------
+// A Y step reads, for grid row r and candidate c, plane row ((cy0 + r) << rs) + oy + rel(c) at ONE column segment: a 16 x 16 window is
+// 16 rows x 16 candidates = 256 row segments of 64 bytes, each an L2 request of its own (two 64-byte sectors at dword alignment; PMC of
+// round 4: the level-16 launch pulled 1.02 x its candidate bytes through the L1s, the Y steps all of them, while the X steps of the wide
+// tiles re-use their lines: 0.19 x).  But rel(c) = S k + rho (S = 2^rs) and row = S (cy0 + r + k) + oy + rho: the candidates of one residue
+// class rho walk the SAME rows P_rho[j] = S (cy0 + j) + oy + rho, j = r + k -- 95 distinct rows for 16 grid rows at rs = 3, 97 at rs = 2,
+// not 256.  The workgroup copies those rows once into LDS (direct-to-LDS buffer loads, 16 bytes per lane, the rows of a class
+// consecutive) and every candidate is then ONE ds_read_b128 at the thread's own chunk + a compile-time row offset (threads are row-major
+// over the tile: 64 lanes read 1 KB contiguous, conflict-free).  Same bytes, same order of additions as strip_sads: identical results.
+template <int... I, class F> __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+__host__ __device__ constexpr int rel16(int cz) { const int d = cz - 8; return d > 0 ? d * d : -(d * d); }
+// RS: log2 of the frame-to-grid ratio; WROWS: grid rows of the tile; LPR: threads per tile row (4 grid pixels each); NW: waves of the workgroup
+template <int RS, int WROWS, int LPR, int NW> struct YRows {
+    static constexpr int S = 1 << RS;
+    __host__ __device__ static constexpr int rho(int cz) { return rel16(cz) & (S - 1); }
+    __host__ __device__ static constexpr int k(int cz) { return (rel16(cz) - rho(cz)) / S; }
+    // classes in order of first appearance; a class is named by any of its candidates
+    __host__ __device__ static constexpr bool first_of_class(int cz) { for (int i = 0; i < cz; i++) if (rho(i) == rho(cz)) return false; return true; }
+    __host__ __device__ static constexpr int kmin(int cz) { int m = k(cz); for (int i = 0; i < 16; i++) if (rho(i) == rho(cz) && k(i) < m) m = k(i); return m; }
+    __host__ __device__ static constexpr int kmax(int cz) { int m = k(cz); for (int i = 0; i < 16; i++) if (rho(i) == rho(cz) && k(i) > m) m = k(i); return m; }
+    __host__ __device__ static constexpr int rows(int cz) { return WROWS + kmax(cz) - kmin(cz); }                       // staged rows of cz's class
+    __host__ __device__ static constexpr int base(int cz) {                                                              // first staged row of cz's class
+        int b = 0;
+        for (int i = 0; i < 16; i++) { if (rho(i) == rho(cz)) return b; if (first_of_class(i)) b += rows(i); }
+        return b;
+    }
+    __host__ __device__ static constexpr int total() { int b = 0; for (int i = 0; i < 16; i++) if (first_of_class(i)) b += rows(i); return b; }
+    __host__ __device__ static constexpr int row0(int cz) { return base(cz) + k(cz) - kmin(cz); }                        // staged row of candidate cz for tile row 0
+    __host__ __device__ static constexpr int disp(int cz) { return S * (kmin(cz) - base(cz)) + rho(cz); }                // plane row of staged row q of the class = S cy0 + oy + disp + S q
+    static constexpr int kTotal = total();
+    static constexpr int kCopies = (kTotal * LPR + 64 * NW - 1) / (64 * NW);                                              // copy instructions per wave (64 x 16 bytes each)
+    static constexpr int kDwords = kCopies * NW * 256;                                                                    // LDS
+};
+template <int WROWS, int LPR, int NW> constexpr int ystage_dwords() {
+    return YRows<2, WROWS, LPR, NW>::kDwords > YRows<3, WROWS, LPR, NW>::kDwords ? YRows<2, WROWS, LPR, NW>::kDwords : YRows<3, WROWS, LPR, NW>::kDwords;
+}
+
+// tid: thread of the workgroup, row-major over the tile (tile row tid / LPR); (wx0, cy0): first grid column / row of the tile; ref: the thread's
+// four frame-N samples.  Workgroup-uniform call (contains a barrier when NW > 1).
+template <int RS, int WROWS, int LPR, int NW>
+__device__ __forceinline__ void ysads_tile_lds(uint32_t* sad, const FlowStep& a, const uint32_t* ref, int ox, int oy, int wx0, int cy0, int tid, uint32_t* stage) {
+    using Y = YRows<RS, WROWS, LPR, NW>;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const PhaseLayout& pl = a.pl;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const unsigned row_el = (unsigned)(pl.nph2 * pl.lwp);
+    const int ph0 = ox & (pl.nph - 1);
+    const unsigned colbase = (unsigned)((ph0 >> 1) * pl.lwp + pl.mx + wx0 + (ox >> RS));
+    const int rowbase = (cy0 << RS) + oy;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.pp1, 0, (int)pl.bytes, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < Y::kCopies; i++) {
+        const int t0 = (i * NW + wave) * 64;                    // wave-uniform
+        const int t = t0 + lane;
+        const int q = min(t / LPR, Y::kTotal - 1);              // (spare slots behind the last row copy it again)
+        int d = 0;
+        static_for<16>([&](auto CZ) {                            // class of staged row q (compile-time tables, one compare per class)
+            constexpr int cz = decltype(CZ)::value;
+            if constexpr (Y::first_of_class(cz)) {
+                constexpr int b = Y::base(cz), dd = Y::disp(cz);
+                if (cz == 0 || q >= b) d = dd;
+            }
+        });
+        const unsigned off = (__umul24((unsigned)(rowbase + d + (q << RS)), row_el) + colbase + (unsigned)((t & (LPR - 1)) * 4)) * 4u;
+        HF_DBG_CHECK(rowbase + d + (q << RS) >= 0 && (size_t)off + 16 <= pl.bytes, 108);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(stage + t0 * 4), 16, off, 0, 0, 0);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                        // vmcnt(0): this wave's rows are in LDS
+    if constexpr (NW > 1) __syncthreads();
+    const uint32_t sel = 0x03020c00u | (unsigned)(ph0 & 1);
+    typedef __attribute__((address_space(3))) const flow_v4* lds_chunks;
+    const lds_chunks mine = (lds_chunks)stage + tid;           // tile row r of a class lies LPR r chunks behind the class's row for tile row 0
+    flow_v4 c1[16];
+    static_for<16>([&](auto CZ) {
+        constexpr int cz = decltype(CZ)::value, chunk = Y::row0(cz) * LPR;
+        c1[cz] = mine[chunk];
+    });
+#pragma unroll
+    for (int cz = 0; cz < 16; cz++) {
+        uint32_t t = sad[cz];
+#pragma unroll
+        for (int i = 0; i < 4; i++) t = __builtin_amdgcn_sad_u8(__builtin_amdgcn_perm(c1[cz][i], c1[cz][i], sel), ref[i], t);
+        sad[cz] = t;
+    }
+}
+
+// The staged form applies to full tiles (R = 16) of planes with rs = 2 or 3 whose candidate rows need no reflection.  ox, oy: the window's.
+template <int WROWS, int LPR, int NW>
+__device__ __forceinline__ bool ysads_tile_try(uint32_t* sad, const Geom& g, const FlowStep& a, const uint32_t* ref, int ox, int oy, int wx0, int cy0, int tid, uint32_t* stage) {
+    ox = __builtin_amdgcn_readfirstlane(ox); oy = __builtin_amdgcn_readfirstlane(oy);
+    wx0 = __builtin_amdgcn_readfirstlane(wx0); cy0 = __builtin_amdgcn_readfirstlane(cy0);
+    if (g.rs != 2 && g.rs != 3) return false;
+    if ((cy0 << g.rs) + oy + rel16(0) < 0 || ((cy0 + WROWS - 1) << g.rs) + oy + rel16(15) > g.H - 1) return false;
+    if (g.rs == 3) ysads_tile_lds<3, WROWS, LPR, NW>(sad, a, ref, ox, oy, wx0, cy0, tid, stage);
+    else ysads_tile_lds<2, WROWS, LPR, NW>(sad, a, ref, ox, oy, wx0, cy0, tid, stage);
+    return true;
+}
+
+// The same for 8 x 8 windows, four per wave (Map<8>: 16 lanes = one window, lane i of it = tile row i / 2, column group i & 1): every window
+// has its own offsets, so each 16-lane group copies ITS 63 (rs = 3) / 73 (rs = 2) rows of 32 bytes -- 128 row segments per window before --
+// with per-lane addresses.  A copy instruction lands lane-contiguous in LDS: slot t of window w lies at 1,024 (t / 16) + 256 w + 16 (t % 16).
+template <int RS>
+__device__ __forceinline__ void ysads_win8_lds(uint32_t* sad, const FlowStep& a, const uint32_t* ref, int ox, int oy, int cx0, int cy, int lane, uint32_t* stage) {
+    using Y = YRows<RS, 8, 2, 1>;
+    constexpr int kCopies = (Y::kTotal * 2 + 15) / 16;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const PhaseLayout& pl = a.pl;
+    const int i16 = lane & 15;
+    const unsigned row_el = (unsigned)(pl.nph2 * pl.lwp);
+    const int ph0 = ox & (pl.nph - 1);
+    const unsigned colbase = (unsigned)((ph0 >> 1) * pl.lwp + pl.mx + (cx0 - (i16 & 1) * 4) + (ox >> RS));
+    const int rowbase = ((cy - (i16 >> 1)) << RS) + oy;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.pp1, 0, (int)pl.bytes, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < kCopies; i++) {
+        const int t = i * 16 + i16;
+        const int q = min(t >> 1, Y::kTotal - 1);
+        int d = 0;
+        static_for<16>([&](auto CZ) {
+            constexpr int cz = decltype(CZ)::value;
+            if constexpr (Y::first_of_class(cz)) {
+                constexpr int b = Y::base(cz), dd = Y::disp(cz);
+                if (cz == 0 || q >= b) d = dd;
+            }
+        });
+        const unsigned off = (__umul24((unsigned)(rowbase + d + (q << RS)), row_el) + colbase + (unsigned)((t & 1) * 4)) * 4u;
+        HF_DBG_CHECK(rowbase + d + (q << RS) >= 0 && (size_t)off + 16 <= pl.bytes, 109);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(stage + i * 256), 16, off, 0, 0, 0);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                        // vmcnt(0); one wave = one workgroup
+    const uint32_t sel = 0x03020c00u | (unsigned)(ph0 & 1);
+    typedef __attribute__((address_space(3))) const flow_v4* lds_chunks;
+    const lds_chunks mine = (lds_chunks)stage + (lane >> 4) * 16;   // the window's 16 chunks of copy 0
+    flow_v4 c1[16];
+    static_for<16>([&](auto CZ) {
+        constexpr int cz = decltype(CZ)::value, c2 = Y::row0(cz) * 2, A = c2 & 15;
+        const int u = A + i16;                                  // slot c2 + i16 = copy (c2 / 16) + (u / 16), chunk u % 16
+        c1[cz] = mine[(c2 >> 4) * 64 + u + (A != 0 && u >= 16 ? 48 : 0)];
+    });
+#pragma unroll
+    for (int cz = 0; cz < 16; cz++) {
+        uint32_t t = sad[cz];
+#pragma unroll
+        for (int i = 0; i < 4; i++) t = __builtin_amdgcn_sad_u8(__builtin_amdgcn_perm(c1[cz][i], c1[cz][i], sel), ref[i], t);
+        sad[cz] = t;
+    }
+}
+constexpr int kWin8StageDwords = ((YRows<2, 8, 2, 1>::kTotal * 2 + 15) / 16) * 256;   // rs = 2 needs more rows than rs = 3
+static_assert(YRows<2, 8, 2, 1>::kTotal >= YRows<3, 8, 2, 1>::kTotal, "LDS of the 8 x 8 windows");
+
+// cx0, cy, ox, oy: the lane's own (per window).  Taken only if all four windows of the wave need no reflection.
+__device__ __forceinline__ bool ysads_win8_try(uint32_t* sad, const Geom& g, const FlowStep& a, const uint32_t* ref, int ox, int oy, int cx0, int cy, int lane, uint32_t* stage) {
+    if (g.rs != 2 && g.rs != 3) return false;
+    const int cy0 = cy - ((lane & 15) >> 1);
+    const bool outside = (cy0 << g.rs) + oy + rel16(0) < 0 || ((cy0 + 7) << g.rs) + oy + rel16(15) > g.H - 1;
+    if (__builtin_amdgcn_ballot_w64(outside) != 0) return false;
+    if (g.rs == 3) ysads_win8_lds<3>(sad, a, ref, ox, oy, cx0, cy, lane, stage);
+    else ysads_win8_lds<2>(sad, a, ref, ox, oy, cx0, cy, lane, stage);
+    return true;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -588,7 +753,7 @@ template <int WS> struct MapSel<WS, true> { using type = MapRow<WS>; };
 // (TileId::wave).  A 480x270 grid has only 135 tiles for 256 CUs; split, every CU's L1 takes a share of the
 // candidate rows' cache lines (a Y step pulls ~16 x 8 row segments per wave, 32 useful bytes per 128-byte line).
 template <int WS, bool SPLIT, bool FULL, bool ROWS1>
-__device__ __forceinline__ void flow_level_small_body(const Geom& g, const FlowStep& a, const TileId& tile, uint32_t (*s_part)[4][16]) {
+__device__ __forceinline__ void flow_level_small_body(const Geom& g, const FlowStep& a, const TileId& tile, uint32_t (*s_part)[4][16], [[maybe_unused]] uint32_t* s_rows) {
     using M = typename MapSel<WS, ROWS1>::type;
     constexpr int PX = M::PX, G = M::G;
     const int R = FULL ? 16 : a.R;
@@ -619,8 +784,18 @@ __device__ __forceinline__ void flow_level_small_body(const Geom& g, const FlowS
         uint32_t sad[16];
 #pragma unroll
         for (int cz = 0; cz < 16; cz++) sad[cz] = 0u;
+        bool from_lds = false;
+        if constexpr (WS == 16 && FULL && SPLIT) {          // one wave = one window
+            if (axis == 1) from_lds = ysads_tile_try<16, 4, 1>(sad, g, a, strip[0].ref, off[0], off[1], cx0, cy, lane, s_rows);   // (lane 0 holds the window's origin)
+        } else if constexpr (WS == 8 && FULL && SPLIT) {    // one wave = four windows
+            if (axis == 1) from_lds = ysads_win8_try(sad, g, a, strip[0].ref, off[0], off[1], cx0, cy, lane, s_rows);
+        } else if constexpr (WS == 32 && FULL) {           // the workgroup = one window
+            if (axis == 1) from_lds = ysads_tile_try<32, 8, 4>(sad, g, a, strip[0].ref, off[0], off[1], cx0 - lx, cy - ly, tid, s_rows);
+        }
+        if (!from_lds) {
 #pragma unroll
-        for (int r = 0; r < M::NR; r++) strip_sads<PX, G == 64, FULL>(sad, g, a, strip[r], off[0], off[1], axis);
+            for (int r = 0; r < M::NR; r++) strip_sads<PX, G == 64, FULL>(sad, g, a, strip[r], off[0], off[1], axis);
+        }
         int first = group_reduce<G, M::XM>(sad, lane);
         if constexpr (WS == 32) {   // four waves share the window
             if ((lane & 3) == 0) s_part[axis][wave][first] = sad[0];
@@ -649,21 +824,22 @@ __global__ __launch_bounds__(SPLIT ? 64 : 256) void flow_level_small_kernel(cons
     const FlowStep a = member_step(batch, tile.pair);
     static_assert(!SPLIT || WS <= 16, "a 32x32 window is shared by the four waves of a workgroup");
     __shared__ uint32_t s_part[SPLIT ? 1 : 2][4][16];
+    __shared__ __attribute__((aligned(16))) uint32_t s_rows[WS == 16 && SPLIT ? ystage_dwords<16, 4, 1>() : WS == 32 ? ystage_dwords<32, 8, 4>() : WS == 8 && SPLIT ? kWin8StageDwords : 4];   // ysads_tile_lds
     // Workgroup-uniform choice: tiles that lie inside the grid with the full search radius (all but the last tile row /
     // column once the governor has settled at 16) run a body without validity masks and per-candidate tests.
     // (Registers: 16 candidates x 16 bytes in flight per row = ~100 per lane for the one-row levels, 140-170 for the block levels.  Capping
     //  the one-row levels and the partial kernel at 72 -- 8 candidates in flight -- lets a chain wave fit beside the period warp's five waves
     //  per SIMD: inside the pipeline the warp launch then got 11 % shorter and the chain 39 % longer, the same frames/s; DESIGN.md appendix D.)
     const bool full = a.R == 16 && (tile.tx + 1) * M::TW <= g.lw && (tile.ty + 1) * M::TH <= g.lh;
-    if (full) flow_level_small_body<WS, SPLIT, true, ROWS1>(g, a, tile, s_part);
-    else flow_level_small_body<WS, SPLIT, false, ROWS1>(g, a, tile, s_part);
+    if (full) flow_level_small_body<WS, SPLIT, true, ROWS1>(g, a, tile, s_part, s_rows);
+    else flow_level_small_body<WS, SPLIT, false, ROWS1>(g, a, tile, s_part, s_rows);
 }
 
 // Windows > 32, one axis: raw SAD sums of a 32 x (8 * WPB) tile -> one atomic per candidate.
 // WPB = waves per workgroup.  Fewer waves per workgroup = more workgroups for the 256 CUs (a 480x270 grid has 135
 // 32x32 tiles) at the price of more atomics on the same R addresses of each window.
 template <int WPB, bool FULL>
-__device__ __forceinline__ void flow_big_partial_body(const Geom& g, const FlowStep& a, const TileId& tile, uint32_t (*s_part)[16]) {
+__device__ __forceinline__ void flow_big_partial_body(const Geom& g, const FlowStep& a, const TileId& tile, uint32_t (*s_part)[16], [[maybe_unused]] uint32_t* s_rows) {
     const int R = FULL ? 16 : a.R;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // wave = 64 grid pixels x 4 rows: the 16 lanes the texture addresser handles together read 256 contiguous bytes of ONE
@@ -688,7 +864,9 @@ __device__ __forceinline__ void flow_big_partial_body(const Geom& g, const FlowS
     uint32_t sad[16];
 #pragma unroll
     for (int cz = 0; cz < 16; cz++) sad[cz] = 0u;
-    strip_sads<4, true, FULL>(sad, g, a, strip, ox, oy, a.axis);
+    bool from_lds = false;
+    if constexpr (FULL && WPB == 4) if (a.axis == 1) from_lds = ysads_tile_try<16, 16, 4>(sad, g, a, strip.ref, ox, oy, tx0, ty0, tid, s_rows);
+    if (!from_lds) strip_sads<4, true, FULL>(sad, g, a, strip, ox, oy, a.axis);
     const int first = group_reduce<64>(sad, lane);
     HF_DBG_CHECK(wx >= 0 && wy >= 0 && wx < a.cur.nwx && wy < a.cur.nwy, 106);
     uint32_t* dst = &a.sums[(wy * a.cur.nwx + wx) * 16];
@@ -712,9 +890,10 @@ __global__ __launch_bounds__(64 * WPB) void flow_big_partial_kernel(const Geom g
     if (!tile.valid) return;
     const FlowStep a = member_step(batch, tile.pair);
     __shared__ uint32_t s_part[WPB][16];
+    __shared__ __attribute__((aligned(16))) uint32_t s_rows[WPB == 4 ? ystage_dwords<16, 16, 4>() : 4];   // Y launches: ysads_tile_lds
     const bool full = a.R == 16 && (tile.tx + 1) * 64 <= g.lw && (tile.ty + 1) * (4 * WPB) <= g.lh;   // see flow_level_small_kernel
-    if (full) flow_big_partial_body<WPB, true>(g, a, tile, s_part);
-    else flow_big_partial_body<WPB, false>(g, a, tile, s_part);
+    if (full) flow_big_partial_body<WPB, true>(g, a, tile, s_part, s_rows);
+    else flow_big_partial_body<WPB, false>(g, a, tile, s_part, s_rows);
 }
 
 // Windows > 32, one axis: 16 lanes per window finish the sums, pick the winner, update the table.
