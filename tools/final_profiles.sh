@@ -38,4 +38,9 @@ cd $R
 # instructions per wave of the staged period warp (16-member launches) and its SQ / TD / TA / TCP / TCC counters
 bash tools/pmc_warp_valu.sh product > $O/pmc_warp_valu.txt 2>&1
 bash tools/pmc_warp_batch.sh 16 > $O/pmc_warp_wg_kernel.txt 2>&1
+# the 12 chain launches alone, 16 pairs per launch: busy fractions, occupancy, L2 -> L1 bytes
+{ echo "# tools/pmc_chain_batch.sh 16: the 12 launches of the flow chain alone, 16 pairs per launch (2160p HDR = 480 x 270 grid), read by tools/pmc_chain_derive.py."
+  echo "# Useful candidate bytes per launch (16 pairs x 129,600 pixels x 16 candidates x 4 B) = 132.7 MB per axis: 1 axis for flow_big_partial, 2 for the level kernels."
+  echo "# valu% = vector ALU busy, wait% = share of wave-cycles spent waiting, td% / tcc% = texture-data unit / L2 channels busy, L2->L1 = TCP_TCC_READ_REQ x 64 B."
+  bash tools/pmc_chain_batch.sh 16 2>&1 | grep -v " rc=0$"; } > $O/pmc_chain_batch16.txt
 ls $O
