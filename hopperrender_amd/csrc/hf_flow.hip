@@ -332,6 +332,14 @@ template <int RS, int WROWS, int LPR, int NW> struct YRows {
     static constexpr int kCopies = (kTotal * LPR + 64 * NW - 1) / (64 * NW);                                              // copy instructions per wave (64 x 16 bytes each)
     static constexpr int kDwords = kCopies * NW * 256;                                                                    // LDS
 };
+// staged row q of a class holds plane row S cy0 + oy + disp + S q: for tile row r, candidate cz that must be S (cy0 + r) + oy + rel16(cz)
+template <int RS> constexpr bool yrows_consistent() {
+    using Y = YRows<RS, 16, 4, 1>;
+    for (int cz = 0; cz < 16; cz++)
+        if (Y::disp(cz) + Y::S * Y::row0(cz) != rel16(cz) || Y::row0(cz) < Y::base(cz) || Y::row0(cz) + 16 > Y::base(cz) + Y::rows(cz)) return false;
+    return true;
+}
+static_assert(yrows_consistent<2>() && yrows_consistent<3>() && YRows<3, 16, 4, 1>::kTotal == 95 && YRows<2, 16, 4, 1>::kTotal == 97, "class tables of the staged Y step");
 template <int WROWS, int LPR, int NW> constexpr int ystage_dwords() {
     return YRows<2, WROWS, LPR, NW>::kDwords > YRows<3, WROWS, LPR, NW>::kDwords ? YRows<2, WROWS, LPR, NW>::kDwords : YRows<3, WROWS, LPR, NW>::kDwords;
 }
