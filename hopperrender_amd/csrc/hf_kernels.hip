@@ -84,6 +84,66 @@ __global__ __launch_bounds__(256) void blur_flow_kernel(const BlurBatch batch, i
         for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < zero_count; i += nthreads) zero[i] = 0u;
     }
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if constexpr (TS == 32 && RFIX == 4) {
+        // A chain that ended at 2 x 2 windows on a grid of even size (the usual case): the 8 taps of an output are pixels X - 4 .. X + 3 = four
+        // whole windows for even X, half + three + half windows for odd X, so with S4[i] = v[i] + .. + v[i + 3] over WINDOWS the row sum is
+        // S4[a] + S4[a + (X & 1)], a = (X - 4 - (X & 1)) / 2, and the 8 x 8 sum four reads of W44 = the 4 x 4 window sums: 20 x 20 gathered
+        // offsets instead of 40 x 40, 4 + 4 LDS reads per output instead of 8 + 16.  Integer sums: the same value as the tap loops below.
+        // (Even sizes: the reflection of blurFlowKernelSDR.h:7-14 then maps pixel pairs onto pixel pairs, i.e. windows onto windows.)
+        const int X0 = blockIdx.x * 32, Y0 = blockIdx.y * 32;
+        if (L.tx && L.ty && L.log2w == 1 && !(lw & 1) && !(lh & 1) && lw >= 64 && lh >= 64 && L.nwx * 2 == lw && L.nwy * 2 == lh) {   // kernel-uniform
+            constexpr int NW = 20, NS = 17;                   // windows per tile edge, S4 / W44 values per edge
+            uint32_t* v = (uint32_t*)smem;                    // [NW][NW] packed offsets
+            int* hsx = (int*)(v + NW * NW);                   // [NW][NS] horizontal 4-window sums
+            int* hsy = hsx + NW * NS;
+            int* wx = hsy + NW * NS;                          // [NS][NS] 4 x 4 window sums
+            int* wy = wx + NS * NS;
+            const int tid = threadIdx.x;
+            const int wa0 = X0 / 2 - 2, wb0 = Y0 / 2 - 2;
+            for (int i = tid; i < NW * NW; i += 256) {
+                const int j = i / NW, k = i - j * NW;
+                int wa = wa0 + k, wb = wb0 + j;
+                wa = wa < 0 ? -1 - wa : wa >= L.nwx ? 2 * L.nwx - 1 - wa : wa;
+                wb = wb < 0 ? -1 - wb : wb >= L.nwy ? 2 * L.nwy - 1 - wb : wb;
+                const int w = wb * L.nwx + wa;
+                HF_DBG_CHECK(wb >= 0 && wb < L.nwy && wa >= 0 && wa < L.nwx, 201);
+                v[i] = (uint32_t)(uint16_t)L.tx[w] | ((uint32_t)(uint16_t)L.ty[w] << 16);
+            }
+            __syncthreads();
+            for (int i = tid; i < NW * NS; i += 256) {
+                const int j = i / NS, k = i - j * NS;
+                int sx = 0, sy = 0;
+#pragma unroll
+                for (int t = 0; t < 4; t++) { const uint32_t w = v[j * NW + k + t]; sx += (int)(int16_t)(w & 0xFFFFu); sy += (int)w >> 16; }
+                hsx[i] = sx; hsy[i] = sy;
+            }
+            __syncthreads();
+            for (int i = tid; i < NS * NS; i += 256) {
+                const int j = i / NS, k = i - j * NS;
+                int sx = 0, sy = 0;
+#pragma unroll
+                for (int t = 0; t < 4; t++) { sx += hsx[(j + t) * NS + k]; sy += hsy[(j + t) * NS + k]; }
+                wx[i] = sx; wy[i] = sy;
+            }
+            __syncthreads();
+            const int tx = tid & 31, ty = tid >> 5;           // 32 x 8 threads, four output rows each
+            const int ax = (tx - (tx & 1)) / 2, dx = tx & 1;  // (X0 is even: the parity of X is tx's)
+#pragma unroll
+            for (int o = 0; o < 4; o++) {
+                const int cy = ty + 8 * o, ay = (cy - (cy & 1)) / 2, dy = cy & 1;
+                const int i00 = ay * NS + ax, i01 = i00 + dx, i10 = i00 + dy * NS, i11 = i10 + dx;
+                const int sx = wx[i00] + wx[i01] + wx[i10] + wx[i11], sy = wy[i00] + wy[i01] + wy[i10] + wy[i11];
+                const int rx = (int)(int16_t)div_trunc(sx, 64, 6), ry = (int)(int16_t)div_trunc(sy, 64, 6);
+                if (X0 + tx < lw && Y0 + cy < lh) {
+                    const size_t q = (size_t)(Y0 + cy) * lw + X0 + tx;
+                    blurred[q] = (int16_t)rx;
+                    blurred[(size_t)lw * lh + q] = (int16_t)ry;
+                    packed[q] = ((uint32_t)rx & 0xFFFFu) | ((uint32_t)ry << 16);
+                }
+            }
+            return;
+        }
+    }
     const int T = TS + 2 * r;                     // tile edge
     uint32_t* tile = (uint32_t*)smem;             // [T][T] packed offsets
     int* hx = (int*)(tile + T * T);               // [T][TS] horizontal sums of x
