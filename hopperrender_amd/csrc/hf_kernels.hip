@@ -1327,8 +1327,11 @@ __global__ void rcp_probe_kernel(const float* in, float* out, int n) {
 // launchers
 // ------------------------------------------------------------------------------------------
 void launch_blur_flow(const Geom& g, const BlurBatch& b, int radius, int zero_count, hipStream_t stream) {
-    if (radius == 4 && b.n > 4) {   // the reference's radius in a batch: 32 x 32 outputs per workgroup, taps unrolled (a single pair is
-                                    // faster with four times the workgroups: 4.3 vs 6.0 us)
+    // the window-sum form of blur_flow_kernel<32, 4> applies (same test as in the kernel): then 32 x 32 tiles are the faster ones at every batch size
+    const FlowLevel& L = b.s[0].last;
+    const bool window_sums = L.tx && L.ty && L.log2w == 1 && !(g.lw & 1) && !(g.lh & 1) && g.lw >= 64 && g.lh >= 64 && L.nwx * 2 == g.lw && L.nwy * 2 == g.lh;
+    if (radius == 4 && (b.n > 4 || window_sums)) {   // the reference's radius: 32 x 32 outputs per workgroup, taps unrolled (with the tap loops a single
+                                                     // pair is faster with four times the workgroups: 4.3 vs 6.0 us)
         const dim3 grd((g.lw + 31) / 32, (g.lh + 31) / 32, b.n);
         const int T = 32 + 8;
         const size_t smem = (size_t)T * T * sizeof(uint32_t) + 2 * (size_t)T * 32 * sizeof(int);   // 16.6 KB
