@@ -43,4 +43,5 @@ bash tools/pmc_warp_batch.sh 16 > $O/pmc_warp_wg_kernel.txt 2>&1
   echo "# Useful candidate bytes per launch (16 pairs x 129,600 pixels x 16 candidates x 4 B) = 132.7 MB per axis: 1 axis for flow_big_partial, 2 for the level kernels."
   echo "# valu% = vector ALU busy, wait% = share of wave-cycles spent waiting, td% / tcc% = texture-data unit / L2 channels busy, L2->L1 = TCP_TCC_READ_REQ x 64 B."
   bash tools/pmc_chain_batch.sh 16 2>&1 | grep -v " rc=0$"; } > $O/pmc_chain_batch16.txt
+python3 tools/chain_beside_warp.py $O/stats_default/p_kernel_trace.csv > $O/chain_beside_warp.txt 2>&1
 ls $O
