@@ -339,9 +339,13 @@ template <int RS> constexpr bool yrows_consistent() {
         if (Y::disp(cz) + Y::S * Y::row0(cz) != rel16(cz) || Y::row0(cz) < Y::base(cz) || Y::row0(cz) + 16 > Y::base(cz) + Y::rows(cz)) return false;
     return true;
 }
-static_assert(yrows_consistent<2>() && yrows_consistent<3>() && YRows<3, 16, 4, 1>::kTotal == 95 && YRows<2, 16, 4, 1>::kTotal == 97, "class tables of the staged Y step");
-template <int WROWS, int LPR, int NW> constexpr int ystage_dwords() {
-    return YRows<2, WROWS, LPR, NW>::kDwords > YRows<3, WROWS, LPR, NW>::kDwords ? YRows<2, WROWS, LPR, NW>::kDwords : YRows<3, WROWS, LPR, NW>::kDwords;
+static_assert(yrows_consistent<0>() && yrows_consistent<1>() && yrows_consistent<2>() && yrows_consistent<3>() && yrows_consistent<4>() &&
+              YRows<3, 16, 4, 1>::kTotal == 95 && YRows<2, 16, 4, 1>::kTotal == 97, "class tables of the staged Y step");
+// Dynamic LDS of a launch whose tiles may take the staged Y step (0: this rs keeps the gathers).  The launch passes exactly what its
+// geometry needs: 24 KB for the partial kernel's Y launches at rs = 3, nothing for its X launches.
+template <int WROWS, int LPR, int NW> constexpr size_t ystage_bytes(int rs) {
+    return 4 * (size_t)(rs == 0 ? YRows<0, WROWS, LPR, NW>::kDwords : rs == 1 ? YRows<1, WROWS, LPR, NW>::kDwords : rs == 2 ? YRows<2, WROWS, LPR, NW>::kDwords :
+                        rs == 3 ? YRows<3, WROWS, LPR, NW>::kDwords : rs == 4 ? YRows<4, WROWS, LPR, NW>::kDwords : 0);
 }
 
 // tid: thread of the workgroup, row-major over the tile (tile row tid / LPR); (wx0, cy0): first grid column / row of the tile; ref: the thread's
@@ -393,15 +397,20 @@ __device__ __forceinline__ void ysads_tile_lds(uint32_t* sad, const FlowStep& a,
     }
 }
 
-// The staged form applies to full tiles (R = 16) of planes with rs = 2 or 3 whose candidate rows need no reflection.  ox, oy: the window's.
+// The staged form applies to full tiles (R = 16) of planes with rs <= 4 whose candidate rows need no reflection.  ox, oy: the window's.
 template <int WROWS, int LPR, int NW>
 __device__ __forceinline__ bool ysads_tile_try(uint32_t* sad, const Geom& g, const FlowStep& a, const uint32_t* ref, int ox, int oy, int wx0, int cy0, int tid, uint32_t* stage) {
     ox = __builtin_amdgcn_readfirstlane(ox); oy = __builtin_amdgcn_readfirstlane(oy);
     wx0 = __builtin_amdgcn_readfirstlane(wx0); cy0 = __builtin_amdgcn_readfirstlane(cy0);
-    if (g.rs != 2 && g.rs != 3) return false;
+    if (g.rs < 0 || g.rs > 4) return false;               // (kernel-uniform; such a launch has no dynamic LDS)
     if ((cy0 << g.rs) + oy + rel16(0) < 0 || ((cy0 + WROWS - 1) << g.rs) + oy + rel16(15) > g.H - 1) return false;
-    if (g.rs == 3) ysads_tile_lds<3, WROWS, LPR, NW>(sad, a, ref, ox, oy, wx0, cy0, tid, stage);
-    else ysads_tile_lds<2, WROWS, LPR, NW>(sad, a, ref, ox, oy, wx0, cy0, tid, stage);
+    switch (g.rs) {
+        case 0: ysads_tile_lds<0, WROWS, LPR, NW>(sad, a, ref, ox, oy, wx0, cy0, tid, stage); break;
+        case 1: ysads_tile_lds<1, WROWS, LPR, NW>(sad, a, ref, ox, oy, wx0, cy0, tid, stage); break;
+        case 2: ysads_tile_lds<2, WROWS, LPR, NW>(sad, a, ref, ox, oy, wx0, cy0, tid, stage); break;
+        case 3: ysads_tile_lds<3, WROWS, LPR, NW>(sad, a, ref, ox, oy, wx0, cy0, tid, stage); break;
+        default: ysads_tile_lds<4, WROWS, LPR, NW>(sad, a, ref, ox, oy, wx0, cy0, tid, stage); break;
+    }
     return true;
 }
 
@@ -454,17 +463,25 @@ __device__ __forceinline__ void ysads_win8_lds(uint32_t* sad, const FlowStep& a,
         sad[cz] = t;
     }
 }
-constexpr int kWin8StageDwords = ((YRows<2, 8, 2, 1>::kTotal * 2 + 15) / 16) * 256;   // rs = 2 needs more rows than rs = 3
-static_assert(YRows<2, 8, 2, 1>::kTotal >= YRows<3, 8, 2, 1>::kTotal, "LDS of the 8 x 8 windows");
+template <int RS> constexpr size_t win8_stage_bytes_of() { return (size_t)((YRows<RS, 8, 2, 1>::kTotal * 2 + 15) / 16) * 1024; }
+constexpr size_t win8_stage_bytes(int rs) {
+    return rs == 0 ? win8_stage_bytes_of<0>() : rs == 1 ? win8_stage_bytes_of<1>() : rs == 2 ? win8_stage_bytes_of<2>() : rs == 3 ? win8_stage_bytes_of<3>() :
+           rs == 4 ? win8_stage_bytes_of<4>() : 0;
+}
 
 // cx0, cy, ox, oy: the lane's own (per window).  Taken only if all four windows of the wave need no reflection.
 __device__ __forceinline__ bool ysads_win8_try(uint32_t* sad, const Geom& g, const FlowStep& a, const uint32_t* ref, int ox, int oy, int cx0, int cy, int lane, uint32_t* stage) {
-    if (g.rs != 2 && g.rs != 3) return false;
+    if (g.rs < 0 || g.rs > 4) return false;
     const int cy0 = cy - ((lane & 15) >> 1);
     const bool outside = (cy0 << g.rs) + oy + rel16(0) < 0 || ((cy0 + 7) << g.rs) + oy + rel16(15) > g.H - 1;
     if (__builtin_amdgcn_ballot_w64(outside) != 0) return false;
-    if (g.rs == 3) ysads_win8_lds<3>(sad, a, ref, ox, oy, cx0, cy, lane, stage);
-    else ysads_win8_lds<2>(sad, a, ref, ox, oy, cx0, cy, lane, stage);
+    switch (g.rs) {
+        case 0: ysads_win8_lds<0>(sad, a, ref, ox, oy, cx0, cy, lane, stage); break;
+        case 1: ysads_win8_lds<1>(sad, a, ref, ox, oy, cx0, cy, lane, stage); break;
+        case 2: ysads_win8_lds<2>(sad, a, ref, ox, oy, cx0, cy, lane, stage); break;
+        case 3: ysads_win8_lds<3>(sad, a, ref, ox, oy, cx0, cy, lane, stage); break;
+        default: ysads_win8_lds<4>(sad, a, ref, ox, oy, cx0, cy, lane, stage); break;
+    }
     return true;
 }
 
@@ -832,7 +849,7 @@ __global__ __launch_bounds__(SPLIT ? 64 : 256) void flow_level_small_kernel(cons
     const FlowStep a = member_step(batch, tile.pair);
     static_assert(!SPLIT || WS <= 16, "a 32x32 window is shared by the four waves of a workgroup");
     __shared__ uint32_t s_part[SPLIT ? 1 : 2][4][16];
-    __shared__ __attribute__((aligned(16))) uint32_t s_rows[WS == 16 && SPLIT ? ystage_dwords<16, 4, 1>() : WS == 32 ? ystage_dwords<32, 8, 4>() : WS == 8 && SPLIT ? kWin8StageDwords : 4];   // ysads_tile_lds
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_rows[];   // the launch's dynamic LDS: candidate rows of the Y step (launch_flow_level_small)
     // Workgroup-uniform choice: tiles that lie inside the grid with the full search radius (all but the last tile row /
     // column once the governor has settled at 16) run a body without validity masks and per-candidate tests.
     // (Registers: 16 candidates x 16 bytes in flight per row = ~100 per lane for the one-row levels, 140-170 for the block levels.  Capping
@@ -898,7 +915,7 @@ __global__ __launch_bounds__(64 * WPB) void flow_big_partial_kernel(const Geom g
     if (!tile.valid) return;
     const FlowStep a = member_step(batch, tile.pair);
     __shared__ uint32_t s_part[WPB][16];
-    __shared__ __attribute__((aligned(16))) uint32_t s_rows[WPB == 4 ? ystage_dwords<16, 16, 4>() : 4];   // Y launches: ysads_tile_lds
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_rows[];   // Y launches: candidate rows (launch_flow_big_partial)
     const bool full = a.R == 16 && (tile.tx + 1) * 64 <= g.lw && (tile.ty + 1) * (4 * WPB) <= g.lh;   // see flow_level_small_kernel
     if (full) flow_big_partial_body<WPB, true>(g, a, tile, s_part, s_rows);
     else flow_big_partial_body<WPB, false>(g, a, tile, s_part, s_rows);
@@ -1018,13 +1035,15 @@ void launch_flow_level_small(const Geom& g, const FlowBatch& b, hipStream_t stre
     const int tw = rows1 && ws == 2 ? MapRow<2>::TW : 32;
     const int tiles_x = (g.lw + tw - 1) / tw, tiles_y = (g.lh + 31) / 32;   // (32 x 32 tiles at every level but MapRow<2>: 16 x 32)
     const FlowBatchArgs kb = pack_batch(b, tiles_x, tiles_y);
+    // dynamic LDS: the candidate rows of the Y step (full tiles only exist at the full search radius)
+    const size_t lds = b.s[0].R != 16 ? 0 : ws == 32 ? ystage_bytes<32, 8, 4>(g.rs) : ws == 16 ? ystage_bytes<16, 4, 1>(g.rs) : ws == 8 ? win8_stage_bytes(g.rs) : 0;
     // windows <= 16 never span waves: one-wave workgroups (SPLIT), see flow_level_small_kernel
     const dim3 grd(xcd_grid(tiles_x, tiles_y, 1, b.n));
     auto split = [&](int waves) { return dim3(xcd_grid(tiles_x, tiles_y, waves, b.n)); };
     switch (ws) {
-        case 32: flow_level_small_kernel<32, false><<<grd, 256, 0, stream>>>(g, kb); break;
-        case 16: flow_level_small_kernel<16, true><<<split(Map<16>::WAVES), 64, 0, stream>>>(g, kb); break;
-        case 8: flow_level_small_kernel<8, true><<<split(Map<8>::WAVES), 64, 0, stream>>>(g, kb); break;
+        case 32: flow_level_small_kernel<32, false><<<grd, 256, lds, stream>>>(g, kb); break;
+        case 16: flow_level_small_kernel<16, true><<<split(Map<16>::WAVES), 64, lds, stream>>>(g, kb); break;
+        case 8: flow_level_small_kernel<8, true><<<split(Map<8>::WAVES), 64, lds, stream>>>(g, kb); break;
         case 4:
             if (rows1) flow_level_small_kernel<4, true, true><<<split(MapRow<4>::WAVES), 64, 0, stream>>>(g, kb);
             else flow_level_small_kernel<4, true><<<split(Map<4>::WAVES), 64, 0, stream>>>(g, kb);
@@ -1040,7 +1059,8 @@ constexpr int kBigWavesPerBlock = 4;   // measured on MI355X (2160p HDR chain): 
 void launch_flow_big_partial(const Geom& g, const FlowBatch& b, hipStream_t stream) {
     const int tiles_x = (g.lw + 63) / 64, tiles_y = (g.lh + 4 * kBigWavesPerBlock - 1) / (4 * kBigWavesPerBlock);
     const dim3 grd(xcd_grid(tiles_x, tiles_y, 1, b.n));
-    flow_big_partial_kernel<kBigWavesPerBlock><<<grd, 64 * kBigWavesPerBlock, 0, stream>>>(g, pack_batch(b, tiles_x, tiles_y));
+    const size_t lds = b.s[0].axis == 1 && b.s[0].R == 16 && kBigWavesPerBlock == 4 ? ystage_bytes<16, 16, 4>(g.rs) : 0;   // Y launches: candidate rows
+    flow_big_partial_kernel<kBigWavesPerBlock><<<grd, 64 * kBigWavesPerBlock, lds, stream>>>(g, pack_batch(b, tiles_x, tiles_y));
 }
 
 void launch_flow_big_argmin(const Geom& g, const FlowBatch& b, hipStream_t stream) {

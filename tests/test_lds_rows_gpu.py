@@ -1,9 +1,9 @@
 """GPU: the Y steps that read their candidate rows from LDS (csrc/hf_flow.hip ysads_tile_lds / ysads_win8_lds: windows >= 8, full
-tiles, R = 16, rs = 2 or 3, candidate rows that need no reflection -- everything else keeps the per-candidate gathers) against the CPU
+tiles, R = 16, rs <= 4, candidate rows that need no reflection -- everything else keeps the per-candidate gathers) against the CPU
 oracle, on inputs chosen for the decisions that path makes per workgroup / per wave:
   * white noise: offsets all over the +-64 range, so tiles near the top and bottom edge mix staged and reflected windows;
   * a frame shifted vertically by a known amount: every window carries a large Y offset, rows far from the tile;
-  * grids that are not multiples of the tiles (partial tiles take the gathers) at rs = 2 and rs = 3;
+  * grids that are not multiples of the tiles (partial tiles take the gathers); every resolution scalar 0 .. 4 (256-line to 8K frames);
   * a batch of 6 (the block-per-lane mapping of the fine levels) next to the single context.
 Bar: bit-exact offsets, blurred flow and total frame delta (calcDeltaSumsKernelSDR.h:61-190, determineLowestLayerKernelSDR.h:16-26)."""
 import numpy as np
@@ -42,6 +42,10 @@ CASES = [
     (1, 1088, 1920, 136, "noise"),                    # 240 x 136     3
     (0, 1080, 1920, 180, "scene"),                    # 240 x 135     3   135 grid rows: the last tile row has 7
     (1, 1200, 2080, 300, "shift24"),                  # 520 x 300     2   wider than 512: four levels of large windows
+    (0, 256, 480, 270, "noise"),                      # 480 x 256     0   the grid is the frame: one phase, one residue class
+    (1, 540, 960, 270, "shift-20"),                   # 480 x 270     1
+    (0, 540, 960, 270, "noise"),                      # 480 x 270     1
+    (0, 4320, 7680, 270, "noise"),                    # 480 x 270     4   8K: seven residue classes
 ]
 
 
