@@ -22,6 +22,10 @@
 //     level only needs the window's own new X offset plus LAST level's Y offsets of its neighbours, so X
 //     and Y of a level run in ONE launch (5 launches for levels 32..2).  Larger windows take two
 //     launches per axis (partial sums with one atomic per candidate per workgroup, then a tiny argmin).
+//  4. CANDIDATE ROWS THROUGH LDS.  The 16 candidates of a Y step differ by S k + rho (S = 2^rs): within a residue class rho they read
+//     the same plane rows for neighbouring grid rows, so a tile of 16 grid rows needs 95 distinct row segments (rs = 3), not 256.  Tiles
+//     that lie in one window (and every 8 x 8 window by itself) copy those rows once into LDS and read the candidates from there
+//     (ysads_tile_lds / ysads_win8_lds): the chain's launches are bound by what passes the L1s, and this is 20 % less of it.
 #include <utility>
 #include "hf_kernels.h"
 #include "hf_phase_plane.h"

@@ -4,7 +4,8 @@
 //
 // What each kernel replaces (reference HopperRender/):
 //   (the refinement chain -- calcDeltaSums / determineLowestLayer / adjustOffsetArray -- is hf_flow.hip)
-//   blur_flow_kernel     - blurFlowKernelSDR.h:17-92, separable through LDS, runtime radius.
+//   blur_flow_kernel     - blurFlowKernelSDR.h:17-92, separable through LDS, runtime radius; the reference's radius on a chain that ended at
+//                          2 x 2 windows: the 8 x 8 box sum as four reads of 4 x 4 WINDOW sums.
 //   warp_kernel          - warpFrameKernel{SDR,HDR}.h:116-184 (all 7 modes), both planes, one launch.
 //   copy_kernel          - copyFrameKernel{SDR,HDR}.h:12-25, both planes, one launch.
 //
