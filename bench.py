@@ -210,25 +210,36 @@ def host_io_block(hdr, H, W, target, n_periods=24, device=0, async_only=False):
     return res
 
 
-def other_workloads(a):
+def other_workloads(a, budget_s=150.0):
     """BASELINE configs 2, 4 and 5 as ~1 s legs of this same script in fresh child processes (their own HIP runtime and hardware
     queues), AFTER the timed region of the default workload: what the driver's one bench line would otherwise never show.  Reported
-    next to `value`, never part of it."""
+    next to `value`, never part of it.  ONE shared deadline (`budget_s`) bounds what the legs add to the run; a leg that fails or does
+    not fit is named in `failed` (and on stderr) -- a regression of configs 2, 4 or 5 must not hide inside an entry."""
     import subprocess
-    res = {}
+    res, failed = {}, []
+    deadline = time.monotonic() + budget_s
     for name, steps in OTHER_WORKLOADS.items():
         cmd = [sys.executable, os.path.abspath(__file__), "--workload", name, "--steps", str(steps), "--warmup", "2", "--radius", str(a.radius),
                "--no-cpu-baseline", "--no-reference", "--no-host-io", "--no-other-workloads"]
+        left = deadline - time.monotonic()
         try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+            if left < 20.0:
+                raise TimeoutError(f"skipped: {left:.0f} s of the legs' shared {budget_s:.0f} s budget left")
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=left)
+            if r.returncode != 0:
+                raise RuntimeError(f"exit status {r.returncode}: {r.stderr[-300:]}")
             d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
             roof = d["roofline"]
             res[name] = {"value": d["value"], "unit": d["unit"], "frac": roof["frac"], "frac_algorithmic": roof["frac_algorithmic"],
+                         "frac_compulsory": roof.get("frac_compulsory"),
                          "ms_per_flow_calc": d["ms_per_flow_calc"], "timed_region_s": d["timed_region_s"], "steps": d["steps"],
                          "pair_streams": d["config"]["pair_streams_total"], "flow_batch": d["config"]["flow_batch"],
                          "kernel": roof["kernel"], "bytes_per_output_frame": roof["traffic_pipeline"]["hbm_bytes_per_output_frame"]}
         except Exception as e:
             res[name] = {"error": repr(e)[:300]}
+            failed.append(name)
+            print(f"bench.py: other_workloads leg {name} failed: {e!r}"[:500], file=sys.stderr)
+    res["failed"] = failed
     return res
 
 

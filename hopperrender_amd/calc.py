@@ -50,6 +50,7 @@ class OpticalFlowCalc:
                             blur_radius, search_radius, flags)
         capi.check(self._lib.hf_create(C.byref(cfg), C.byref(self._ctx)))
         self.device_index = self._lib.hf_get_device(self._ctx)   # device_index = -1: the first suitable device
+        capi._devices_used.add(self.device_index)
         st = self._stats()
         self.m_frameWidth, self.m_frameHeight = st.frame_width, st.frame_height
         self.m_inputStride, self.m_outputStride = st.input_stride, st.output_stride

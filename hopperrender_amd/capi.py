@@ -165,6 +165,44 @@ SIGNATURES = {
 }
 
 _lib = None
+_devices_used = set()   # devices this process created contexts on (calc.OpticalFlowCalc); read by the debug-bounds exit check
+
+
+def is_debug_bounds_build():
+    return "libhopperflow_dbg" in os.path.basename(lib_path())
+
+
+def debug_bounds_violations(devices=None):
+    """Violation records of the bounds-checking build (csrc/hf_kernels.h HF_DBG_CHECK) of THIS process: {device: (count, first[4])} for every
+    device it opened contexts on.  The records are per process, device and translation unit, so every process that does GPU work under
+    libhopperflow_dbg.so has to read its own -- the exit hook below does, for test children (bench.py ranks, host-I/O workers, cli workers)."""
+    L = load()
+    out = {}
+    for dev in sorted(devices if devices is not None else _devices_used):
+        cfg = HfConfig(struct_size=C.sizeof(HfConfig), is_hdr=0, frame_height=64, frame_width=96, delta_scalar=8, neighbor_scalar=6,
+                       black_level=0.0, white_level=255.0, max_calc_res=270, device_index=dev)
+        ctx = _vp()
+        check(L.hf_create(C.byref(cfg), C.byref(ctx)))
+        n, first = C.c_uint32(0), (C.c_uint32 * 4)()
+        rc = L.hf_debug_bounds_violations(ctx, C.byref(n), first, 0)
+        L.hf_destroy(ctx)
+        if rc == 0:
+            out[dev] = (n.value, list(first))
+    return out
+
+
+def _debug_bounds_exit_check():
+    try:
+        bad = {d: v for d, v in debug_bounds_violations().items() if v[0]}
+    except Exception as e:   # (a process that lost its GPU cannot report; say so, do not mask the original failure)
+        import sys
+        sys.stderr.write(f"[HopperRender] debug-bounds exit check could not run: {e!r}\n")
+        return
+    if bad:
+        import sys
+        sys.stderr.write(f"[HopperRender] HF_DEBUG_BOUNDS: out-of-range gather indices recorded in process {os.getpid()}: {bad} (device: (count, [site, block, thread, line]))\n")
+        sys.stderr.flush()
+        os._exit(97)
 
 
 def lib_path():
@@ -186,6 +224,9 @@ def load():
             fn.restype = res
             fn.argtypes = args
         _lib = L
+        if is_debug_bounds_build():   # every process under the bounds-checking build answers for its own violation records when it ends
+            import atexit
+            atexit.register(_debug_bounds_exit_check)
     return _lib
 
 

@@ -670,10 +670,13 @@ struct FlowBatchArgs {
     FlowPtrs m[kMaxFlowBatch];
 };
 static_assert(sizeof(FlowBatchArgs) + sizeof(Geom) <= 4096, "kernel arguments of a batched chain launch");
+// waves_per_tile: what decode_tile divides the unit index by first (SPLIT launches); the dividers see at most tiles x members (+ the
+// grid's padding to a multiple of 8)
 static FlowBatchArgs pack_batch(const FlowBatch& b, int tiles_x, int tiles_y) {
     FlowBatchArgs k;
     k.n = b.n;
-    k.tiles = make_fastdiv((uint32_t)(tiles_x * tiles_y)); k.tiles_x = make_fastdiv((uint32_t)tiles_x);   // (units x tiles < 2^32: grids up to 64 k tiles)
+    const uint64_t max_v = (uint64_t)tiles_x * tiles_y * b.n + 8;
+    k.tiles = make_fastdiv((uint32_t)(tiles_x * tiles_y), max_v); k.tiles_x = make_fastdiv((uint32_t)tiles_x, (uint64_t)tiles_x * tiles_y);
     k.common = b.s[0];
     for (int i = 0; i < b.n; i++) {
         const FlowStep& f = b.s[i];

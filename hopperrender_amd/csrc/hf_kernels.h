@@ -44,14 +44,18 @@ struct Geom {
     int lw, lh;          // low-res grid
 };
 
-// Division of a wave-uniform index by a launch constant on the SCALAR unit: u / d == mulhi(u, ceil(2^32 / d)) while u * d < 2^32 (the
-// launchers check it).  Left to the compiler a uniform u / d is ~25 VECTOR instructions (v_rcp_iflag_f32, v_mul_hi_u32 ...) and every
-// workgroup of the batched kernels decodes its unit index with three of them before it can start.
+// Division of a wave-uniform index by a launch constant on the SCALAR unit: u / d == mulhi(u, ceil(2^32 / d)) while u * d < 2^32.
+// Left to the compiler a uniform u / d is ~25 VECTOR instructions (v_rcp_iflag_f32, v_mul_hi_u32 ...) and every workgroup of the
+// batched kernels decodes its unit index with three of them before it can start.  Every launcher builds its dividers with the largest
+// index the launch decodes (make_fastdiv(d, max_u)): where the multiply-high form would not be exact -- grids far beyond 8K -- the
+// divider carries magic == 0 and the kernel takes the plain division (a uniform branch; tests/test_fastdiv_math.py).
 struct FastDiv { uint32_t d, magic; };
-inline FastDiv make_fastdiv(uint32_t d) { return FastDiv{d, d > 1 ? (uint32_t)(((1ull << 32) + d - 1) / d) : 0u}; }
 inline bool fastdiv_exact(uint64_t max_u, uint32_t d) { return max_u * d < (1ull << 32); }
+inline FastDiv make_fastdiv(uint32_t d, uint64_t max_u) {
+    return FastDiv{d, d > 1 && fastdiv_exact(max_u, d) ? (uint32_t)(((1ull << 32) + d - 1) / d) : 0u};
+}
 #ifdef __HIPCC__
-__device__ __forceinline__ uint32_t fastdiv(uint32_t u, const FastDiv f) { return f.magic ? __umulhi(u, f.magic) : u; }
+__device__ __forceinline__ uint32_t fastdiv(uint32_t u, const FastDiv f) { return f.magic ? __umulhi(u, f.magic) : f.d > 1 ? u / f.d : u; }
 #endif
 
 constexpr int kMaxFlowBatch = 32;      // contexts per hf_batch (FlowBatch below)

@@ -978,7 +978,10 @@ __device__ __forceinline__ void warp_wg_body(const Geom& g, const WarpArgs& a, c
     const unsigned tid = threadIdx.x, lane = tid & 63u;
     const int cx0 = tx0 + (int)(lane & (kWarpTX - 1)) * VEC, cy0 = ty0 + (wave * kWarpTY + (int)(lane / kWarpTX)) * ROWS;
     const uint64_t valid_mask = __builtin_amdgcn_ballot_w64(lane_valid);
-    const bool present = valid_mask != 0, full = valid_mask == ~0ull;          // wave-uniform
+    // full: every lane owns VEC whole elements of its row.  Phase C stores 16 bytes per lane unconditionally, so a lane that hangs over the
+    // row's end (W % VEC != 0: its store would reach into the stride padding, which warpFrameKernelSDR.h:116-120 never writes) makes its
+    // wave a PARTIAL one: the workgroup then takes the generic body, whose ragged lanes store element by element up to W.
+    const bool present = valid_mask != 0, full = __builtin_amdgcn_ballot_w64(lane_valid && cx0 + VEC <= W) == ~0ull;          // wave-uniform
 
     // ---- phase A, per FLOW CELL instead of per lane.  All lanes of a flow cell share their displacements (a cell is 2^rs luma rows
     // high and one (luma) or two (chroma: lx & ~1) cells wide; a 16-byte thread lies inside one cell), and a run is
@@ -1311,9 +1314,9 @@ __global__ __launch_bounds__(256) void copy_kernel(const Geom g, const E* __rest
 }
 
 // hf_debug_bounds_selftest: one deliberately out-of-range "index" -- the debug build must trap on it, the product build compiles the check away
-__global__ void bounds_selftest_kernel(const int* limit, int* out) {
+__global__ void bounds_selftest_kernel(const int limit, int* out) {
     const int i = (int)threadIdx.x + 64;
-    HF_DBG_CHECK(i < *limit, 999);
+    HF_DBG_CHECK(i < limit, 999);
     out[threadIdx.x] = i;
 }
 
@@ -1441,7 +1444,9 @@ static bool launch_warp_fast(const Geom& g, const WarpBatchArgs& b, hipStream_t 
             po.blocks = plane_blocks;
         }
         const int nb = wg_blocks_per_member(wpr, (y_tiles_ + NW - 1) / NW, (uv_tiles_ + NW - 1) / NW, po.blocks);
-        po.per_member = make_fastdiv((uint32_t)nb); po.per_sr = make_fastdiv((uint32_t)(wpr * 3 + po.blocks)); po.wpr = make_fastdiv((uint32_t)wpr);
+        const uint64_t max_unit = (uint64_t)nb * b.n + 8;   // (units of a launch incl. the padding of its grid to a multiple of 8)
+        po.per_member = make_fastdiv((uint32_t)nb, max_unit); po.per_sr = make_fastdiv((uint32_t)(wpr * 3 + po.blocks), (uint64_t)nb);
+        po.wpr = make_fastdiv((uint32_t)wpr, (uint64_t)wpr * 3 + po.blocks);
         const dim3 wg(((nb * b.n + 7) / 8) * 8), wb(64 * NW);
         const size_t lds_bytes = (size_t)2 * wg_chunks(NW * WR / 2) * 16;
 #define HF_WARP_WG_LAUNCH(M)                                                                                                                  \
@@ -1582,9 +1587,8 @@ void launch_copy(const Geom& g, const void* src, void* out, float black, float w
 }
 
 void launch_bounds_selftest(int* scratch, hipStream_t stream) {
-    const int limit = 64;                            // lanes hold 64 .. 127: every one violates "i < 64"
-    if (hipMemcpyAsync(scratch, &limit, sizeof(int), hipMemcpyHostToDevice, stream) != hipSuccess) return;
-    bounds_selftest_kernel<<<1, 64, 0, stream>>>(scratch, scratch + 1);
+    const int limit = 64;                            // lanes hold 64 .. 127: every one violates "i < 64" (a kernel argument: nothing of this frame outlives the call)
+    bounds_selftest_kernel<<<1, 64, 0, stream>>>(limit, scratch + 1);
 }
 
 bool dbg_bounds_read_kernels(unsigned out[5], bool reset) {

@@ -23,17 +23,15 @@ def native_lib():
 @pytest.fixture(scope="session", autouse=True)
 def _no_bounds_violations_under_the_debug_library():
     """`HF_LIB=hopperrender_amd/lib/libhopperflow_dbg.so python -m pytest tests -m gpu` runs the whole GPU suite on the bounds-checking
-    build (csrc/hf_kernels.h HF_DBG_CHECK): at the end of the session the device-side violation records of this process must be empty.
+    build (csrc/hf_kernels.h HF_DBG_CHECK): at the end of the session the device-side violation records of this process must be empty on
+    EVERY device it opened contexts on.  Child processes (bench.py ranks, host-I/O workers, cli workers) answer for their own records:
+    capi.load() registers an exit hook under that library which ends the child with status 97 and a message on stderr, so the test that
+    started it fails.  Limits: a check records and the access still executes (results of a violating run are not trustworthy); hosts that
+    bind the C ABI without this Python layer call hf_debug_bounds_violations themselves.
     With the product library (no checks compiled in) this is a no-op."""
     yield
-    if "libhopperflow_dbg" not in os.environ.get("HF_LIB", ""):
-        return
-    import ctypes as C
     from hopperrender_amd import capi
-    from hopperrender_amd.calc import OpticalFlowCalcSDR
-    c = OpticalFlowCalcSDR(64, 96)
-    n = C.c_uint32(0)
-    first = (C.c_uint32 * 4)()
-    capi.check(c._lib.hf_debug_bounds_violations(c._ctx, C.byref(n), first, 0), c._ctx)
-    c.close()
-    assert n.value == 0, f"{n.value} out-of-range gather indices recorded; first: site {first[0]}, block {first[1]}, thread {first[2]}, line {first[3]}"
+    if not capi.is_debug_bounds_build():
+        return
+    bad = {d: v for d, v in capi.debug_bounds_violations().items() if v[0]}
+    assert not bad, f"out-of-range gather indices recorded, device: (count, [site, block, thread, line]) = {bad}"

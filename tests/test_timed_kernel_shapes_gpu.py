@@ -23,15 +23,10 @@ T6 = T5 + [0.0]
 LEVELS = [(0.0, 255.0), (16.0, 235.0), (0.0, 200.0)]
 
 
-def _oracle_rcp(calc, hdr):
-    """The oracle divides through the DEVICE's v_rcp_f32 for the level settings in play (as the reference's OpenCL build does)."""
-    from oracle import oracle
-    s = 256.0 if hdr else 1.0
-    ys = sorted({np.float32((w - b) * s) for b, w in LEVELS} | {np.float32(w * s) for _, w in LEVELS})
-    r = calc.deviceRcp(np.array(ys, np.float32))
-    oracle.set_flavour(1, 1, {float(y): float(x) for y, x in zip(ys, r)})
-
-
+# The three level settings below are pinned by the reference itself: tests/golden/levels_ramp.npz holds every code value through the
+# reference's copyFrame at 0/255, 16/235 and 0/200 (SDR and HDR), and the oracle reproduces those ramps with its DEFAULT reciprocal
+# (tests/test_oracle_golden.py::test_levels_ramp_matches_reference; only white = 180 needs the 1-ulp-low v_rcp_f32 value).  So the
+# oracle here runs as the goldens pinned it -- nothing the HIP library computes is handed to its own checker.
 def test_batch_of_16_strided_levels_and_a_misaligned_member(native_lib):
     from hopperrender_amd import capi, synth
     from hopperrender_amd.calc import DeviceBuffer, FlowBatch, OpticalFlowCalcHDR
@@ -66,7 +61,7 @@ def test_batch_of_16_strided_levels_and_a_misaligned_member(native_lib):
         _, flows[k], _, oob = oracle.calculate_optical_flow(frames[k - 1], frames[k], g, R)
         assert oob == 0
     try:
-        _oracle_rcp(members[0], True)
+        oracle.set_flavour(1, 1, None)
         batch.runPeriod(batch.preparePeriod(src(0), None, None, calculate_flow=False))
         batch.runPeriod(batch.preparePeriod(src(1), None, None))                     # flow (f0, f1); f0's plane from the plane kernel
         for k in (2, 3):                                                             # deferred periods: warp first, it builds f(k-1)'s plane
