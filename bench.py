@@ -69,6 +69,83 @@ WARP_SYMBOL_PREFIX = {1: "warp_wg_kernel<unsigned short, 2,", 0: "warp_fast_kern
 OTHER_WORKLOADS = {"sdr1080_24to60": 24, "sdr1080_64pairs": 24, "hdr2160_nb10_blur32": 8}   # name: steps (about 1 s timed each)
 
 
+def _read(path):
+    try:
+        with open(path) as f:
+            return f.read().strip()
+    except Exception:
+        return None
+
+
+def device_sysfs(dev_index):
+    """sysfs directory of the HIP device (via its PCI address), or None."""
+    import glob
+    import torch
+    try:
+        p = torch.cuda.get_device_properties(dev_index)
+        bdf = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+        d = "/sys/bus/pci/devices/" + bdf
+        if os.path.isdir(d):
+            return d
+    except Exception:
+        pass
+    cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
+    cards = [c for c in cards if os.path.exists(os.path.join(c, "pp_dpm_sclk"))]
+    return cards[dev_index] if dev_index < len(cards) else None
+
+
+def device_sample(sysfs):
+    """Clock levels and power of the device right now (cheap sysfs reads, no child process): what a reader needs to tell a slow box from a
+    regression.  pp_dpm_*: the level marked '*' is the current one."""
+    import glob
+    if not sysfs:
+        return None
+    out = {}
+    for key, name in (("sclk_mhz", "pp_dpm_sclk"), ("mclk_mhz", "pp_dpm_mclk"), ("fclk_mhz", "pp_dpm_fclk")):
+        txt = _read(os.path.join(sysfs, name))
+        if txt:
+            cur = [l for l in txt.splitlines() if l.rstrip().endswith("*")]
+            try:
+                out[key] = int("".join(ch for ch in cur[0].split(":")[1] if ch.isdigit())) if cur else None
+            except Exception:
+                out[key] = None
+    for hw in glob.glob(os.path.join(sysfs, "hwmon", "hwmon*")):
+        for key, name in (("power_w", "power1_average"), ("power_w", "power1_input"), ("power_cap_w", "power1_cap"), ("temp_c", "temp1_input")):
+            v = _read(os.path.join(hw, name))
+            if v and v.lstrip("-").isdigit() and key not in out:
+                out[key] = round(int(v) / (1e6 if key.startswith("power") else 1e3), 1)
+    return out
+
+
+def device_block(dev_index, sysfs, start, end):
+    """The `device` object of the line: which GPU this was, and its clocks / power when the timed region started and ended.  The boxes of the
+    pool differ by up to 9 % on this pipeline: compare frames/s across lines only with these fields side by side."""
+    import hashlib
+    import torch
+    d = {}
+    try:
+        p = torch.cuda.get_device_properties(dev_index)
+        d.update({"name": p.name, "gcn_arch": getattr(p, "gcnArchName", None), "compute_units": p.multi_processor_count,
+                  "memory_gib": round(p.total_memory / 2 ** 30, 1), "clock_rate_khz_max": getattr(p, "clock_rate", None),
+                  "pci": "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)})
+        uid = getattr(p, "uuid", None)
+        d["uuid"] = str(uid) if uid is not None else None
+    except Exception as e:
+        d["error"] = repr(e)[:200]
+    uniq = _read(os.path.join(sysfs, "unique_id")) if sysfs else None
+    d["unique_id"] = uniq
+    # a stable box id: the GPU's own serial (unique_id) where the driver exposes it, else host name + PCI address
+    import socket
+    d["box_id"] = hashlib.sha256((uniq or (socket.gethostname() + str(d.get("pci")))).encode()).hexdigest()[:12]
+    d["hostname"] = socket.gethostname()
+    d["vbios"] = _read(os.path.join(sysfs, "vbios_version")) if sysfs else None
+    d["at_start_of_timed_region"] = start
+    d["at_end_of_timed_region"] = end
+    d["note"] = ("sclk / mclk = the pp_dpm level in force when sampled (the host has just issued / just drained the timed steps); power_cap_w = "
+                 "hwmon power1_cap; the chip lowers its clock under load (MI355X_MICROARCH.md 'DVFS give-back'), and devices of the pool differ")
+    return d
+
+
 def warp_symbol(hdr):
     """Name of the dominant kernel as `rocprofv3 --kernel-trace` prints it, taken from the symbol table of the library this process
     loaded (nm -C), so that the bench line can never name a kernel the binary does not contain."""
@@ -437,13 +514,17 @@ def main():
         if not a.no_profile:
             c.resetProfile()
 
+    sysfs = device_sysfs(dev_index) if rank == 0 else None
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     frames_out = 0
+    dev_mid = []
     for k in range(a.warmup, a.warmup + a.steps):
         frames_out += run_step(k)
+        if rank == 0 and k in (a.warmup, a.warmup + a.steps - 1):   # two sysfs reads (~0.1 ms) while the queues are full: first and last step
+            dev_mid.append(device_sample(sysfs))
     host_issue_wall_s = time.perf_counter() - t0   # the host is done issuing; the GPU may still be busy.  NOT the host's cost:
                                                    # once the hardware queues are full every further call blocks until the GPU
                                                    # has retired a packet, so this wall time tracks the GPU's
@@ -556,11 +637,30 @@ def main():
             bytes_per_frame = ((2 + k_out) * F + 4 * N + F + 3 * pp_bytes) / k_out
             basis = "model (no PMC record for this workload): per source period 2F + kF + 4N (warp) + F + plane write + 2 plane reads"
         physical_gbs = value / n_gpus * bytes_per_frame / 1e9
+        # The guide's x 2 on FETCH_SIZE is calibrated for WIDE coalesced reads (16 bytes per lane: the warp's window copies, the plane build).
+        # The chain's gathers (16-byte segments at dword alignment, 64-byte row pieces) are not such reads: for them x 2 is an upper bound.
+        # Both readings are printed: `frac` doubles every kernel's FETCH_SIZE, `frac_narrow_gathers_x1` leaves the chain + blur kernels' as counted.
+        per_k_all = pipe.get("per_kernel_bytes_per_pair_and_period") or {}
+        k_out_sched = frames_total / max(1.0, float(n_gpus * a.streams * P * a.steps))        # output frames per pair and source period
+        narrow = sum(v["read"] / 2 for kname, v in per_k_all.items() if kname.startswith(("flow_", "blur_")))
+        bytes_per_frame_x1 = bytes_per_frame - narrow / (pipe.get("output_frames_per_pair_and_period") or k_out_sched) if per_k_all else None
+        # COMPULSORY bytes: what no implementation of the path can avoid moving per pair and source period -- the two source
+        # frames once (2F), every output frame once (kF), the blurred flow once per output (4N each) and the flow calculation's own
+        # B_flow = 6 N bpp + 4 N -- against the same 8 TB/s.
+        bpp = 2 if hdr else 1
+        b_flow = 6 * N * bpp + 4 * N
+        compulsory_pair_period = 2 * F + k_out_sched * F + k_out_sched * 4 * N + b_flow
+        compulsory_gbs = value / n_gpus * (compulsory_pair_period / k_out_sched) / 1e9
         roof = {"bound": "hbm", "achieved": round(physical_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(physical_gbs / HBM_PEAK_GBS, 4), "frac_of_measured_copy_bw_6290": round(physical_gbs / 6290.0, 4),
                 "definition": "physical: frames/s per GPU x HBM bytes the pipeline moves per output frame (all kernels)",
                 "traffic_pipeline": {"hbm_bytes_per_output_frame": int(bytes_per_frame), "basis": basis,
                                      "per_kernel_bytes_per_pair_and_period": pipe.get("per_kernel_bytes_per_pair_and_period")},
+                "frac_narrow_gathers_x1": round(value / n_gpus * bytes_per_frame_x1 / 1e9 / HBM_PEAK_GBS, 4) if bytes_per_frame_x1 else None,
+                "frac_compulsory": round(compulsory_gbs / HBM_PEAK_GBS, 4), "achieved_compulsory": round(compulsory_gbs, 1),
+                "compulsory_definition": "frames/s per GPU x (2F + kF + 4N k + B_flow) / k bytes per output frame, k = output frames per pair and source period, "
+                                         "B_flow = 6 N bpp + 4 N (SURVEY.md 8(d)): bytes NO implementation can avoid",
+                "compulsory_bytes_per_pair_and_period": int(compulsory_pair_period), "moved_over_compulsory": round(bytes_per_frame * k_out_sched / compulsory_pair_period, 3),
                 "frac_algorithmic": round(pipeline_gbs / HBM_PEAK_GBS, 4), "achieved_algorithmic": round(pipeline_gbs, 1),
                 "algorithmic_definition": "SURVEY.md 8(d): frames/s per GPU x B_out, B_out = 3F + 4N bytes per output frame",
                 "algorithmic_bytes_per_unit": b_out,
@@ -630,6 +730,7 @@ def main():
                        "source_periods_per_step": a.streams * P, "source_periods_per_stream_and_step": P,
                        "output_frames_total": int(frames_total), "parallelism": f"pair-sharded x{n_gpus}, no collective",
                        "frame_bytes": F, "flow_grid": [st["low_width"], st["low_height"]], "res_scalar": st["res_scalar"]},
+            "device": device_block(dev_index, sysfs, dev_mid[0] if dev_mid else None, dev_mid[-1] if dev_mid else None),
             "ms_per_flow_calc": round(prof["flow_ms"] / prof["flow_chains"], 4) if prof["flow_chains"] else None,
             "ms_per_flow_calc_note": "device time of one refinement chain + blur while the other batch streams keep the GPU busy"
                                      + (f"; chains run {a.batch} pairs per launch (hf_batch): this is the batch's time / {a.batch}" if a.batch > 1 else ""),

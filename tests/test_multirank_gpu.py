@@ -98,4 +98,13 @@ def test_default_line_carries_the_other_baseline_configs():
         assert "error" not in w, (name, w)
         assert w["value"] > 0 and 0 < w["frac"] < 1 and w["frac_algorithmic"] > 0 and w["timed_region_s"] > 0.3, (name, w)
     assert o["sdr1080_64pairs"]["pair_streams"] == 64 and o["sdr1080_64pairs"]["flow_batch"] == 16
-    assert d["roofline"]["kernel"].startswith("warp_wg_kernel<unsigned short, 2,")
+    r = d["roofline"]
+    assert r["kernel"].startswith("warp_wg_kernel<unsigned short, 2,")
+    # the line describes itself: compulsory bytes, both readings of FETCH_SIZE on the chain's gathers, and the device
+    assert 0 < r["frac_compulsory"] < r["frac_narrow_gathers_x1"] <= r["frac"] < 1 and r["moved_over_compulsory"] > 1
+    assert r["compulsory_bytes_per_pair_and_period"] == int(2 * 24883200 + 5.00625 * (24883200 + 4 * 129600) + 6 * 129600 * 2 + 4 * 129600) or abs(
+        r["compulsory_bytes_per_pair_and_period"] / (7 * 24883200) - 1) < 0.03
+    dev = d["device"]
+    assert dev["name"] and dev["box_id"] and dev["compute_units"] == 256
+    for when in ("at_start_of_timed_region", "at_end_of_timed_region"):
+        assert dev[when] is None or set(dev[when]) <= {"sclk_mhz", "mclk_mhz", "fclk_mhz", "power_w", "power_cap_w", "temp_c"}
