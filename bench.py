@@ -189,6 +189,10 @@ def parse_args():
                     help="A-B: create the process group (a single-rank RCCL communicator when not launched by torchrun) BEFORE the "
                          "batch streams, to see what the communicator's streams do to the hardware-queue layout")
     ap.add_argument("--no-profile", action="store_true", help="no per-kernel HIP events in the timed region")
+    ap.add_argument("--timeline-out", default="", help="DIAGNOSTIC: record the start / stop of every dispatch of every batch stream for --timeline-steps "
+                    "steps in the middle of the timed region (hf_batch_timeline_*: no profiler) plus a stand-alone leg of one batch, and write "
+                    "the raw records + tools/timeline_report.py's analysis to this JSON file")
+    ap.add_argument("--timeline-steps", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference", action="store_true")
     ap.add_argument("--no-host-io", action="store_true")
@@ -501,6 +505,13 @@ def main():
             c.sync()
         torch.cuda.synchronize()
 
+    timeline_on = bool(a.timeline_out) and bool(batches) and rank == 0
+    if timeline_on:
+        # armed before the warm-up (enable synchronises the batch's stream), recording from the middle of the timed region
+        tl_periods = max(2, int(round(a.timeline_steps * P)))
+        tl_skip = (a.warmup + a.steps // 2) * P
+        for b in batches:
+            b.timelineEnable(tl_periods * 16 + 32, tl_skip)
     if not pg_done:
         init_dist()
     rank_devices = [dev_index]
@@ -555,6 +566,23 @@ def main():
             p = c.profile()
             for k in prof:
                 prof[k] += p[k]
+
+    timeline = None
+    if timeline_on:
+        streams = [b.timelineRead() for b in batches]
+        for b in batches:
+            b.timelineEnable(0)
+        # the same launches with ONE batch stream running and the others idle: stand-alone durations
+        b0 = batches[0]
+        b0.timelineEnable(12 * 16 + 32, 2)
+        base = (a.warmup + a.steps) * P + BURST
+        sched_alone = BlendSchedule(SOURCE_24, target).plan(base + 20)[base:]
+        for i in range(14):
+            b0.runPeriod(b0.preparePeriod([src_ptr(s, base + i) for s in range(a.batch)], [sched_alone[i] for _ in range(a.batch)], out_ptrs[:a.batch], 2))
+        b0.sync()
+        alone = b0.timelineRead()
+        b0.timelineEnable(0)
+        timeline = {"streams": streams, "alone": alone, "periods_per_step": P}
 
     # Context for the roofline figure, OUTSIDE the timed region: the dominant kernel alone on the GPU -- one batch of a.batch members,
     # i.e. exactly the launch the pipeline issues (same kernel, same grid), one fused period launch at a time, source frames
@@ -769,6 +797,19 @@ def main():
                     out["speedup_vs_reference_opencl"] = round(out["value"] / n_gpus / r["frames_per_s"], 2)
             except Exception as e:
                 out["reference_opencl"] = {"error": repr(e)}
+        if timeline:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from timeline_report import analyze
+            out["DIAGNOSTIC_NOT_A_BENCHMARK"] = "timeline: the chains of %.2g steps were issued launch by launch with events on every dispatch" % a.timeline_steps
+            run = {"frames_per_s": out["value"], "ms_per_step": out["ms_per_step"], "workload": a.workload, "batch_streams": a.streams // a.batch,
+                   "flow_batch": a.batch, "steps": a.steps, "timeline_steps": a.timeline_steps, "device": out.get("device")}
+            rep = analyze(timeline["streams"], timeline["alone"], P)
+            rep["run"] = run
+            os.makedirs(os.path.dirname(os.path.abspath(a.timeline_out)), exist_ok=True)
+            json.dump(rep, open(a.timeline_out, "w"), indent=1)
+            json.dump(dict(timeline, run=run), open(a.timeline_out.replace(".json", "") + "_raw.json", "w"))
+            out["timeline"] = {"file": a.timeline_out, "implied_ms_per_step": rep.get("implied_ms_per_step"), "mean_queues_busy": (rep.get("concurrency") or {}).get("mean_queues_busy"),
+                               "serial_over_pipelined": rep.get("serial_over_pipelined")}
         result_line = json.dumps(out)
 
     for b in batches:

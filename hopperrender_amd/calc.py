@@ -369,6 +369,20 @@ class FlowBatch:
     def sync(self):
         self._check(self._lib.hf_batch_sync(self._b))
 
+    def timelineEnable(self, max_launches, skip_periods=0):
+        """hf_batch_timeline_enable: after skip_periods further runPeriod calls every dispatch carries its own start / stop events (0: off)."""
+        self._check(self._lib.hf_batch_timeline_enable(self._b, int(max_launches), int(skip_periods)))
+
+    def timelineRead(self):
+        """hf_batch_timeline_read: [(kernel, period, start_ms, end_ms)] on the device's clock, relative to the process's reference event."""
+        n = C.c_int(0)
+        self._check(self._lib.hf_batch_timeline_read(self._b, None, 0, C.byref(n)))
+        if n.value == 0:
+            return []
+        recs = (capi.HfTimelineRecord * n.value)()
+        self._check(self._lib.hf_batch_timeline_read(self._b, recs, n.value, C.byref(n)))
+        return [(r.kernel.decode(), r.period, r.start_ms, r.end_ms) for r in recs[:n.value]]
+
     def __len__(self):
         return self._lib.hf_batch_size(self._b)
 

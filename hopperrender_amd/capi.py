@@ -65,6 +65,10 @@ class HfStats(C.Structure):
                 ("input_frame_bytes", C.c_uint64), ("output_frame_bytes", C.c_uint64), ("phase_plane_bytes", C.c_uint64)]
 
 
+class HfTimelineRecord(C.Structure):
+    _fields_ = [("kernel", C.c_char * 32), ("period", C.c_int32), ("reserved", C.c_int32), ("start_ms", C.c_double), ("end_ms", C.c_double)]
+
+
 class HfProfile(C.Structure):
     _fields_ = [("warp_launches", C.c_uint64), ("warp_ms", C.c_double), ("copy_launches", C.c_uint64),
                 ("copy_ms", C.c_double), ("flow_chains", C.c_uint64), ("flow_ms", C.c_double), ("warp_frames", C.c_uint64)]
@@ -119,6 +123,8 @@ SIGNATURES = {
     "hf_batch_defers_planes": (_i, [_vp]),
     "hf_batch_sync": (_i, [_vp]),
     "hf_batch_size": (_i, [_vp]),
+    "hf_batch_timeline_enable": (_i, [_vp, _i, _i]),
+    "hf_batch_timeline_read": (_i, [_vp, C.POINTER(HfTimelineRecord), _i, C.POINTER(_i)]),
     "hf_batch_last_error": (C.c_char_p, [_vp]),
     "hf_download_frame_device": (_i, [_vp, _vp]),
     "hf_set_output_buffer": (_i, [_vp, _vp]),

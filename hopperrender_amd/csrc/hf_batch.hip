@@ -95,7 +95,7 @@ int batch_interpolate(hf_batch* b, const int* n_out, const float* t, void* const
                 c->warp_started = true;
             }
         }
-        const int span = span_open(l, 0);
+        const int span = hf::t_launch_observer == &b->tl ? -1 : span_open(l, 0);   // (an observed launch carries the timeline's events, not a profile span's)
         bool built[hf::kMaxFlowBatch];
         if (hf::launch_warp_periods(l->g, n, periods, mode, b->stream, span >= 0 ? l->spans[span].b : nullptr, span >= 0 ? l->spans[span].e : nullptr,
                                     before_chain ? &l->pl : nullptr, built)) {
@@ -217,6 +217,7 @@ void hf_batch_destroy(hf_batch* b) {
     }
     for (hipStream_t ws : b->warp_streams) hipStreamDestroy(ws);
     if (b->stream) hipStreamDestroy(b->stream);
+    for (hipEvent_t e : b->tl.events) hipEventDestroy(e);
     delete b;
 }
 
@@ -234,6 +235,13 @@ int hf_batch_calculate_optical_flow(hf_batch* b) {
         key.push_back(m->ring_phase * 2 + m->blur_phase);
     }
     if (ensure_older_planes(b->members.data(), n, b->stream)) return batch_fail(b, HF_ERR_HIP, "phase-plane launch failed");
+    if (hf::t_launch_observer == &b->tl) {
+        // timeline: the chain's launches one by one, each with the events of its own dispatch (a graph replay has no per-node timestamps)
+        if (int rc = enqueue_flow_chain(b->members.data(), n, b->stream)) return batch_fail(b, rc, l->err);
+        for (hf_ctx* m : b->members)
+            if (int rc = after_flow_enqueued(m, b->stream)) return batch_fail(b, rc, m->err);
+        return HF_OK;
+    }
     auto it = b->graphs.find(key);
     if (it == b->graphs.end()) {
         hipGraph_t graph = nullptr;
@@ -271,6 +279,21 @@ int hf_batch_interpolate_period(hf_batch* b, const int* n_out, const float* t, v
 int hf_batch_run_period(hf_batch* b, const void* const* device_frames, int calculate_flow, const int* n_out, const float* t,
                         void* const* device_out, int mode) {
     if (!b) return batch_fail(nullptr, HF_ERR_INVALID_ARGUMENT, "null batch");
+    struct ObserverGuard {   // timeline on: every launch of this call carries its own start / stop events (hf_kernels.h HF_LAUNCH)
+        hf_batch* b;
+        explicit ObserverGuard(hf_batch* x) : b(nullptr) {
+            if (!x->tl.active) return;
+            if (x->tl.skip > 0) { x->tl.skip--; return; }      // armed, not recording yet
+            b = x;
+            hf::t_launch_observer = &b->tl;
+        }
+        ~ObserverGuard() {
+            if (!b) return;
+            hf::t_launch_observer = nullptr;
+            b->tl.period++;
+            if (b->tl.recs.size() + 32 > b->tl.capacity) b->tl.active = false;   // no room for another whole period: back to graph replays
+        }
+    } observer_guard(b);
     if (device_frames) if (int rc = batch_update(b, device_frames, b->defer_planes)) return rc;
     // Deferred phase planes: a period whose older frame still lacks its full plane issues its warps FIRST (they do not depend on
     // this period's chain) and lets that launch build the plane; same results as the order of the three calls.
@@ -292,6 +315,78 @@ int hf_batch_run_period(hf_batch* b, const void* const* device_frames, int calcu
 }
 
 int hf_batch_defers_planes(const hf_batch* b) { return b && b->defer_planes ? 1 : 0; }
+
+// ---- timeline: start / stop of every dispatch of a batch on the device's clock, no profiler attached ----
+namespace {
+std::mutex g_tl_mutex;
+std::map<int, hipEvent_t> g_tl_reference;   // per device: the zero of every batch's timeline in this process
+}
+int hf_batch_timeline_enable(hf_batch* b, int max_launches, int skip_periods) {
+    if (!b) return batch_fail(nullptr, HF_ERR_INVALID_ARGUMENT, "null batch");
+    hf_ctx* l = b->members[0];
+    if (hipSetDevice(l->device) != hipSuccess) return batch_fail(b, HF_ERR_HIP, "hipSetDevice failed");
+    if (max_launches < 0 || max_launches > (1 << 20) || skip_periods < 0) return batch_fail(b, HF_ERR_INVALID_ARGUMENT, "hf_batch_timeline_enable: max_launches outside [0, 2^20] or skip_periods < 0");
+    if (hipStreamSynchronize(b->stream) != hipSuccess) return batch_fail(b, HF_ERR_HIP, "hipStreamSynchronize failed");
+    b->tl.active = false;
+    b->tl.recs.clear();
+    b->tl.period = 0;
+    b->tl.dropped = 0;
+    b->tl.capacity = 0;
+    if (max_launches == 0) {
+        for (hipEvent_t e : b->tl.events) hipEventDestroy(e);
+        b->tl.events.clear();
+        return HF_OK;
+    }
+    {
+        std::lock_guard<std::mutex> lock(g_tl_mutex);
+        if (!g_tl_reference.count(l->device)) {
+            hipEvent_t ref = nullptr;
+            if (hipEventCreate(&ref) != hipSuccess || hipEventRecord(ref, b->stream) != hipSuccess || hipEventSynchronize(ref) != hipSuccess)
+                return batch_fail(b, HF_ERR_HIP, "hf_batch_timeline_enable: cannot record the reference event");
+            g_tl_reference[l->device] = ref;
+        }
+    }
+    while (b->tl.events.size() < 2 * (size_t)max_launches) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return batch_fail(b, HF_ERR_OUT_OF_MEMORY, "hf_batch_timeline_enable: hipEventCreate failed");
+        b->tl.events.push_back(e);
+    }
+    b->tl.recs.reserve((size_t)max_launches);
+    b->tl.capacity = (size_t)max_launches;
+    b->tl.skip = skip_periods;
+    b->tl.active = max_launches >= 32;
+    return HF_OK;
+}
+
+int hf_batch_timeline_read(hf_batch* b, hf_timeline_record* out, int capacity, int* n_records) {
+    if (!b) return batch_fail(nullptr, HF_ERR_INVALID_ARGUMENT, "null batch");
+    if (!n_records || (capacity > 0 && !out)) return batch_fail(b, HF_ERR_INVALID_ARGUMENT, "hf_batch_timeline_read: null argument");
+    hf_ctx* l = b->members[0];
+    if (hipSetDevice(l->device) != hipSuccess) return batch_fail(b, HF_ERR_HIP, "hipSetDevice failed");
+    if (hipStreamSynchronize(b->stream) != hipSuccess) return batch_fail(b, HF_ERR_HIP, "hipStreamSynchronize failed");
+    hipEvent_t ref = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_tl_mutex);
+        auto it = g_tl_reference.find(l->device);
+        if (it != g_tl_reference.end()) ref = it->second;
+    }
+    *n_records = (int)b->tl.recs.size();
+    if (!ref) return b->tl.recs.empty() ? HF_OK : batch_fail(b, HF_ERR_STATE, "hf_batch_timeline_read: no reference event");
+    const int n = *n_records < capacity ? *n_records : capacity;
+    for (int i = 0; i < n; i++) {
+        const hf_timeline::Rec& r = b->tl.recs[(size_t)i];
+        float t0 = 0.f, t1 = 0.f;
+        if (hipEventElapsedTime(&t0, ref, r.b) != hipSuccess || hipEventElapsedTime(&t1, ref, r.e) != hipSuccess)
+            return batch_fail(b, HF_ERR_HIP, "hf_batch_timeline_read: hipEventElapsedTime failed (record " + std::to_string(i) + ")");
+        hf_timeline_record& o = out[i];
+        std::memset(&o, 0, sizeof(o));
+        std::strncpy(o.kernel, r.name, sizeof(o.kernel) - 1);
+        o.period = r.period;
+        o.start_ms = (double)t0;
+        o.end_ms = (double)t1;
+    }
+    return HF_OK;
+}
 
 int hf_batch_sync(hf_batch* b) {
     if (!b) return batch_fail(nullptr, HF_ERR_INVALID_ARGUMENT, "null batch");

@@ -137,8 +137,27 @@ struct hf_ctx {
     bool timing() const { return (cfg.flags & HF_FLAG_NO_TIMING) == 0; }   // record the reference's timing events
 };
 
+// Per-launch device timestamps of a batch (hf_batch_timeline_*): the start / stop events of every dispatch the batch issues while it is on.
+struct hf_timeline final : hf::LaunchObserver {
+    struct Rec { const char* name; hipEvent_t b, e; int period; };
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> events;      // 2 per record, created when the timeline is switched on
+    size_t capacity = 0;
+    int skip = 0;                        // hf_batch_run_period calls still to pass unobserved before the recording starts
+    bool active = false;                 // records left: hf_batch_run_period observes its launches and issues the chain eagerly (no graph replay)
+    int period = 0;                      // hf_batch_run_period calls since it was switched on
+    uint64_t dropped = 0;                // launches issued while on but out of records (cannot happen: it switches itself off when full)
+    bool next(const char* name, hipEvent_t* s, hipEvent_t* e) override {
+        if (recs.size() >= capacity) { dropped++; return false; }
+        *s = events[2 * recs.size()]; *e = events[2 * recs.size() + 1];
+        recs.push_back(Rec{name, *s, *e, period});
+        return true;
+    }
+};
+
 // ---- batches (throughput drivers; include/hopperflow.h) ----
 struct hf_batch {
+    hf_timeline tl;
     std::vector<hf_ctx*> members;
     std::vector<hipStream_t> own_streams;   // the members' own streams, restored by hf_batch_destroy
     std::vector<hipStream_t> own_warp_streams;

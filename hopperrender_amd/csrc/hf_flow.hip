@@ -32,6 +32,8 @@
 
 namespace hf {
 
+thread_local LaunchObserver* t_launch_observer = nullptr;   // hf_kernels.h HF_LAUNCH
+
 namespace {
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
@@ -990,11 +992,11 @@ static bool launch_prep_fast(const Geom& g, const PhaseLayout& pl, const PrepBat
     for (int i = 0; i < b.n; i++) if (((uintptr_t)b.frame[i]) & 15) return false;
     const dim3 grd((lw / 4 + 127) / 128, g.H / 2, b.n);
     switch (g.rs) {
-        case 0: prep_phase_fast_kernel<E, 0><<<grd, 128, 0, stream>>>(b, g.H, g.W, g.in_stride, pl); break;
-        case 1: prep_phase_fast_kernel<E, 1><<<grd, 128, 0, stream>>>(b, g.H, g.W, g.in_stride, pl); break;
-        case 2: prep_phase_fast_kernel<E, 2><<<grd, 128, 0, stream>>>(b, g.H, g.W, g.in_stride, pl); break;
-        case 3: prep_phase_fast_kernel<E, 3><<<grd, 128, 0, stream>>>(b, g.H, g.W, g.in_stride, pl); break;
-        default: prep_phase_fast_kernel<E, 4><<<grd, 128, 0, stream>>>(b, g.H, g.W, g.in_stride, pl); break;
+        case 0: HF_LAUNCH("plane", (prep_phase_fast_kernel<E, 0>), grd, dim3(128), 0, stream, b, g.H, g.W, g.in_stride, pl); break;
+        case 1: HF_LAUNCH("plane", (prep_phase_fast_kernel<E, 1>), grd, dim3(128), 0, stream, b, g.H, g.W, g.in_stride, pl); break;
+        case 2: HF_LAUNCH("plane", (prep_phase_fast_kernel<E, 2>), grd, dim3(128), 0, stream, b, g.H, g.W, g.in_stride, pl); break;
+        case 3: HF_LAUNCH("plane", (prep_phase_fast_kernel<E, 3>), grd, dim3(128), 0, stream, b, g.H, g.W, g.in_stride, pl); break;
+        default: HF_LAUNCH("plane", (prep_phase_fast_kernel<E, 4>), grd, dim3(128), 0, stream, b, g.H, g.W, g.in_stride, pl); break;
     }
     return true;
 }
@@ -1003,8 +1005,8 @@ void launch_prep_frames(const Geom& g, const PhaseLayout& pl, const PrepBatch& b
     if (g.hdr ? launch_prep_fast<uint16_t>(g, pl, b, stream) : launch_prep_fast<uint8_t>(g, pl, b, stream)) return;
     const size_t smem = 2 * (size_t)((g.W + 15) / 16) * 16;
     const dim3 grd(g.H, b.n);
-    if (g.hdr) prep_phase_kernel<uint16_t><<<grd, 256, smem, stream>>>(b, g.H, g.W, g.in_stride, pl);
-    else prep_phase_kernel<uint8_t><<<grd, 256, smem, stream>>>(b, g.H, g.W, g.in_stride, pl);
+    if (g.hdr) HF_LAUNCH("plane", (prep_phase_kernel<uint16_t>), grd, dim3(256), smem, stream, b, g.H, g.W, g.in_stride, pl);
+    else HF_LAUNCH("plane", (prep_phase_kernel<uint8_t>), grd, dim3(256), smem, stream, b, g.H, g.W, g.in_stride, pl);
 }
 
 // Grid samples only: element (cy << rs, phase pair 0, column j) of the plane = what load_strip reads of the newer frame.
@@ -1023,8 +1025,8 @@ __global__ __launch_bounds__(256) void prep_grid_kernel(const PrepBatch batch, i
 
 void launch_prep_grid(const Geom& g, const PhaseLayout& pl, const PrepBatch& b, hipStream_t stream) {
     const dim3 grd((g.lw + 255) / 256, g.lh, b.n);
-    if (g.hdr) prep_grid_kernel<uint16_t><<<grd, 256, 0, stream>>>(b, g.H, g.in_stride, pl, g.lw);
-    else prep_grid_kernel<uint8_t><<<grd, 256, 0, stream>>>(b, g.H, g.in_stride, pl, g.lw);
+    if (g.hdr) HF_LAUNCH("grid_samples", (prep_grid_kernel<uint16_t>), grd, dim3(256), 0, stream, b, g.H, g.in_stride, pl, g.lw);
+    else HF_LAUNCH("grid_samples", (prep_grid_kernel<uint8_t>), grd, dim3(256), 0, stream, b, g.H, g.in_stride, pl, g.lw);
 }
 
 void launch_prep_frame(const Geom& g, const PhaseLayout& pl, const void* frame, uint32_t* pp, hipStream_t stream) {
@@ -1048,16 +1050,16 @@ void launch_flow_level_small(const Geom& g, const FlowBatch& b, hipStream_t stre
     const dim3 grd(xcd_grid(tiles_x, tiles_y, 1, b.n));
     auto split = [&](int waves) { return dim3(xcd_grid(tiles_x, tiles_y, waves, b.n)); };
     switch (ws) {
-        case 32: flow_level_small_kernel<32, false><<<grd, 256, lds, stream>>>(g, kb); break;
-        case 16: flow_level_small_kernel<16, true><<<split(Map<16>::WAVES), 64, lds, stream>>>(g, kb); break;
-        case 8: flow_level_small_kernel<8, true><<<split(Map<8>::WAVES), 64, lds, stream>>>(g, kb); break;
+        case 32: HF_LAUNCH("level_32", (flow_level_small_kernel<32, false>), grd, dim3(256), lds, stream, g, kb); break;
+        case 16: HF_LAUNCH("level_16", (flow_level_small_kernel<16, true>), split(Map<16>::WAVES), dim3(64), lds, stream, g, kb); break;
+        case 8: HF_LAUNCH("level_8", (flow_level_small_kernel<8, true>), split(Map<8>::WAVES), dim3(64), lds, stream, g, kb); break;
         case 4:
-            if (rows1) flow_level_small_kernel<4, true, true><<<split(MapRow<4>::WAVES), 64, 0, stream>>>(g, kb);
-            else flow_level_small_kernel<4, true><<<split(Map<4>::WAVES), 64, 0, stream>>>(g, kb);
+            if (rows1) HF_LAUNCH("level_4", (flow_level_small_kernel<4, true, true>), split(MapRow<4>::WAVES), dim3(64), 0, stream, g, kb);
+            else HF_LAUNCH("level_4", (flow_level_small_kernel<4, true>), split(Map<4>::WAVES), dim3(64), 0, stream, g, kb);
             break;
         default:
-            if (rows1) flow_level_small_kernel<2, true, true><<<split(MapRow<2>::WAVES), 64, 0, stream>>>(g, kb);
-            else flow_level_small_kernel<2, true><<<split(Map<2>::WAVES), 64, 0, stream>>>(g, kb);
+            if (rows1) HF_LAUNCH("level_2", (flow_level_small_kernel<2, true, true>), split(MapRow<2>::WAVES), dim3(64), 0, stream, g, kb);
+            else HF_LAUNCH("level_2", (flow_level_small_kernel<2, true>), split(Map<2>::WAVES), dim3(64), 0, stream, g, kb);
             break;
     }
 }
@@ -1067,12 +1069,12 @@ void launch_flow_big_partial(const Geom& g, const FlowBatch& b, hipStream_t stre
     const int tiles_x = (g.lw + 63) / 64, tiles_y = (g.lh + 4 * kBigWavesPerBlock - 1) / (4 * kBigWavesPerBlock);
     const dim3 grd(xcd_grid(tiles_x, tiles_y, 1, b.n));
     const size_t lds = b.s[0].axis == 1 && b.s[0].R == 16 && kBigWavesPerBlock == 4 ? ystage_bytes<16, 16, 4>(g.rs) : 0;   // Y launches: candidate rows
-    flow_big_partial_kernel<kBigWavesPerBlock><<<grd, 64 * kBigWavesPerBlock, lds, stream>>>(g, pack_batch(b, tiles_x, tiles_y));
+    HF_LAUNCH(b.s[0].axis ? "large_windows_y" : "large_windows_x", (flow_big_partial_kernel<kBigWavesPerBlock>), grd, dim3(64 * kBigWavesPerBlock), lds, stream, g, pack_batch(b, tiles_x, tiles_y));
 }
 
 void launch_flow_big_argmin(const Geom& g, const FlowBatch& b, hipStream_t stream) {
     const int nwin = b.s[0].cur.nwx * b.s[0].cur.nwy;
-    flow_big_argmin_kernel<<<dim3((nwin + 15) / 16, b.n), 256, 0, stream>>>(g, pack_batch(b, 1, 1));
+    HF_LAUNCH("large_windows_argmin", flow_big_argmin_kernel, dim3((nwin + 15) / 16, b.n), dim3(256), 0, stream, g, pack_batch(b, 1, 1));
 }
 
 bool dbg_bounds_read_flow(unsigned out[5], bool reset) {

@@ -5,6 +5,9 @@
 // Citations are relative to the reference's HopperRender/ directory.
 #pragma once
 #include <hip/hip_runtime.h>
+#ifdef __HIPCC__
+#include <hip/hip_ext.h>
+#endif
 #include <stdint.h>
 
 // Device debug build (`python -m hopperrender_amd.build --debug-bounds` => -DHF_DEBUG_BOUNDS, library libhopperflow_dbg.so): every
@@ -33,6 +36,29 @@ __device__ __forceinline__ void dbg_bounds_record(int site, int line) {
 #endif
 
 namespace hf {
+
+// ---- per-launch device timestamps without a profiler (hf_batch_timeline_*, include/hopperflow.h) ----
+// `rocprofv3 --kernel-trace` makes the four batch streams host-issue-bound (its per-dispatch cost), so its timeline is not the timed
+// run's.  Instead every launch of the library can carry the start / stop events of its own dispatch (hipExtLaunchKernelGGL: the same
+// timestamps the kernel trace reads): while a thread has a LaunchObserver installed, HF_LAUNCH hands each launch a pair of events from it
+// and notes the kernel's name; otherwise it is the plain launch.  Installed only by hf_batch_run_period of a batch whose timeline is on.
+struct LaunchObserver {
+    virtual bool next(const char* kernel_name, hipEvent_t* start, hipEvent_t* stop) = 0;   // false: out of records, launch unobserved
+protected:
+    ~LaunchObserver() = default;
+};
+extern thread_local LaunchObserver* t_launch_observer;
+
+#ifdef __HIPCC__
+#define HF_LAUNCH(NAME, KERNEL, GRID, BLOCK, LDS, STREAM, ...)                                                     \
+    do {                                                                                                            \
+        hipEvent_t hf_e0_ = nullptr, hf_e1_ = nullptr;                                                              \
+        if (::hf::t_launch_observer && ::hf::t_launch_observer->next((NAME), &hf_e0_, &hf_e1_))                    \
+            hipExtLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, STREAM, hf_e0_, hf_e1_, 0, __VA_ARGS__);                \
+        else                                                                                                        \
+            hipLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, STREAM, __VA_ARGS__);                                      \
+    } while (0)
+#endif
 
 // Geometry shared by all kernels (reference ctor, opticalFlowCalcSDR.cpp:206-222).
 struct Geom {

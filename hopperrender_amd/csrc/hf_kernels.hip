@@ -857,6 +857,13 @@ constexpr int warp_max_waves(size_t elem, int group, int vb) { return vb == 16 &
 // waves executed the per-element edge path next to the run path -- that, not the interior code, was most of the
 // 1,940 VALU instructions per wave.  With 128-pixel tiles 2 of 30 tiles per row are edge tiles.)
 constexpr int kWarpTX = 16, kWarpTY = 4;
+constexpr int ilog2c(int v) { return v <= 1 ? 0 : 1 + ilog2c(v >> 1); }
+// Deferred phase planes (see warp_wg_kernel): plane-building workgroups carried by a period warp launch.
+struct PlaneOut {
+    PhaseLayout pl;
+    int blocks;                          // plane-building workgroups per super row (0: the launch builds no planes)
+    FastDiv per_member, per_sr, wpr;     // unit index -> (member, super row, block): scalar divisions (hf_kernels.h)
+};
 template <typename E, int GROUP, int ROWS, int MODE, int VB, bool DW>
 __global__ __launch_bounds__(64 * warp_max_waves(sizeof(E), GROUP, VB)) void warp_fast_kernel(const Geom g, const WarpBatchArgs batch, int y_groups, int out_chunk, int n_chunks) {
     constexpr int VEC = VB / sizeof(E);
@@ -963,8 +970,6 @@ struct WgShared {                                  // static LDS of warp_wg_kern
     int state[NW];                                 // per wave: 2 = no tile (past the plane's end), 1 = full tile, 0 = partial tile
     int item[NW];                                  // per wave: bit 0 = all its items stageable, bit 1 = all of them interior (no mirroring)
 };
-
-constexpr int ilog2c(int v) { return v <= 1 ? 0 : 1 + ilog2c(v >> 1); }
 
 template <typename E, int MODE, int CZ, int NW, int ROWS>
 __device__ __forceinline__ void warp_wg_body(const Geom& g, const WarpArgs& a, const int tx0, const int ty0, const bool lane_valid, const int wave,
@@ -1123,7 +1128,11 @@ __device__ __forceinline__ void warp_wg_body(const Geom& g, const WarpArgs& a, c
     const E* __restrict__ A = (const E*)a.frame12 + (size_t)CZ * H * Si;
     const E* __restrict__ B = (const E*)a.frame21 + (size_t)CZ * H * Si;
     typedef __attribute__((address_space(3))) void* lds_ptr;
-    auto stage = [&](const void* plane, const int cmin, const int ymin, const int C, const int R, unsigned char* const win) {
+    // AUX: cache policy of the copy.  Frame N-2 (source A) is read for the last time here: its window copy is non-temporal (aux 2) so that its
+    // lines leave L2 / the Infinity Cache first -- +0.9-1.2 % frames/s on the 2160p HDR pipeline, alternating on one box; the same hint on
+    // source B, which the plane-building workgroups of this launch read too, costs 0.7-1.6 % (tools/attic/r05).
+    auto stage = [&](const void* plane, const int cmin, const int ymin, const int C, const int R, unsigned char* const win, auto AUXC) {
+        constexpr int AUX = decltype(AUXC)::value;
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(plane), 0, (int)plane_bytes, 0x00020000);
         const unsigned magic = ((1u << 20) + (unsigned)C - 1u) / (unsigned)C;   // q / C == (q * magic) >> 20 for q < 4096, C <= 64 (q * (magic C - 2^20) < 2^20)
         const int nq = R * C;
@@ -1137,7 +1146,7 @@ __device__ __forceinline__ void warp_wg_body(const Geom& g, const WarpArgs& a, c
                 if (wg_in) {   // the window lies where mirrorCoordinate is the identity: a rectangle of the plane
                     const unsigned off = __umul24((unsigned)(ymin - kExtY) + row, pitch_b) + ((unsigned)cmin + col) * 16u - (unsigned)(kExtX * SZ);
                     HF_DBG_CHECK(q >= (unsigned)nq || (size_t)off + 16 <= (size_t)plane_bytes, 212);   // (only the padding chunks behind the window may lie past the plane: they read as 0)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(win + (size_t)q0 * 16), 16, off, 0, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(win + (size_t)q0 * 16), 16, off, 0, 0, AUX);
                 } else {       // a tile at the frame edge: rows fold back as whole rows; a chunk that touches the left / right mirror zone is
                                // gathered element by element (a reflected run is reversed) -- once per period, not once per output and row
                     const int y = mirror_warp_bl(ymin - kExtY + (int)row, dim_y);
@@ -1146,7 +1155,7 @@ __device__ __forceinline__ void warp_wg_body(const Geom& g, const WarpArgs& a, c
                     const bool zone = x0 < 1 || (!CZ && x0 + VEC - 1 > W - 2);  // (chroma: only runs left of the right zone are staged)
                     if (!zone) {
                         HF_DBG_CHECK(q >= (unsigned)nq || (size_t)rowoff + (size_t)(x0 * SZ) + 16 <= (size_t)plane_bytes, 213);
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(win + (size_t)q0 * 16), 16, rowoff + (unsigned)(x0 * SZ), 0, 0, 0);
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(win + (size_t)q0 * 16), 16, rowoff + (unsigned)(x0 * SZ), 0, 0, AUX);
                     } else {
                         __attribute__((aligned(16))) E v[VEC];
 #pragma unroll
@@ -1163,8 +1172,8 @@ __device__ __forceinline__ void warp_wg_body(const Geom& g, const WarpArgs& a, c
             }
         }
     };
-    if (need_a) stage(A, cmin_a, ymin_a, C_a, R_a, lds);
-    if (need_b) stage(B, cmin_b, ymin_b, C_b, R_b, lds + CHUNKS * 16);
+    if (need_a) stage(A, cmin_a, ymin_a, C_a, R_a, lds, std::integral_constant<int, 2>{});
+    if (need_b) stage(B, cmin_b, ymin_b, C_b, R_b, lds + CHUNKS * 16, std::integral_constant<int, 0>{});
     __builtin_amdgcn_s_waitcnt(0x0F70);                                         // vmcnt(0): this wave's share of the windows is in LDS
     __syncthreads();
     if (!full) return;                                                          // a wave without a tile only helped copying
@@ -1225,11 +1234,6 @@ __device__ __forceinline__ void warp_wg_body(const Geom& g, const WarpArgs& a, c
 // 16-byte loads and stores) for every member that asks (WarpArgs::plane21), placed right in front of the warp workgroups of the same
 // picture rows: the frame's rows are fetched from HBM once for both, and the stand-alone plane kernel with its 25 MB re-read of the
 // frame is not launched (prep_grid_kernel supplies the grid samples the chain of THIS period needs).
-struct PlaneOut {
-    PhaseLayout pl;
-    int blocks;                          // plane-building workgroups per super row (0: the launch builds no planes)
-    FastDiv per_member, per_sr, wpr;     // unit index -> (member, super row, block): scalar divisions (hf_kernels.h)
-};
 static_assert(sizeof(Geom) + sizeof(WarpBatchArgs) + sizeof(PlaneOut) <= 4096, "kernel arguments of warp_wg_kernel (a launch carries at most 4 KB)");
 static_assert(sizeof(WarpArgs) == 168, "hf_kernels.h kMaxWarpBatch is sized for 168-byte members");
 
@@ -1339,7 +1343,7 @@ void launch_blur_flow(const Geom& g, const BlurBatch& b, int radius, int zero_co
         const dim3 grd((g.lw + 31) / 32, (g.lh + 31) / 32, b.n);
         const int T = 32 + 8;
         const size_t smem = (size_t)T * T * sizeof(uint32_t) + 2 * (size_t)T * 32 * sizeof(int);   // 16.6 KB
-        blur_flow_kernel<32, 4><<<grd, 256, smem, stream>>>(b, g.lw, g.lh, radius, zero_count);
+        HF_LAUNCH("blur", (blur_flow_kernel<32, 4>), grd, dim3(256), smem, stream, b, g.lw, g.lh, radius, zero_count);
         return;
     }
     const dim3 grd((g.lw + 15) / 16, (g.lh + 15) / 16, b.n);
@@ -1347,7 +1351,7 @@ void launch_blur_flow(const Geom& g, const BlurBatch& b, int radius, int zero_co
     const size_t smem = (size_t)T * T * sizeof(uint32_t) + 2 * (size_t)T * 16 * sizeof(int);
     if (smem > 48 * 1024)     // large radii (up to 64: 101 KB of the CU's 160 KB LDS) need the opt-in; the attribute is per device
         (void)hipFuncSetAttribute((const void*)blur_flow_kernel<16, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    blur_flow_kernel<16, 0><<<grd, 256, smem, stream>>>(b, g.lw, g.lh, radius, zero_count);
+    HF_LAUNCH("blur", (blur_flow_kernel<16, 0>), grd, dim3(256), smem, stream, b, g.lw, g.lh, radius, zero_count);
 }
 
 void launch_pack_flow(const Geom& g, const int16_t* flow, uint32_t* packed, hipStream_t stream) {
@@ -1402,6 +1406,10 @@ static bool launch_warp_fast(const Geom& g, const WarpBatchArgs& b, hipStream_t 
     const int mode = b.s[0].mode;
     bool dw = false;
     if (!warp_fast_shape<E, VB>(g, b, dw)) return false;
+    if (t_launch_observer && !ev0 && !ev1) {   // timeline (hf_kernels.h): the dispatch carries the observer's events
+        hipEvent_t o0 = nullptr, o1 = nullptr;
+        if (t_launch_observer->next("warp_period", &o0, &o1)) { ev0 = o0; ev1 = o1; }
+    }
     const int rows = 2;  // rows per thread (divides the 2^rs rows of a flow cell); measured on MI355X, 2160p HDR blend: 1 row 25.9 us, 2 rows 24.3 us, 4 rows 30.2 us
                          // (re-measured with the final kernel, fused period HBM-cold: 2 rows 51.1 us, 4 rows 59.3 us -- halving the
                          // per-element scalar work does not pay for halving the number of waves)
@@ -1563,7 +1571,11 @@ bool launch_warp_periods(const Geom& g, int n, const WarpPeriod* periods, int mo
 bool warp_period_can_build_planes(const Geom& g, const PhaseLayout& pl, int n_members) {
     const size_t esz = g.hdr ? 2 : 1;
     const int VEC = (int)(16 / esz), cell = 1 << g.rs;
-    if (cell < VEC || (size_t)g.W * g.H * esz <= (size_t)1920 * 1088) return false;     // one flow cell per 16-byte thread, no 8-byte threads
+    // one flow cell per 16-byte thread, no 8-byte threads.  (Frames that take warp_fast_kernel -- 1080p and smaller -- keep their eager planes:
+    // plane-building workgroups in THAT launch were built and measured in round 5, bit-exact and 2 % slower than the stand-alone plane kernel
+    // there: 131.3-131.7 k against 134.0-134.5 k frames/s at 1080p SDR -- the frame is small enough to be re-read from L2, and the deferred order
+    // adds the grid-sample launch; tools/attic/r05/deferred_planes_fast_kernel.diff)
+    if (cell < VEC || (size_t)g.W * g.H * esz <= (size_t)1920 * 1088) return false;
     const int y_groups = (g.H + 1) / 2, uv_groups = ((g.H >> 1) + 1) / 2;
     const int wpr = (g.W + kWarpTX * VEC - 1) / (kWarpTX * VEC);
     const long n_tiles = (long)wpr * ((y_groups + kWarpTY - 1) / kWarpTY + (uv_groups + kWarpTY - 1) / kWarpTY);

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HF_ABI_VERSION 4
+#define HF_ABI_VERSION 5
 
 typedef struct hf_ctx hf_ctx;
 
@@ -240,6 +240,24 @@ int hf_batch_run_period(hf_batch* batch, const void* const* device_frames, int c
 /* 1: hf_batch_run_period defers the phase planes of this batch (see above); 0: it builds them eagerly. */
 int hf_batch_defers_planes(const hf_batch* batch);
 int hf_batch_sync(hf_batch* batch);   /* hf_sync() of every member */
+/* Timeline of a batch WITHOUT a profiler: while it is on, every dispatch hf_batch_run_period issues (grid samples, fused period warp, each
+ * launch of the refinement chain -- issued one by one instead of as a graph replay -- and the blur) carries the start / stop events of
+ * the dispatch itself (hipExtLaunchKernelGGL), i.e. the timestamps a kernel trace would read, on the clock of the device and relative to
+ * ONE reference per process and device, so the records of several batches (streams) line up.  (rocprofv3's kernel trace costs enough per
+ * dispatch to make four batch streams host-bound: its timeline is not the un-profiled run's.)  The first skip_periods calls of
+ * hf_batch_run_period after _enable pass unobserved (so a driver can arm the timeline before its timed region -- _enable synchronises the
+ * batch's stream -- and have it record in the middle); it switches itself off when max_launches records are taken (a period needs
+ * about 16).  hf_batch_timeline_enable(batch, 0, 0) switches it off and frees the events; _read
+ * synchronises the batch's stream and returns the records taken so far (*n_records = how many exist; at most `capacity` are written). */
+typedef struct hf_timeline_record {
+    char kernel[32];      /* "grid_samples", "warp_period", "plane", "large_windows_x" / "_y", "level_32" ... "level_2", "blur" */
+    int32_t period;       /* hf_batch_run_period calls since the recording started */
+    int32_t reserved;
+    double start_ms;      /* start / end of the dispatch, milliseconds since the process's reference event on this device */
+    double end_ms;
+} hf_timeline_record;
+int hf_batch_timeline_enable(hf_batch* batch, int max_launches, int skip_periods);
+int hf_batch_timeline_read(hf_batch* batch, hf_timeline_record* out, int capacity, int* n_records);
 int hf_batch_size(const hf_batch* batch);
 const char* hf_batch_last_error(const hf_batch* batch);   /* batch == NULL: error of the last failed hf_batch_create (per thread) */
 
