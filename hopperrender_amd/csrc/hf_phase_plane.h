@@ -66,11 +66,19 @@ __device__ __forceinline__ void plane_fast_task(const E* __restrict__ f, uint32_
                 el[c] = pack_element(ya, yb, u, v);
                 sw[c] = RS > 0 ? pack_element(yb, ya, u, v) : el[c];
             }
-            *(uint4*)(base + (size_t)p2 * pl.lwp + pl.mx + j0) = make_uint4(el[0], el[1], el[2], el[3]);
+            // Non-temporal stores: the chain reads the plane one to twelve launches later, by which time a batch's planes (12 x 22 MB) have
+            // long left the 4 MB L2s whatever the policy -- but written with the default policy they push out what the launch still needs
+            // (source rows shared by neighbouring tiles and by these workgroups, the flow tables).  +2-4 % frames/s on the 2160p HDR
+            // pipeline, alternating on one box (tools/attic/r05); the frame LOADS above must keep the default policy (non-temporal: -7 %).
+            typedef unsigned pp_v4 __attribute__((ext_vector_type(4)));
+            auto put = [](uint32_t* dst, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+                const pp_v4 v = {a, b, c, d};
+                __builtin_nontemporal_store(v, (pp_v4*)dst);
+            };
+            put(base + (size_t)p2 * pl.lwp + pl.mx + j0, el[0], el[1], el[2], el[3]);
             uint32_t* mrow = base + (size_t)(NPH2 - 1 - p2) * pl.lwp;
-            const uint4 rev = make_uint4(sw[3], sw[2], sw[1], sw[0]);
-            if (left) *(uint4*)(mrow + jl) = rev;
-            if (right) *(uint4*)(mrow + jr) = rev;
+            if (left) put(mrow + jl, sw[3], sw[2], sw[1], sw[0]);
+            if (right) put(mrow + jr, sw[3], sw[2], sw[1], sw[0]);
         }
     }
 }

@@ -11,7 +11,9 @@ pairs = [("bench_default.json", "bench_default.json"), ("bench_sdr1080.json", "b
          ("microbench.txt", "microbench.txt"), ("stats_default/p_kernel_stats.csv", "bench_default_kernel_stats.csv"),
          ("stats_sdr1080/p_kernel_stats.csv", "bench_sdr1080_kernel_stats.csv"), ("stats_streams1/p_kernel_stats.csv", "bench_streams1_kernel_stats.csv"),
          ("stats_chain16/p_kernel_stats.csv", "chain_batch16_kernel_stats.csv"), ("pmc_warp_valu.txt", "pmc_warp_instructions.txt"),
-         ("pmc_warp_wg_kernel.txt", "pmc_warp_wg_kernel.txt"), ("pmc_chain_batch16.txt", "pmc_chain_batch16.txt"), ("chain_beside_warp.txt", "chain_beside_warp.txt")]
+         ("pmc_warp_wg_kernel.txt", "pmc_warp_wg_kernel.txt"), ("pmc_chain_batch16.txt", "pmc_chain_batch16.txt"), ("chain_beside_warp.txt", "chain_beside_warp.txt"),
+         ("pipeline_timeline.json", "pipeline_timeline.json"), ("pipeline_timeline_sdr1080.json", "pipeline_timeline_sdr1080.json"),
+         ("bench_default_timeline_run.json", "bench_default_timeline_run.json"), ("bench_default_plain_after_timeline.json", "bench_default_plain_after_timeline.json")]
 for a, b in pairs:
     if os.path.exists(os.path.join(src, a)):
         shutil.copyfile(os.path.join(src, a), os.path.join(dst, f"{rnd}_{b}")); print("copied", b)

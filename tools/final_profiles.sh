@@ -6,7 +6,7 @@
 #   batched pipeline at the bench's operating point, stand-alone kernel times.
 #   `tools/final_profiles.sh TAG bench` re-runs only the four bench lines -- after `copy_profiles.py` has regenerated
 #   profiles/roofline_traffic.json from the PMC passes, so that the committed lines price their bytes with THIS round's traffic record.
-TAG=${1:-r04}
+TAG=${1:-r05}
 export TMPDIR=/tmp; R=$PWD; O=$R/gpurun_out/$TAG
 if [ "$2" != bench ]; then rm -rf $O; fi
 mkdir -p $O
@@ -15,6 +15,13 @@ python bench.py --workload sdr1080_24to60 --no-reference > $O/bench_sdr1080.json
 python bench.py --workload sdr1080_64pairs --no-reference --no-cpu-baseline --no-host-io > $O/bench_sdr1080_64pairs.json 2> $O/bench_cfg4.err
 python bench.py --workload hdr2160_nb10_blur32 --no-reference --no-cpu-baseline --no-host-io > $O/bench_hdr2160_nb10_blur32.json 2> $O/bench_cfg5.err
 if [ "$2" = bench ]; then ls $O; exit 0; fi
+# the pipeline's timeline WITHOUT a profiler (hf_batch_timeline_*: start / stop events of every dispatch, one step in the middle of the timed
+# region, plus a stand-alone leg of one batch), bracketed by the plain lines above / below: concurrency per kernel, stretch vs stand-alone,
+# idle gaps per queue (tools/timeline_report.py)
+TQ="--no-cpu-baseline --no-reference --no-host-io --no-other-workloads"
+python bench.py $TQ --timeline-out $O/pipeline_timeline.json > $O/bench_default_timeline_run.json 2>> $O/bench_default.err
+python bench.py $TQ --workload sdr1080_24to60 --timeline-out $O/pipeline_timeline_sdr1080.json > $O/bench_sdr1080_timeline_run.json 2>> $O/bench_sdr1080.err
+python bench.py $TQ > $O/bench_default_plain_after_timeline.json 2>> $O/bench_default.err
 python tools/microbench.py > $O/microbench.txt 2>&1
 python tools/microbench.py --hdr 0 --H 1080 --W 1920 >> $O/microbench.txt 2>&1
 python tools/chain_time.py --batch 1 2 4 8 16 >> $O/microbench.txt 2>&1
