@@ -189,6 +189,7 @@ def parse_args():
                     help="A-B: create the process group (a single-rank RCCL communicator when not launched by torchrun) BEFORE the "
                          "batch streams, to see what the communicator's streams do to the hardware-queue layout")
     ap.add_argument("--no-profile", action="store_true", help="no per-kernel HIP events in the timed region")
+    ap.add_argument("--no-clock-probe", action="store_true", help="do not sample the shader clock in the middle of the timed region")
     ap.add_argument("--timeline-out", default="", help="DIAGNOSTIC: record the start / stop of every dispatch of every batch stream for --timeline-steps "
                     "steps in the middle of the timed region (hf_batch_timeline_*: no profiler) plus a stand-alone leg of one batch, and write "
                     "the raw records + tools/timeline_report.py's analysis to this JSON file")
@@ -532,10 +533,20 @@ def main():
     t0 = time.perf_counter()
     frames_out = 0
     dev_mid = []
+    clock_under_load = clock_probe_call_ms = None
+    import ctypes as C
     for k in range(a.warmup, a.warmup + a.steps):
         frames_out += run_step(k)
         if rank == 0 and k in (a.warmup, a.warmup + a.steps - 1):   # two sysfs reads (~0.1 ms) while the queues are full: first and last step
             dev_mid.append(device_sample(sysfs))
+        if rank == 0 and k == a.warmup + a.steps // 2 and not a.no_clock_probe:
+            # the shader clock the device sustains under THIS load: a one-wave probe on a stream of its own, 0.3 ms in the middle of the timed
+            # region (the host is queues ahead of the GPU here; the call blocks the issuing loop for about a millisecond of a multi-second region)
+            mhz = C.c_double(0.0)
+            tp = time.perf_counter()
+            if capi.load().hf_clock_probe(dev_index, 300, C.byref(mhz)) == 0:
+                clock_under_load = round(mhz.value, 1)
+            clock_probe_call_ms = round(1e3 * (time.perf_counter() - tp), 3)
     host_issue_wall_s = time.perf_counter() - t0   # the host is done issuing; the GPU may still be busy.  NOT the host's cost:
                                                    # once the hardware queues are full every further call blocks until the GPU
                                                    # has retired a packet, so this wall time tracks the GPU's
@@ -758,7 +769,10 @@ def main():
                        "source_periods_per_step": a.streams * P, "source_periods_per_stream_and_step": P,
                        "output_frames_total": int(frames_total), "parallelism": f"pair-sharded x{n_gpus}, no collective",
                        "frame_bytes": F, "flow_grid": [st["low_width"], st["low_height"]], "res_scalar": st["res_scalar"]},
-            "device": device_block(dev_index, sysfs, dev_mid[0] if dev_mid else None, dev_mid[-1] if dev_mid else None),
+            "device": dict(device_block(dev_index, sysfs, dev_mid[0] if dev_mid else None, dev_mid[-1] if dev_mid else None),
+                           shader_clock_mhz_under_load=clock_under_load, clock_probe_call_ms=clock_probe_call_ms,
+                           shader_clock_note="hf_clock_probe in the middle of the timed region: shader cycles per 100 MHz reference tick over 0.3 ms, one wave "
+                                             "beside the running pipeline -- the clock the device actually sustains under this load (pp_dpm sclk is the level requested)"),
             "ms_per_flow_calc": round(prof["flow_ms"] / prof["flow_chains"], 4) if prof["flow_chains"] else None,
             "ms_per_flow_calc_note": "device time of one refinement chain + blur while the other batch streams keep the GPU busy"
                                      + (f"; chains run {a.batch} pairs per launch (hf_batch): this is the batch's time / {a.batch}" if a.batch > 1 else ""),

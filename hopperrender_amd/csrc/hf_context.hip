@@ -531,6 +531,39 @@ int hf_device_rcp(hf_ctx* c, const float* host_in, float* host_out, int n) {
     return HF_OK;
 }
 
+// ---- shader clock under load ----
+// One wave reads the shader-cycle counter (s_memtime) and the 100 MHz reference counter (s_memrealtime) around a spin of `ticks` reference
+// ticks: cycles / time = the clock the shader array actually runs at while everything else the process has queued keeps the device
+// busy (MI355X_MICROARCH.md "DVFS give-back": the chip lowers its clock under load, by a device-dependent amount -- what makes the boxes
+// of a pool differ).  Reads no buffer and writes 16 bytes; in a translation unit of its own so that the product kernels' code is untouched.
+__global__ void clock_probe_kernel(unsigned long long ticks, unsigned long long* out) {
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
+    unsigned long long r1 = r0;
+    while (r1 - r0 < ticks) { __builtin_amdgcn_s_sleep(8); r1 = __builtin_amdgcn_s_memrealtime(); }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = r1 - r0; }
+}
+
+int hf_clock_probe(int device_index, int duration_us, double* shader_mhz) {
+    if (!shader_mhz || duration_us < 10 || duration_us > 100000) return fail(nullptr, HF_ERR_INVALID_ARGUMENT, "hf_clock_probe: bad argument");
+    *shader_mhz = 0.0;
+    if (hipSetDevice(device_index) != hipSuccess) return fail(nullptr, HF_ERR_NO_DEVICE, "hf_clock_probe: bad device %d", device_index);
+    unsigned long long* res = nullptr;
+    hipStream_t s = nullptr;
+    if (hipHostMalloc((void**)&res, 2 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) return fail(nullptr, HF_ERR_OUT_OF_MEMORY, "hf_clock_probe: hipHostMalloc failed");
+    res[0] = res[1] = 0;
+    int rc = HF_OK;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) rc = fail(nullptr, HF_ERR_HIP, "hf_clock_probe: cannot create a stream");
+    if (rc == HF_OK) {
+        clock_probe_kernel<<<1, 64, 0, s>>>((unsigned long long)duration_us * 100ull, res);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) rc = fail(nullptr, HF_ERR_HIP, "hf_clock_probe: launch failed");
+    }
+    if (rc == HF_OK && res[1] > 0) *shader_mhz = (double)res[0] / ((double)res[1] / 100.0);
+    if (s) hipStreamDestroy(s);
+    hipHostFree(res);
+    return rc;
+}
+
 int hf_device_malloc(int device_index, size_t bytes, void** out) {
     if (!out) return HF_ERR_INVALID_ARGUMENT;
     if (hipSetDevice(device_index) != hipSuccess) return fail(nullptr, HF_ERR_NO_DEVICE, "hf_device_malloc: bad device %d", device_index);

@@ -292,6 +292,12 @@ int hf_debug_bounds_selftest(hf_ctx* ctx);
  * built by AMD OpenCL (x / y -> x * rcp(y)); CPU checkers use this to reproduce levels bit-exactly. */
 int hf_device_rcp(hf_ctx* ctx, const float* host_in, float* host_out, int n);
 
+/* Clock of the shader array RIGHT NOW, in MHz: one wave compares the shader-cycle counter with the 100 MHz reference counter over
+ * duration_us microseconds, on a stream of its own, while whatever else the process has queued keeps running (blocks until the probe
+ * has run).  The chip lowers its clock under load by a device-dependent amount; bench.py samples this in the middle of its timed region
+ * so that lines from different boxes can be normalised. */
+int hf_clock_probe(int device_index, int duration_us, double* shader_mhz);
+
 /* ---- measurement: HIP events on ctx's own stream (torch events cannot see this stream) ---- */
 int hf_timer_begin(hf_ctx* ctx);
 int hf_timer_end(hf_ctx* ctx, float* elapsed_ms); /* synchronises on the end event */

@@ -26,7 +26,7 @@ def test_every_declared_symbol_is_exported_and_bound(native_lib):
     assert not (set(syms) - set(capi.SIGNATURES)), f"not bound in capi.py: {sorted(set(syms) - set(capi.SIGNATURES))}"
     for s in syms:
         assert getattr(native_lib, s) is not None
-    assert native_lib.hf_abi_version() == 5   # round 5: hf_batch_timeline_enable / _read (round 4: hf_debug_bounds_*; round 3: hf_batch_run_period / hf_batch_sync, hf_select_device, device_index = -1)
+    assert native_lib.hf_abi_version() == 5   # round 5: hf_batch_timeline_enable / _read, hf_clock_probe (round 4: hf_debug_bounds_*; round 3: hf_batch_run_period / hf_batch_sync, hf_select_device, device_index = -1)
 
 
 def test_struct_layouts_match_the_header(native_lib, tmp_path):

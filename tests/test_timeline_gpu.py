@@ -69,3 +69,11 @@ def test_timeline_off_and_argument_checks(native_lib):
     b.close()
     for m in ms:
         m.close()
+
+
+def test_clock_probe_reads_a_plausible_shader_clock(native_lib):
+    import ctypes as C
+    mhz = C.c_double(0.0)
+    assert native_lib.hf_clock_probe(0, 200, C.byref(mhz)) == 0
+    assert 100.0 < mhz.value < 2600.0, mhz.value          # idle: a low DPM level; under load: up to the 2.4 GHz peak
+    assert native_lib.hf_clock_probe(0, 5, C.byref(mhz)) != 0
