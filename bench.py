@@ -519,8 +519,20 @@ def main():
     if world > 1:     # which device every rank opened (rank r -> r % device_count): part of the line, checked by the multi-rank tests
         rank_devices = [None] * world
         dist.all_gather_object(rank_devices, dev_index)
+    clock_under_load = clock_probe_call_ms = None
+    import ctypes as C
     for k in range(a.warmup):
         run_step(k)
+        if rank == 0 and k == a.warmup - 1 and not a.no_clock_probe:
+            # The shader clock the device sustains under THIS load: a one-wave probe on a stream of its own, 0.3 ms, issued behind the last
+            # warm-up step while the GPU is still working through it.  NOT inside the timed region: its normal-priority stream only gets
+            # through when the highest-priority batch streams leave a gap (measured: the call returns after 0.1-0.7 s), and the issuing
+            # loop must not stand still that long while it is being timed.
+            mhz = C.c_double(0.0)
+            tp = time.perf_counter()
+            if capi.load().hf_clock_probe(dev_index, 300, C.byref(mhz)) == 0:
+                clock_under_load = round(mhz.value, 1)
+            clock_probe_call_ms = round(1e3 * (time.perf_counter() - tp), 3)
     sync_all()
     for c in calcs:
         if not a.no_profile:
@@ -533,20 +545,10 @@ def main():
     t0 = time.perf_counter()
     frames_out = 0
     dev_mid = []
-    clock_under_load = clock_probe_call_ms = None
-    import ctypes as C
     for k in range(a.warmup, a.warmup + a.steps):
         frames_out += run_step(k)
         if rank == 0 and k in (a.warmup, a.warmup + a.steps - 1):   # two sysfs reads (~0.1 ms) while the queues are full: first and last step
             dev_mid.append(device_sample(sysfs))
-        if rank == 0 and k == a.warmup + a.steps // 2 and not a.no_clock_probe:
-            # the shader clock the device sustains under THIS load: a one-wave probe on a stream of its own, 0.3 ms in the middle of the timed
-            # region (the host is queues ahead of the GPU here; the call blocks the issuing loop for about a millisecond of a multi-second region)
-            mhz = C.c_double(0.0)
-            tp = time.perf_counter()
-            if capi.load().hf_clock_probe(dev_index, 300, C.byref(mhz)) == 0:
-                clock_under_load = round(mhz.value, 1)
-            clock_probe_call_ms = round(1e3 * (time.perf_counter() - tp), 3)
     host_issue_wall_s = time.perf_counter() - t0   # the host is done issuing; the GPU may still be busy.  NOT the host's cost:
                                                    # once the hardware queues are full every further call blocks until the GPU
                                                    # has retired a packet, so this wall time tracks the GPU's
@@ -771,8 +773,8 @@ def main():
                        "frame_bytes": F, "flow_grid": [st["low_width"], st["low_height"]], "res_scalar": st["res_scalar"]},
             "device": dict(device_block(dev_index, sysfs, dev_mid[0] if dev_mid else None, dev_mid[-1] if dev_mid else None),
                            shader_clock_mhz_under_load=clock_under_load, clock_probe_call_ms=clock_probe_call_ms,
-                           shader_clock_note="hf_clock_probe in the middle of the timed region: shader cycles per 100 MHz reference tick over 0.3 ms, one wave "
-                                             "beside the running pipeline -- the clock the device actually sustains under this load (pp_dpm sclk is the level requested)"),
+                           shader_clock_note="hf_clock_probe behind the last warm-up step (same load, outside the timed region): shader cycles per 100 MHz reference tick "
+                                             "over 0.3 ms, one wave beside the running pipeline -- the clock the device actually sustains under this load (pp_dpm sclk is the level requested)"),
             "ms_per_flow_calc": round(prof["flow_ms"] / prof["flow_chains"], 4) if prof["flow_chains"] else None,
             "ms_per_flow_calc_note": "device time of one refinement chain + blur while the other batch streams keep the GPU busy"
                                      + (f"; chains run {a.batch} pairs per launch (hf_batch): this is the batch's time / {a.batch}" if a.batch > 1 else ""),

@@ -294,7 +294,7 @@ int hf_device_rcp(hf_ctx* ctx, const float* host_in, float* host_out, int n);
 
 /* Clock of the shader array RIGHT NOW, in MHz: one wave compares the shader-cycle counter with the 100 MHz reference counter over
  * duration_us microseconds, on a stream of its own, while whatever else the process has queued keeps running (blocks until the probe
- * has run).  The chip lowers its clock under load by a device-dependent amount; bench.py samples this in the middle of its timed region
+ * has run).  The chip lowers its clock under load by a device-dependent amount; bench.py samples this behind its last warm-up step (the same load, outside the timed region)
  * so that lines from different boxes can be normalised. */
 int hf_clock_probe(int device_index, int duration_us, double* shader_mhz);
 
