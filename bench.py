@@ -117,6 +117,30 @@ def device_sample(sysfs):
     return out
 
 
+def hbm_probe(dev_index):
+    """What THIS box's memory system sustains for plain streams, on the idle device before anything else runs: a 2 GiB fill and a 2 GiB ->
+    2 GiB copy of torch tensors (best of 5, HIP events).  The boxes of the pool run this pipeline up to 9 % apart at the same shader clock
+    (device.shader_clock_mhz_under_load) -- and the same few per cent apart on these two lines, so a reader can normalise `value`."""
+    import torch
+    try:
+        n = 1 << 29
+        a = torch.empty(n, dtype=torch.float32, device=f"cuda:{dev_index}")
+        b = torch.empty_like(a)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.fill_(1.0); b.copy_(a); torch.cuda.synchronize(dev_index)
+        fill = copy = 0.0
+        for _ in range(5):
+            e0.record(); a.fill_(2.0); e1.record(); e1.synchronize()
+            fill = max(fill, 4.0 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+            e0.record(); b.copy_(a); e1.record(); e1.synchronize()
+            copy = max(copy, 8.0 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+        del a, b
+        torch.cuda.empty_cache()
+        return {"fill_GBps": round(fill, 1), "copy_GBps_read_plus_write": round(copy, 1), "bytes": 4 * n}
+    except Exception as e:
+        return {"error": repr(e)[:200]}
+
+
 def device_block(dev_index, sysfs, start, end):
     """The `device` object of the line: which GPU this was, and its clocks / power when the timed region started and ended.  The boxes of the
     pool differ by up to 9 % on this pipeline: compare frames/s across lines only with these fields side by side."""
@@ -364,6 +388,7 @@ def main():
     if a.gpus != n_gpus and rank == 0 and world > 1:
         print(f"warning: --gpus {a.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
+    hbm_idle = hbm_probe(dev_index) if rank == 0 else None     # before any stream of the workload exists
     import __graft_entry__
     __graft_entry__.build(quiet=True)
     from hopperrender_amd import capi, synth
@@ -772,7 +797,7 @@ def main():
                        "output_frames_total": int(frames_total), "parallelism": f"pair-sharded x{n_gpus}, no collective",
                        "frame_bytes": F, "flow_grid": [st["low_width"], st["low_height"]], "res_scalar": st["res_scalar"]},
             "device": dict(device_block(dev_index, sysfs, dev_mid[0] if dev_mid else None, dev_mid[-1] if dev_mid else None),
-                           shader_clock_mhz_under_load=clock_under_load, clock_probe_call_ms=clock_probe_call_ms,
+                           shader_clock_mhz_under_load=clock_under_load, clock_probe_call_ms=clock_probe_call_ms, hbm_streams_idle_device=hbm_idle,
                            shader_clock_note="hf_clock_probe behind the last warm-up step (same load, outside the timed region): shader cycles per 100 MHz reference tick "
                                              "over 0.3 ms, one wave beside the running pipeline -- the clock the device actually sustains under this load (pp_dpm sclk is the level requested)"),
             "ms_per_flow_calc": round(prof["flow_ms"] / prof["flow_chains"], 4) if prof["flow_chains"] else None,

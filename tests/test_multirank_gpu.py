@@ -107,5 +107,6 @@ def test_default_line_carries_the_other_baseline_configs():
     dev = d["device"]
     assert dev["name"] and dev["box_id"] and dev["compute_units"] == 256
     assert 300.0 < dev["shader_clock_mhz_under_load"] < 2600.0 and dev["clock_probe_call_ms"] < 5000.0
+    assert 2000.0 < dev["hbm_streams_idle_device"]["copy_GBps_read_plus_write"] < 8000.0 and dev["hbm_streams_idle_device"]["fill_GBps"] > 2000.0
     for when in ("at_start_of_timed_region", "at_end_of_timed_region"):
         assert dev[when] is None or set(dev[when]) <= {"sclk_mhz", "mclk_mhz", "fclk_mhz", "power_w", "power_cap_w", "temp_c"}
