@@ -635,10 +635,16 @@ def main():
         for x in calcs[:nb]:
             x.setProfileInterval(1, 1)
             x.resetProfile()
-        for i in range(12):                            # the chain of ONE pair alone
+        for i in range(12):                            # the chain of ONE pair alone, each behind a host synchronisation (an idle device)
             c.updateFrameDeviceRef(pools[0][i % a.pool].ptr)
             c.calculateOpticalFlow()
             c.sync()
+        flow_us_after_sync = 1e3 * c.profile()["flow_ms"] / max(c.profile()["flow_chains"], 1)
+        c.resetProfile()
+        for i in range(48):                            # ... and back to back, the way reference_opencl's figure is taken: device time of each chain
+            c.updateFrameDeviceRef(pools[0][i % a.pool].ptr)
+            c.calculateOpticalFlow()
+        c.sync()
         flow_us = 1e3 * c.profile()["flow_ms"] / max(c.profile()["flow_chains"], 1)
         small = FlowBatch(calcs[:nb]) if nb > 1 else None
         for x in calcs[:nb]:
@@ -658,7 +664,7 @@ def main():
         if small:
             small.close()
         isolated = {"warp_us": 1e3 * p["warp_ms"] / max(p["warp_launches"], 1) / nb, "fpl": p["warp_frames"] / max(p["warp_launches"], 1) / nb,
-                    "launch_us": 1e3 * p["warp_ms"] / max(p["warp_launches"], 1), "flow_chain_us": flow_us, "members": nb}
+                    "launch_us": 1e3 * p["warp_ms"] / max(p["warp_launches"], 1), "flow_chain_us": flow_us, "flow_chain_after_sync_us": flow_us_after_sync, "members": nb}
 
     # Host-I/O leg at N > 1 (the expected scaling limit is host memcpy / the PCIe root complex): EVERY rank feeds
     # one context from pinned host memory and reads every output frame back, all ranks at the same time, each in a child process
@@ -804,6 +810,9 @@ def main():
             "ms_per_flow_calc_note": "device time of one refinement chain + blur while the other batch streams keep the GPU busy"
                                      + (f"; chains run {a.batch} pairs per launch (hf_batch): this is the batch's time / {a.batch}" if a.batch > 1 else ""),
             "ms_per_flow_calc_isolated": round(isolated["flow_chain_us"] / 1e3, 4) if isolated else None,
+            "ms_per_flow_calc_isolated_after_sync": round(isolated["flow_chain_after_sync_us"] / 1e3, 4) if isolated else None,
+            "ms_per_flow_calc_isolated_note": "one pair's refinement chain + blur alone on the GPU, device time per chain: 48 calls back to back (as reference_opencl.ms_per_flow_calc "
+                                              "is taken) / 12 calls each behind a host synchronisation (the device idles in between; what rounds 1-4 printed under the first name)",
             "roofline": roof,
         }
         if host_io_ranks is not None:
