@@ -555,7 +555,7 @@ def main():
             # loop must not stand still that long while it is being timed.
             mhz = C.c_double(0.0)
             tp = time.perf_counter()
-            if capi.load().hf_clock_probe(dev_index, 300, C.byref(mhz)) == 0:
+            if capi.load().hf_clock_probe(dev_index, 3000, C.byref(mhz)) == 0:
                 clock_under_load = round(mhz.value, 1)
             clock_probe_call_ms = round(1e3 * (time.perf_counter() - tp), 3)
     sync_all()
@@ -805,7 +805,7 @@ def main():
             "device": dict(device_block(dev_index, sysfs, dev_mid[0] if dev_mid else None, dev_mid[-1] if dev_mid else None),
                            shader_clock_mhz_under_load=clock_under_load, clock_probe_call_ms=clock_probe_call_ms, hbm_streams_idle_device=hbm_idle,
                            shader_clock_note="hf_clock_probe behind the last warm-up step (same load, outside the timed region): shader cycles per 100 MHz reference tick "
-                                             "over 0.3 ms, one wave beside the running pipeline -- the clock the device actually sustains under this load (pp_dpm sclk is the level requested)"),
+                                             "over 3 ms, one wave beside the running pipeline -- the clock the device actually sustains under this load (pp_dpm sclk is the level requested)"),
             "ms_per_flow_calc": round(prof["flow_ms"] / prof["flow_chains"], 4) if prof["flow_chains"] else None,
             "ms_per_flow_calc_note": "device time of one refinement chain + blur while the other batch streams keep the GPU busy"
                                      + (f"; chains run {a.batch} pairs per launch (hf_batch): this is the batch's time / {a.batch}" if a.batch > 1 else ""),
