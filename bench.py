@@ -549,7 +549,7 @@ def main():
     for k in range(a.warmup):
         run_step(k)
         if rank == 0 and k == a.warmup - 1 and not a.no_clock_probe:
-            # The shader clock the device sustains under THIS load: a one-wave probe on a stream of its own, 0.3 ms, issued behind the last
+            # The shader clock the device sustains under THIS load: a one-wave probe on a stream of its own, 3 ms (the clock moves with the load from millisecond to millisecond), issued behind the last
             # warm-up step while the GPU is still working through it.  NOT inside the timed region: its normal-priority stream only gets
             # through when the highest-priority batch streams leave a gap (measured: the call returns after 0.1-0.7 s), and the issuing
             # loop must not stand still that long while it is being timed.
