@@ -641,7 +641,7 @@ def main():
             c.sync()
         flow_us_after_sync = 1e3 * c.profile()["flow_ms"] / max(c.profile()["flow_chains"], 1)
         c.resetProfile()
-        for i in range(48):                            # ... and back to back, the way reference_opencl's figure is taken: device time of each chain
+        for i in range(48):                            # ... and back to back: device time of each chain (still a new frame, i.e. a cold plane, every time)
             c.updateFrameDeviceRef(pools[0][i % a.pool].ptr)
             c.calculateOpticalFlow()
         c.sync()
@@ -811,8 +811,10 @@ def main():
                                      + (f"; chains run {a.batch} pairs per launch (hf_batch): this is the batch's time / {a.batch}" if a.batch > 1 else ""),
             "ms_per_flow_calc_isolated": round(isolated["flow_chain_us"] / 1e3, 4) if isolated else None,
             "ms_per_flow_calc_isolated_after_sync": round(isolated["flow_chain_after_sync_us"] / 1e3, 4) if isolated else None,
-            "ms_per_flow_calc_isolated_note": "one pair's refinement chain + blur alone on the GPU, device time per chain: 48 calls back to back (as reference_opencl.ms_per_flow_calc "
-                                              "is taken) / 12 calls each behind a host synchronisation (the device idles in between; what rounds 1-4 printed under the first name)",
+            "ms_per_flow_calc_isolated_note": "one pair's refinement chain + blur alone on the GPU, device time per chain, every chain on a NEW frame right behind that frame's plane "
+                                              "build (its plane rows come from HBM): 48 calls back to back / 12 calls each behind a host synchronisation (what rounds 1-4 printed under "
+                                              "the first name).  tools/chain_time.py re-runs ONE frame pair, planes cache-warm, the way reference_opencl.ms_per_flow_calc is taken: 70-71 us "
+                                              "(profiles/r05_microbench.txt)",
             "roofline": roof,
         }
         if host_io_ranks is not None:
