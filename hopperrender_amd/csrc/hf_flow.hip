@@ -93,9 +93,9 @@ __global__ __launch_bounds__(256) void prep_phase_kernel(const PrepBatch batch, 
 }
 
 // Fast path of the plane build (no LDS): one plane_fast_task (hf_phase_plane.h) per thread.
-template <typename E, int RS>
+template <typename E, int RS, bool NT>
 __global__ __launch_bounds__(128) void prep_phase_fast_kernel(const PrepBatch batch, int H, int W, int S, PhaseLayout pl) {
-    plane_fast_task<E, RS, 2>((const E*)batch.frame[blockIdx.z], batch.pp[blockIdx.z], H, W, S, pl, (int)blockIdx.y, (int)(blockIdx.x * 128 + threadIdx.x), 0);
+    plane_fast_task<E, RS, 2, NT>((const E*)batch.frame[blockIdx.z], batch.pp[blockIdx.z], H, W, S, pl, (int)blockIdx.y, (int)(blockIdx.x * 128 + threadIdx.x), 0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -991,12 +991,13 @@ static bool launch_prep_fast(const Geom& g, const PhaseLayout& pl, const PrepBat
         return false;
     for (int i = 0; i < b.n; i++) if (((uintptr_t)b.frame[i]) & 15) return false;
     const dim3 grd((lw / 4 + 127) / 128, g.H / 2, b.n);
+    const bool nt = b.n > 1;     // batches: non-temporal plane stores (hf_phase_plane.h); a single context's plane stays in the caches for its chain
     switch (g.rs) {
-        case 0: HF_LAUNCH("plane", (prep_phase_fast_kernel<E, 0>), grd, dim3(128), 0, stream, b, g.H, g.W, g.in_stride, pl); break;
-        case 1: HF_LAUNCH("plane", (prep_phase_fast_kernel<E, 1>), grd, dim3(128), 0, stream, b, g.H, g.W, g.in_stride, pl); break;
-        case 2: HF_LAUNCH("plane", (prep_phase_fast_kernel<E, 2>), grd, dim3(128), 0, stream, b, g.H, g.W, g.in_stride, pl); break;
-        case 3: HF_LAUNCH("plane", (prep_phase_fast_kernel<E, 3>), grd, dim3(128), 0, stream, b, g.H, g.W, g.in_stride, pl); break;
-        default: HF_LAUNCH("plane", (prep_phase_fast_kernel<E, 4>), grd, dim3(128), 0, stream, b, g.H, g.W, g.in_stride, pl); break;
+        case 0: if (nt) HF_LAUNCH("plane", (prep_phase_fast_kernel<E, 0, true>), grd, dim3(128), 0, stream, b, g.H, g.W, g.in_stride, pl); else HF_LAUNCH("plane", (prep_phase_fast_kernel<E, 0, false>), grd, dim3(128), 0, stream, b, g.H, g.W, g.in_stride, pl); break;
+        case 1: if (nt) HF_LAUNCH("plane", (prep_phase_fast_kernel<E, 1, true>), grd, dim3(128), 0, stream, b, g.H, g.W, g.in_stride, pl); else HF_LAUNCH("plane", (prep_phase_fast_kernel<E, 1, false>), grd, dim3(128), 0, stream, b, g.H, g.W, g.in_stride, pl); break;
+        case 2: if (nt) HF_LAUNCH("plane", (prep_phase_fast_kernel<E, 2, true>), grd, dim3(128), 0, stream, b, g.H, g.W, g.in_stride, pl); else HF_LAUNCH("plane", (prep_phase_fast_kernel<E, 2, false>), grd, dim3(128), 0, stream, b, g.H, g.W, g.in_stride, pl); break;
+        case 3: if (nt) HF_LAUNCH("plane", (prep_phase_fast_kernel<E, 3, true>), grd, dim3(128), 0, stream, b, g.H, g.W, g.in_stride, pl); else HF_LAUNCH("plane", (prep_phase_fast_kernel<E, 3, false>), grd, dim3(128), 0, stream, b, g.H, g.W, g.in_stride, pl); break;
+        default: if (nt) HF_LAUNCH("plane", (prep_phase_fast_kernel<E, 4, true>), grd, dim3(128), 0, stream, b, g.H, g.W, g.in_stride, pl); else HF_LAUNCH("plane", (prep_phase_fast_kernel<E, 4, false>), grd, dim3(128), 0, stream, b, g.H, g.W, g.in_stride, pl); break;
     }
     return true;
 }

@@ -27,7 +27,9 @@ __device__ __forceinline__ uint32_t pack_element(uint32_t ya, uint32_t yb, uint3
 // Requires W == lw << RS, lw % 4 == 0, mx <= lw and 16-byte aligned rows (else: prep_phase_kernel).
 // NZ = 2: both luma rows of chroma row m (z0 = 0; the stand-alone kernel); NZ = 1: luma row 2m + z0 only (the fused warp launch,
 // half the registers per thread).
-template <typename E, int RS, int NZ>
+// NT: non-temporal plane stores (below) -- for the launches of a throughput pipeline; a lone stream keeps the default policy (its chain reads
+// the plane right behind the build, with nothing else competing for the caches).
+template <typename E, int RS, int NZ, bool NT = true>
 __device__ __forceinline__ void plane_fast_task(const E* __restrict__ f, uint32_t* __restrict__ pp, const int H, const int W, const int S,
                                                 const PhaseLayout& pl, const int m, const int t, const int z0) {
     constexpr int NPH = 1 << RS, NE = 4 << RS;               // phases, elements per task and row
@@ -70,10 +72,12 @@ __device__ __forceinline__ void plane_fast_task(const E* __restrict__ f, uint32_
             // long left the 4 MB L2s whatever the policy -- but written with the default policy they push out what the launch still needs
             // (source rows shared by neighbouring tiles and by these workgroups, the flow tables).  +2-4 % frames/s on the 2160p HDR
             // pipeline, alternating on one box (tools/attic/r05); the frame LOADS above must keep the default policy (non-temporal: -7 %).
+            // (NT = false: a single context's plane kernel -- the lone stream's chain, which follows at once, then finds the plane in the caches:
+            //  85 -> 82 us per flow calculation on a new frame.)
             typedef unsigned pp_v4 __attribute__((ext_vector_type(4)));
             auto put = [](uint32_t* dst, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
                 const pp_v4 v = {a, b, c, d};
-                __builtin_nontemporal_store(v, (pp_v4*)dst);
+                if constexpr (NT) __builtin_nontemporal_store(v, (pp_v4*)dst); else *(pp_v4*)dst = v;
             };
             put(base + (size_t)p2 * pl.lwp + pl.mx + j0, el[0], el[1], el[2], el[3]);
             uint32_t* mrow = base + (size_t)(NPH2 - 1 - p2) * pl.lwp;
