@@ -11,4 +11,5 @@ for src in sys.argv[1:]:
         d = subprocess.run(["c++filt", n], capture_output=True, text=True).stdout.strip()
         d = re.sub(r"^void hf::\(anonymous namespace\)::", "", d).split("(")[0]
         v = int(g("next_free_vgpr").group(1))
-        print(f"{d[:90]:90s} vgpr {v:4d} ({512 // max(v, 1) if v <= 512 else 0} waves/SIMD) sgpr {g('next_free_sgpr').group(1):>4} lds {g('group_segment_fixed_size').group(1):>6} scratch {g('private_segment_fixed_size').group(1)}")
+        alloc = -(-v // 8) * 8                                   # the hardware allocates in granules of 8 registers (MI355X_MICROARCH.md "Register files")
+        print(f"{d[:90]:90s} vgpr {v:4d} ({min(8, 512 // max(alloc, 8))} waves/SIMD) sgpr {g('next_free_sgpr').group(1):>4} lds {g('group_segment_fixed_size').group(1):>6} scratch {g('private_segment_fixed_size').group(1)}")
