@@ -77,3 +77,31 @@ def test_clock_probe_reads_a_plausible_shader_clock(native_lib):
     assert native_lib.hf_clock_probe(0, 200, C.byref(mhz)) == 0
     assert 100.0 < mhz.value < 2600.0, mhz.value          # idle: a low DPM level; under load: up to the 2.4 GHz peak
     assert native_lib.hf_clock_probe(0, 5, C.byref(mhz)) != 0
+
+
+def test_timeline_of_an_eager_plane_batch(native_lib):
+    """1080p SDR batches build their planes eagerly: a period is the plane kernel, the chain's twelve launches, then the period warp."""
+    from hopperrender_amd import capi, synth
+    from hopperrender_amd.calc import DeviceBuffer, FlowBatch, OpticalFlowCalcSDR
+    H, W, n = 1080, 1920, 6
+    sc = synth.Scene(H, W, False, 7)
+    dev = []
+    for k in range(5):
+        f = sc.frame(k); b = DeviceBuffer(f.nbytes); b.upload(f); dev.append(b)
+    ms = [OpticalFlowCalcSDR(H, W, search_radius=16, flags=capi.HF_FLAG_ASYNC | capi.HF_FLAG_NO_TIMING) for _ in range(n)]
+    b = FlowBatch(ms)
+    assert not b.defersPlanes()
+    outs = [[DeviceBuffer(ms[0].output_frame_bytes) for _ in range(3)] for _ in range(n)]
+    T = [0.1988, 0.5984, 0.998]
+    b.timelineEnable(2 * 14 + 20, 2)
+    for k in range(5):
+        b.runPeriod(b.preparePeriod([dev[k].ptr] * n, [T] * n if k >= 2 else None, [[x.ptr for x in o] for o in outs] if k >= 2 else None, 2, calculate_flow=k >= 1))
+    b.sync()
+    recs = b.timelineRead()
+    names = [r[0] for r in recs if r[1] == 0]
+    assert names == ["plane"] + ["large_windows_x", "large_windows_y"] * 3 + ["level_32", "level_16", "level_8", "level_4", "level_2", "blur", "warp_period"], names
+    b.close()
+    for m in ms:
+        m.close()
+    for x in dev + [y for o in outs for y in o]:
+        x.free()
