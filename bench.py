@@ -136,7 +136,17 @@ def hbm_probe(dev_index):
             copy = max(copy, 8.0 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9)
         del a, b
         torch.cuda.empty_cache()
-        return {"fill_GBps": round(fill, 1), "copy_GBps_read_plus_write": round(copy, 1), "bytes": 4 * n}
+        out = {"fill_GBps": round(fill, 1), "copy_GBps_read_plus_write": round(copy, 1), "bytes": 4 * n,
+               "note": "torch fill_ / copy_ of 2 GiB tensors; streaming_copy_GBps = the library's own 16-bytes-per-lane non-temporal copy (hf_hbm_copy_probe), read + write"}
+        try:
+            import ctypes as C
+            from hopperrender_amd import capi
+            g = C.c_double(0.0)
+            if capi.load().hf_hbm_copy_probe(dev_index, 4 * n, 5, C.byref(g)) == 0:
+                out["streaming_copy_GBps"] = round(g.value, 1)
+        except Exception as e:
+            out["streaming_copy_error"] = repr(e)[:120]
+        return out
     except Exception as e:
         return {"error": repr(e)[:200]}
 
@@ -388,9 +398,9 @@ def main():
     if a.gpus != n_gpus and rank == 0 and world > 1:
         print(f"warning: --gpus {a.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
-    hbm_idle = hbm_probe(dev_index) if rank == 0 else None     # before any stream of the workload exists
     import __graft_entry__
     __graft_entry__.build(quiet=True)
+    hbm_idle = hbm_probe(dev_index) if rank == 0 else None     # before any stream of the workload exists
     from hopperrender_amd import capi, synth
     from hopperrender_amd.calc import DeviceBuffer, FlowBatch, OpticalFlowCalcHDR, OpticalFlowCalcSDR
     from hopperrender_amd.protocol import SOURCE_24, BlendSchedule
@@ -733,6 +743,9 @@ def main():
                 "compulsory_definition": "frames/s per GPU x (2F + kF + 4N k + B_flow) / k bytes per output frame, k = output frames per pair and source period, "
                                          "B_flow = 6 N bpp + 4 N (SURVEY.md 8(d)): bytes NO implementation can avoid",
                 "compulsory_bytes_per_pair_and_period": int(compulsory_pair_period), "moved_over_compulsory": round(bytes_per_frame * k_out_sched / compulsory_pair_period, 3),
+                "frac_of_this_box_streaming_copy": (round(physical_gbs / hbm_idle["streaming_copy_GBps"], 4) if hbm_idle and hbm_idle.get("streaming_copy_GBps") else None),
+                "frac_of_this_box_note": "achieved (physical GB/s) / what a plain 16-byte-per-lane copy reads + writes per second on the idle device of THIS run "
+                                         "(device.hbm_streams_idle_device.streaming_copy_GBps): the pipeline's traffic is 28 % reads and 72 % writes",
                 "frac_algorithmic": round(pipeline_gbs / HBM_PEAK_GBS, 4), "achieved_algorithmic": round(pipeline_gbs, 1),
                 "algorithmic_definition": "SURVEY.md 8(d): frames/s per GPU x B_out, B_out = 3F + 4N bytes per output frame",
                 "algorithmic_bytes_per_unit": b_out,

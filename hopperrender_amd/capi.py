@@ -147,6 +147,7 @@ SIGNATURES = {
     "hf_hostio_last_error": (C.c_char_p, [_vp]),
     "hf_device_count": (_i, []),
     "hf_clock_probe": (_i, [_i, _i, C.POINTER(C.c_double)]),
+    "hf_hbm_copy_probe": (_i, [_i, C.c_size_t, _i, C.POINTER(C.c_double)]),
     "hf_device_malloc": (_i, [_i, C.c_size_t, C.POINTER(_vp)]),
     "hf_device_free": (_i, [_i, _vp]),
     "hf_memcpy_h2d": (_i, [_i, _vp, _vp, C.c_size_t]),

@@ -564,6 +564,58 @@ int hf_clock_probe(int device_index, int duration_us, double* shader_mhz) {
     return rc;
 }
 
+// ---- what this device's HBM sustains for a plain streaming copy (the yardstick a bandwidth-bound pipeline should be held against) ----
+// 16 bytes per lane, 4 loads in flight per thread, non-temporal loads and stores: the access shape of the guide's "float4 copy".
+__global__ __launch_bounds__(256) void hbm_copy_probe_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+    typedef unsigned v4 __attribute__((ext_vector_type(4)));
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const v4 a = __builtin_nontemporal_load((const v4*)src + i), b = __builtin_nontemporal_load((const v4*)src + i + stride);
+        const v4 c = __builtin_nontemporal_load((const v4*)src + i + 2 * stride), d = __builtin_nontemporal_load((const v4*)src + i + 3 * stride);
+        __builtin_nontemporal_store(a, (v4*)dst + i); __builtin_nontemporal_store(b, (v4*)dst + i + stride);
+        __builtin_nontemporal_store(c, (v4*)dst + i + 2 * stride); __builtin_nontemporal_store(d, (v4*)dst + i + 3 * stride);
+    }
+    for (; i < n16; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load((const v4*)src + i), (v4*)dst + i);
+}
+
+int hf_hbm_copy_probe(int device_index, size_t bytes, int repeats, double* read_plus_write_GBps) {
+    if (!read_plus_write_GBps || bytes < (1u << 20) || repeats < 1 || repeats > 100) return fail(nullptr, HF_ERR_INVALID_ARGUMENT, "hf_hbm_copy_probe: bad argument");
+    *read_plus_write_GBps = 0.0;
+    if (hipSetDevice(device_index) != hipSuccess) return fail(nullptr, HF_ERR_NO_DEVICE, "hf_hbm_copy_probe: bad device %d", device_index);
+    bytes &= ~(size_t)15;
+    void *a = nullptr, *b = nullptr;
+    hipStream_t s = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = HF_OK;
+    if (hipMalloc(&a, bytes) != hipSuccess || hipMalloc(&b, bytes) != hipSuccess) rc = fail(nullptr, HF_ERR_OUT_OF_MEMORY, "hf_hbm_copy_probe: hipMalloc failed");
+    if (rc == HF_OK && (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess))
+        rc = fail(nullptr, HF_ERR_HIP, "hf_hbm_copy_probe: stream / event creation failed");
+    if (rc == HF_OK) {
+        (void)hipMemsetAsync(a, 0x5A, bytes, s);
+        const size_t n16 = bytes / 16;
+        // one pass of four 16-byte elements per thread, no loop: measured fastest on MI355X (tools/ubench/copy_rate.hip, 2 GiB: 5.7 TB/s
+        // with 131,072 workgroups against 4.8-5.3 TB/s with 2,048-32,768 looping ones; plain or non-temporal, 1-8 loads in flight: +-3 %)
+        const unsigned blocks = (unsigned)((n16 + 1023) / 1024);
+        float best = 0.f;
+        for (int r = 0; r <= repeats && rc == HF_OK; r++) {      // (the first pass warms up)
+            (void)hipEventRecord(e0, s);
+            hbm_copy_probe_kernel<<<blocks, 256, 0, s>>>((const uint4*)a, (uint4*)b, n16);
+            (void)hipEventRecord(e1, s);
+            float ms = 0.f;
+            if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) rc = fail(nullptr, HF_ERR_HIP, "hf_hbm_copy_probe: launch failed");
+            else if (r > 0 && ms > 0.f) { const float g = (float)(2.0 * (double)bytes / (ms * 1e-3) / 1e9); best = g > best ? g : best; }
+        }
+        *read_plus_write_GBps = (double)best;
+    }
+    if (e0) hipEventDestroy(e0);
+    if (e1) hipEventDestroy(e1);
+    if (s) hipStreamDestroy(s);
+    if (a) hipFree(a);
+    if (b) hipFree(b);
+    return rc;
+}
+
 int hf_device_malloc(int device_index, size_t bytes, void** out) {
     if (!out) return HF_ERR_INVALID_ARGUMENT;
     if (hipSetDevice(device_index) != hipSuccess) return fail(nullptr, HF_ERR_NO_DEVICE, "hf_device_malloc: bad device %d", device_index);

@@ -297,6 +297,9 @@ int hf_device_rcp(hf_ctx* ctx, const float* host_in, float* host_out, int n);
  * has run).  The chip lowers its clock under load by a device-dependent amount; bench.py samples this behind its last warm-up step (the same load, outside the timed region)
  * so that lines from different boxes can be normalised. */
 int hf_clock_probe(int device_index, int duration_us, double* shader_mhz);
+/* What this device's HBM sustains for a plain streaming copy of `bytes` bytes (16 bytes per lane, non-temporal loads and stores; best of
+ * `repeats` passes; read + write bytes per second, GB/s): the yardstick a bandwidth-bound pipeline should be held against on THIS box. */
+int hf_hbm_copy_probe(int device_index, size_t bytes, int repeats, double* read_plus_write_GBps);
 
 /* ---- measurement: HIP events on ctx's own stream (torch events cannot see this stream) ---- */
 int hf_timer_begin(hf_ctx* ctx);

@@ -105,3 +105,11 @@ def test_timeline_of_an_eager_plane_batch(native_lib):
         m.close()
     for x in dev + [y for o in outs for y in o]:
         x.free()
+
+
+def test_hbm_copy_probe_reads_a_plausible_rate(native_lib):
+    import ctypes as C
+    g = C.c_double(0.0)
+    assert native_lib.hf_hbm_copy_probe(0, 1 << 30, 3, C.byref(g)) == 0
+    assert 2000.0 < g.value < 8000.0, g.value           # GB/s read + write: HBM3E at 8 TB/s peak
+    assert native_lib.hf_hbm_copy_probe(0, 16, 3, C.byref(g)) != 0
