@@ -17,6 +17,7 @@ HF_FLAG_NO_FUSED_WARP = 0x80
 HF_FLAG_NO_TIMING = 0x200
 HF_FLAG_BATCH_NORMAL_PRIORITY = 0x800
 HF_FLAG_BATCH_EAGER_PLANES = 0x1000
+HF_FLAG_NO_SAD_REUSE = 0x2000
 HF_MAX_PERIOD_OUTPUTS = 6
 
 (HF_OK, HF_ERR_INVALID_ARGUMENT, HF_ERR_NO_DEVICE, HF_ERR_OUT_OF_MEMORY, HF_ERR_HIP, HF_ERR_STATE) = (0, -1, -2, -3, -4, -5)

@@ -133,8 +133,8 @@ int hf_batch_create(hf_ctx* const* members, int n, hf_batch** out) {
         const hf::Geom &a = l->g, &b = m->g;
         const bool same = a.hdr == b.hdr && a.H == b.H && a.W == b.W && a.in_stride == b.in_stride && a.out_stride == b.out_stride &&
                           a.rs == b.rs && m->device == l->device && m->cfg.iterations == l->cfg.iterations &&
-                          m->cfg.blur_radius == l->cfg.blur_radius;
-        if (!same) return batch_fail(nullptr, HF_ERR_INVALID_ARGUMENT, "hf_batch_create: members differ in geometry, device, iterations or blur radius");
+                          m->cfg.blur_radius == l->cfg.blur_radius && !m->sadtab == !l->sadtab;
+        if (!same) return batch_fail(nullptr, HF_ERR_INVALID_ARGUMENT, "hf_batch_create: members differ in geometry, device, iterations, blur radius or HF_FLAG_NO_SAD_REUSE");
         if (!m->async() || m->io_in || m->dual() != l->dual())
             return batch_fail(nullptr, HF_ERR_INVALID_ARGUMENT, "hf_batch_create: members must be HF_FLAG_ASYNC contexts (all single-stream or all HF_FLAG_DUAL_STREAM) without async host I/O");
     }

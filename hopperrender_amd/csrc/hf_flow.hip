@@ -232,13 +232,35 @@ __device__ __forceinline__ Elems<PX> buffer_elems(__amdgpu_buffer_rsrc_t rsrc, u
 // on the vector ALU at all (round 1: ~13 of the ~36 VALU instructions per candidate).  Otherwise it is per lane.
 // (The reference does this arithmetic in 16-bit, calcDeltaSumsKernelSDR.h:75-76; offsets are bounded by
 //  iterations * 64 + 64 < 2^15, so nothing ever wraps.)
-template <int PX, bool UNI, bool FULL>
+// Four candidate elements of a strip against its four frame-N samples.  PACK: the SADs of the strip's two 2-pixel halves side by side
+// -- pixels 0, 1 in the low and pixels 2, 3 in the high 16 bits (each <= 2 x 765 per row) -- ADDED to t: the per-block form the SAD
+// tables keep (below); otherwise the sum of all four, added to t.
+template <bool PACK>
+__device__ __forceinline__ uint32_t sad4(const uint32_t* c, uint32_t sel, const uint32_t* ref, uint32_t t) {
+    if constexpr (PACK) {
+        uint32_t hi = __builtin_amdgcn_sad_u8(__builtin_amdgcn_perm(c[2], c[2], sel), ref[2], 0u);
+        hi = __builtin_amdgcn_sad_u8(__builtin_amdgcn_perm(c[3], c[3], sel), ref[3], hi);
+        t = __builtin_amdgcn_sad_u8(__builtin_amdgcn_perm(c[0], c[0], sel), ref[0], t);
+        t = __builtin_amdgcn_sad_u8(__builtin_amdgcn_perm(c[1], c[1], sel), ref[1], t);
+        return t + (hi << 16);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) t = __builtin_amdgcn_sad_u8(__builtin_amdgcn_perm(c[i], c[i], sel), ref[i], t);
+        return t;
+    }
+}
+
+// R16 (here and below): the search radius is 16 although the tile may hang over the grid's edge (FULL false): the candidate loops are
+// unconditional and only the validity masks remain -- the partial tiles of a launch (the bottom tile row of a 480 x 270 grid) are its
+// longest waves, and with a run-time radius every candidate sits behind its own test
+template <int PX, bool UNI, bool FULL, bool PACK = false, bool R16 = FULL>
 __device__ __forceinline__ void strip_sads(uint32_t* sad, const Geom& g, const FlowStep& a, const Strip<PX>& s,
                                            int ox, int oy, int axis) {
+    static_assert(!PACK || (PX == 4 && FULL), "the packed per-block form exists for full tiles of 4-pixel strips");
     const PhaseLayout& pl = a.pl;
     const int sy = s.cy << g.rs;
     const bool ragged = !FULL && (g.lw & (PX - 1)) != 0;              // kernel-uniform: some strip hangs over the right grid edge
-    const int R = FULL ? 16 : a.R;
+    const int R = R16 ? 16 : a.R;
     const bool any = FULL || s.any;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.pp1, 0, (int)pl.bytes, 0x00020000);
     if (UNI) { ox = __builtin_amdgcn_readfirstlane(ox); oy = __builtin_amdgcn_readfirstlane(oy); }
@@ -290,7 +312,9 @@ __device__ __forceinline__ void strip_sads(uint32_t* sad, const Geom& g, const F
 #pragma unroll
     for (int cz = 0; cz < 16; cz++) {
         uint32_t t = sad[cz];
-        if (cz < R && any) {
+        if constexpr (PACK) {
+            t = sad4<true>(c1[cz].d, sel[cz], s.ref, t);
+        } else if (cz < R && any) {
 #pragma unroll
             for (int i = 0; i < PX; i++) {
                 uint32_t v = __builtin_amdgcn_perm(c1[cz].d[i], c1[cz].d[i], sel[cz]);
@@ -356,7 +380,7 @@ template <int WROWS, int LPR, int NW> constexpr size_t ystage_bytes(int rs) {
 
 // tid: thread of the workgroup, row-major over the tile (tile row tid / LPR); (wx0, cy0): first grid column / row of the tile; ref: the thread's
 // four frame-N samples.  Workgroup-uniform call (contains a barrier when NW > 1).
-template <int RS, int WROWS, int LPR, int NW>
+template <int RS, int WROWS, int LPR, int NW, bool PACK = false>
 __device__ __forceinline__ void ysads_tile_lds(uint32_t* sad, const FlowStep& a, const uint32_t* ref, int ox, int oy, int wx0, int cy0, int tid, uint32_t* stage) {
     using Y = YRows<RS, WROWS, LPR, NW>;
     typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -396,26 +420,24 @@ __device__ __forceinline__ void ysads_tile_lds(uint32_t* sad, const FlowStep& a,
     });
 #pragma unroll
     for (int cz = 0; cz < 16; cz++) {
-        uint32_t t = sad[cz];
-#pragma unroll
-        for (int i = 0; i < 4; i++) t = __builtin_amdgcn_sad_u8(__builtin_amdgcn_perm(c1[cz][i], c1[cz][i], sel), ref[i], t);
-        sad[cz] = t;
+        const uint32_t c[4] = {c1[cz][0], c1[cz][1], c1[cz][2], c1[cz][3]};
+        sad[cz] = sad4<PACK>(c, sel, ref, sad[cz]);
     }
 }
 
 // The staged form applies to full tiles (R = 16) of planes with rs <= 4 whose candidate rows need no reflection.  ox, oy: the window's.
-template <int WROWS, int LPR, int NW>
+template <int WROWS, int LPR, int NW, bool PACK = false>
 __device__ __forceinline__ bool ysads_tile_try(uint32_t* sad, const Geom& g, const FlowStep& a, const uint32_t* ref, int ox, int oy, int wx0, int cy0, int tid, uint32_t* stage) {
     ox = __builtin_amdgcn_readfirstlane(ox); oy = __builtin_amdgcn_readfirstlane(oy);
     wx0 = __builtin_amdgcn_readfirstlane(wx0); cy0 = __builtin_amdgcn_readfirstlane(cy0);
     if (g.rs < 0 || g.rs > 4) return false;               // (kernel-uniform; such a launch has no dynamic LDS)
     if ((cy0 << g.rs) + oy + rel16(0) < 0 || ((cy0 + WROWS - 1) << g.rs) + oy + rel16(15) > g.H - 1) return false;
     switch (g.rs) {
-        case 0: ysads_tile_lds<0, WROWS, LPR, NW>(sad, a, ref, ox, oy, wx0, cy0, tid, stage); break;
-        case 1: ysads_tile_lds<1, WROWS, LPR, NW>(sad, a, ref, ox, oy, wx0, cy0, tid, stage); break;
-        case 2: ysads_tile_lds<2, WROWS, LPR, NW>(sad, a, ref, ox, oy, wx0, cy0, tid, stage); break;
-        case 3: ysads_tile_lds<3, WROWS, LPR, NW>(sad, a, ref, ox, oy, wx0, cy0, tid, stage); break;
-        default: ysads_tile_lds<4, WROWS, LPR, NW>(sad, a, ref, ox, oy, wx0, cy0, tid, stage); break;
+        case 0: ysads_tile_lds<0, WROWS, LPR, NW, PACK>(sad, a, ref, ox, oy, wx0, cy0, tid, stage); break;
+        case 1: ysads_tile_lds<1, WROWS, LPR, NW, PACK>(sad, a, ref, ox, oy, wx0, cy0, tid, stage); break;
+        case 2: ysads_tile_lds<2, WROWS, LPR, NW, PACK>(sad, a, ref, ox, oy, wx0, cy0, tid, stage); break;
+        case 3: ysads_tile_lds<3, WROWS, LPR, NW, PACK>(sad, a, ref, ox, oy, wx0, cy0, tid, stage); break;
+        default: ysads_tile_lds<4, WROWS, LPR, NW, PACK>(sad, a, ref, ox, oy, wx0, cy0, tid, stage); break;
     }
     return true;
 }
@@ -423,7 +445,7 @@ __device__ __forceinline__ bool ysads_tile_try(uint32_t* sad, const Geom& g, con
 // The same for 8 x 8 windows, four per wave (Map<8>: 16 lanes = one window, lane i of it = tile row i / 2, column group i & 1): every window
 // has its own offsets, so each 16-lane group copies ITS 63 (rs = 3) / 73 (rs = 2) rows of 32 bytes -- 128 row segments per window before --
 // with per-lane addresses.  A copy instruction lands lane-contiguous in LDS: slot t of window w lies at 1,024 (t / 16) + 256 w + 16 (t % 16).
-template <int RS>
+template <int RS, bool PACK = false>
 __device__ __forceinline__ void ysads_win8_lds(uint32_t* sad, const FlowStep& a, const uint32_t* ref, int ox, int oy, int cx0, int cy, int lane, uint32_t* stage) {
     using Y = YRows<RS, 8, 2, 1>;
     constexpr int kCopies = (Y::kTotal * 2 + 15) / 16;
@@ -463,10 +485,8 @@ __device__ __forceinline__ void ysads_win8_lds(uint32_t* sad, const FlowStep& a,
     });
 #pragma unroll
     for (int cz = 0; cz < 16; cz++) {
-        uint32_t t = sad[cz];
-#pragma unroll
-        for (int i = 0; i < 4; i++) t = __builtin_amdgcn_sad_u8(__builtin_amdgcn_perm(c1[cz][i], c1[cz][i], sel), ref[i], t);
-        sad[cz] = t;
+        const uint32_t c[4] = {c1[cz][0], c1[cz][1], c1[cz][2], c1[cz][3]};
+        sad[cz] = sad4<PACK>(c, sel, ref, sad[cz]);
     }
 }
 template <int RS> constexpr size_t win8_stage_bytes_of() { return (size_t)((YRows<RS, 8, 2, 1>::kTotal * 2 + 15) / 16) * 1024; }
@@ -476,17 +496,18 @@ constexpr size_t win8_stage_bytes(int rs) {
 }
 
 // cx0, cy, ox, oy: the lane's own (per window).  Taken only if all four windows of the wave need no reflection.
+template <bool PACK = false>
 __device__ __forceinline__ bool ysads_win8_try(uint32_t* sad, const Geom& g, const FlowStep& a, const uint32_t* ref, int ox, int oy, int cx0, int cy, int lane, uint32_t* stage) {
     if (g.rs < 0 || g.rs > 4) return false;
     const int cy0 = cy - ((lane & 15) >> 1);
     const bool outside = (cy0 << g.rs) + oy + rel16(0) < 0 || ((cy0 + 7) << g.rs) + oy + rel16(15) > g.H - 1;
     if (__builtin_amdgcn_ballot_w64(outside) != 0) return false;
     switch (g.rs) {
-        case 0: ysads_win8_lds<0>(sad, a, ref, ox, oy, cx0, cy, lane, stage); break;
-        case 1: ysads_win8_lds<1>(sad, a, ref, ox, oy, cx0, cy, lane, stage); break;
-        case 2: ysads_win8_lds<2>(sad, a, ref, ox, oy, cx0, cy, lane, stage); break;
-        case 3: ysads_win8_lds<3>(sad, a, ref, ox, oy, cx0, cy, lane, stage); break;
-        default: ysads_win8_lds<4>(sad, a, ref, ox, oy, cx0, cy, lane, stage); break;
+        case 0: ysads_win8_lds<0, PACK>(sad, a, ref, ox, oy, cx0, cy, lane, stage); break;
+        case 1: ysads_win8_lds<1, PACK>(sad, a, ref, ox, oy, cx0, cy, lane, stage); break;
+        case 2: ysads_win8_lds<2, PACK>(sad, a, ref, ox, oy, cx0, cy, lane, stage); break;
+        case 3: ysads_win8_lds<3, PACK>(sad, a, ref, ox, oy, cx0, cy, lane, stage); break;
+        default: ysads_win8_lds<4, PACK>(sad, a, ref, ox, oy, cx0, cy, lane, stage); break;
     }
     return true;
 }
@@ -585,10 +606,10 @@ __device__ __forceinline__ int group_reduce(uint32_t* sad, int lane) {
 
 // argmin over all candidates of the group; every lane of the group returns the same winner.
 // `captured` (optional) receives the full cost sum of candidate cap_cz.
-template <int G, bool FULL, int XM = 1>
+template <int G, bool R16, int XM = 1>
 __device__ __forceinline__ int group_argmin(const uint32_t* tot, int first, const FlowStep& a, int searched0,
                                             const NbPacked& nb, uint32_t npix, int cap_cz, bool want_cap, uint32_t& captured, int lane) {
-    const int R = FULL ? 16 : a.R;
+    const int R = R16 ? 16 : a.R;
     Best b{0xFFFFFFFFu, 16};
     uint32_t cap = 0;
 #pragma unroll
@@ -658,12 +679,10 @@ __device__ __forceinline__ int resolve_pending(const Geom& g, const FlowStep& a,
 // Kernel-argument form of a FlowBatch.  A launch carries at most 4 KB of arguments and a FlowStep is 248 bytes, but the
 // members of a batch differ only in their 13 buffer pointers: the launch gets ONE FlowStep (member 0's) plus the pointers
 // of every member (104 bytes each: 32 members = 3.3 KB), and a workgroup rebuilds its member's FlowStep in scalar registers.
-struct FlowPtrs {
+struct FlowPtrs {           // what differs between the members of a batch: six allocations (every table / sum pointer is member 0's + a rebase)
     const uint32_t *pp1, *pp2;
-    int16_t *cur_tx, *cur_ty, *prev_tx, *prev_ty;
-    uint32_t *sums, *total_delta;
-    int16_t *pend_tx, *pend_ty, *pend_prev_tx, *pend_prev_ty;
-    const uint32_t* pend_sums;
+    int16_t* tables;
+    uint32_t *sums, *total_delta, *sadtab, *work;
 };
 struct FlowBatchArgs {
     int n;
@@ -682,19 +701,22 @@ static FlowBatchArgs pack_batch(const FlowBatch& b, int tiles_x, int tiles_y) {
     k.common = b.s[0];
     for (int i = 0; i < b.n; i++) {
         const FlowStep& f = b.s[i];
-        k.m[i] = FlowPtrs{f.pp1, f.pp2, f.cur.tx, f.cur.ty, f.prev.tx, f.prev.ty, f.sums, f.total_delta,
-                          f.pend.lvl.tx, f.pend.lvl.ty, f.pend.lvl_prev.tx, f.pend.lvl_prev.ty, f.pend.sums};
+        k.m[i] = FlowPtrs{f.pp1, f.pp2, f.tables_base, f.sums_base, f.total_delta, f.sadtab, f.work};
     }
     return k;
 }
 __device__ __forceinline__ FlowStep member_step(const FlowBatchArgs& k, int i) {
     FlowStep a = k.common;
     const FlowPtrs& p = k.m[i];
-    a.pp1 = p.pp1; a.pp2 = p.pp2;
-    a.cur.tx = p.cur_tx; a.cur.ty = p.cur_ty; a.prev.tx = p.prev_tx; a.prev.ty = p.prev_ty;
-    a.sums = p.sums; a.total_delta = p.total_delta;
-    a.pend.lvl.tx = p.pend_tx; a.pend.lvl.ty = p.pend_ty; a.pend.lvl_prev.tx = p.pend_prev_tx; a.pend.lvl_prev.ty = p.pend_prev_ty;
-    a.pend.sums = p.pend_sums;
+    a.pp1 = p.pp1; a.pp2 = p.pp2; a.total_delta = p.total_delta; a.sadtab = p.sadtab; a.work = p.work;
+    const ptrdiff_t dt = p.tables - a.tables_base, ds = p.sums - a.sums_base;   // (scalar arithmetic; null stays null)
+    auto rt = [dt](int16_t* x) { return x ? x + dt : x; };
+    a.cur.tx = rt(a.cur.tx); a.cur.ty = rt(a.cur.ty); a.prev.tx = rt(a.prev.tx); a.prev.ty = rt(a.prev.ty);
+    a.prev2.tx = rt(a.prev2.tx); a.prev2.ty = rt(a.prev2.ty);
+    a.pend.lvl.tx = rt(a.pend.lvl.tx); a.pend.lvl.ty = rt(a.pend.lvl.ty); a.pend.lvl_prev.tx = rt(a.pend.lvl_prev.tx); a.pend.lvl_prev.ty = rt(a.pend.lvl_prev.ty);
+    a.sums = a.sums ? a.sums + ds : a.sums;
+    a.pend.sums = a.pend.sums ? a.pend.sums + ds : a.pend.sums;
+    a.tables_base = p.tables; a.sums_base = p.sums;
     return a;
 }
 
@@ -725,18 +747,18 @@ inline int xcd_grid(int tiles_x, int tiles_y, int waves_per_tile, int n_pairs) {
 // PX consecutive grid pixels x NR consecutive grid rows per lane; G lanes per window (G == 2: the partner is lane ^ XM).
 template <int WS> struct Map;
 template <> struct Map<32> {   // workgroup tile 32x32 = one window; wave = 8 rows
-    static constexpr int PX = 4, NR = 1, G = 64, XM = 1, TW = 32, TH = 32, WAVES = 4;
+    static constexpr int PX = 4, NR = 1, G = 64, XM = 1, TW = 32, TH = 32, WAVES = 4, RM = 8;   // RM: lane ^ RM = the same columns one grid row up / down
     __device__ static void at(int tid, int& x, int& y) { x = (tid & 7) * 4; y = tid >> 3; }
 };
 template <> struct Map<16> {   // wave = one 16x16 window; workgroup = 2x2 windows
-    static constexpr int PX = 4, NR = 1, G = 64, XM = 1, TW = 32, TH = 32, WAVES = 4;
+    static constexpr int PX = 4, NR = 1, G = 64, XM = 1, TW = 32, TH = 32, WAVES = 4, RM = 4;
     __device__ static void at(int tid, int& x, int& y) {
         const int w = tid >> 6, l = tid & 63;
         x = (w & 1) * 16 + (l & 3) * 4; y = (w >> 1) * 16 + (l >> 2);
     }
 };
 template <> struct Map<8> {    // 16 lanes = one 8x8 window; wave = 2x2 windows
-    static constexpr int PX = 4, NR = 1, G = 16, XM = 1, TW = 32, TH = 32, WAVES = 4;
+    static constexpr int PX = 4, NR = 1, G = 16, XM = 1, TW = 32, TH = 32, WAVES = 4, RM = 2;
     __device__ static void at(int tid, int& x, int& y) {
         const int w = tid >> 6, l = tid & 63, gi = l >> 4, i = l & 15;
         x = (w & 1) * 16 + (gi & 1) * 8 + (i & 1) * 4; y = (w >> 1) * 16 + (gi >> 1) * 8 + (i >> 1);
@@ -747,14 +769,14 @@ template <> struct Map<8> {    // 16 lanes = one 8x8 window; wave = 2x2 windows
 // constants, bias terms and argmin for half the pixels, plus a butterfly; the level-2 and level-4 launches were the two most expensive
 // of the chain.)
 template <> struct Map<4> {    // 2 lanes (l, l ^ 8) = one 4x4 window; wave = 8x4 windows = 32 px x 16 rows; a 32x32 tile is TWO waves
-    static constexpr int PX = 4, NR = 2, G = 2, XM = 8, TW = 32, TH = 32, WAVES = 2;
+    static constexpr int PX = 4, NR = 2, G = 2, XM = 8, TW = 32, TH = 32, WAVES = 2, RM = 0;
     __device__ static void at(int tid, int& x, int& y) {
         const int w = tid >> 6, l = tid & 63;
         x = (l & 7) * 4; y = w * 16 + (l >> 4) * 4 + ((l >> 3) & 1) * 2;
     }
 };
 template <> struct Map<2> {    // one lane = one 2x2 window; wave = 16x4 windows = 32 px x 8 rows; workgroup tile 32x32
-    static constexpr int PX = 2, NR = 2, G = 1, XM = 1, TW = 32, TH = 32, WAVES = 4;
+    static constexpr int PX = 2, NR = 2, G = 1, XM = 1, TW = 32, TH = 32, WAVES = 4, RM = 0;
     __device__ static void at(int tid, int& x, int& y) {
         const int w = tid >> 6, l = tid & 63;
         x = (l & 15) * 2; y = w * 8 + (l >> 4) * 2;
@@ -766,14 +788,14 @@ template <> struct Map<2> {    // one lane = one 2x2 window; wave = 16x4 windows
 // twice the waves finish sooner -- 8.7 / 7.8 us instead of 12.4 / 10.2 us for the level-2 / level-4 launch of one 480 x 270 pair.
 template <int WS> struct MapRow : Map<WS> {};
 template <> struct MapRow<4> {   // 4 lanes = one 4x4 window; wave = 4x4 windows
-    static constexpr int PX = 4, NR = 1, G = 4, XM = 1, TW = 32, TH = 32, WAVES = 4;
+    static constexpr int PX = 4, NR = 1, G = 4, XM = 1, TW = 32, TH = 32, WAVES = 4, RM = 1;
     __device__ static void at(int tid, int& x, int& y) {
         const int w = tid >> 6, l = tid & 63, gi = l >> 2;
         x = (w & 1) * 16 + (gi & 3) * 4; y = (w >> 1) * 16 + (gi >> 2) * 4 + (l & 3);
     }
 };
 template <> struct MapRow<2> {   // 2 lanes (l, l ^ 1) = one 2x2 window; wave = 8x4 windows; workgroup tile 16x32
-    static constexpr int PX = 2, NR = 1, G = 2, XM = 1, TW = 16, TH = 32, WAVES = 4;
+    static constexpr int PX = 2, NR = 1, G = 2, XM = 1, TW = 16, TH = 32, WAVES = 4, RM = 0;
     __device__ static void at(int tid, int& x, int& y) {
         const int w = tid >> 6, l = tid & 63, gi = l >> 1;
         x = (gi & 7) * 2; y = w * 8 + (gi >> 3) * 2 + (l & 1);
@@ -786,15 +808,18 @@ template <int WS> struct MapSel<WS, true> { using type = MapRow<WS>; };
 // SPLIT (windows <= 16, where a window never spans waves): the four waves of a tile are four one-wave workgroups
 // (TileId::wave).  A 480x270 grid has only 135 tiles for 256 CUs; split, every CU's L1 takes a share of the
 // candidate rows' cache lines (a Y step pulls ~16 x 8 row segments per wave, 32 useful bytes per 128-byte line).
-template <int WS, bool SPLIT, bool FULL, bool ROWS1>
+template <int WS, bool SPLIT, bool FULL, bool ROWS1, bool R16 = FULL>
 __device__ __forceinline__ void flow_level_small_body(const Geom& g, const FlowStep& a, const TileId& tile, uint32_t (*s_part)[4][16], [[maybe_unused]] uint32_t* s_rows) {
     using M = typename MapSel<WS, ROWS1>::type;
     constexpr int PX = M::PX, G = M::G;
-    const int R = FULL ? 16 : a.R;
+    const int R = R16 ? 16 : a.R;
     const int tid = SPLIT ? (int)(tile.wave * 64 + threadIdx.x) : (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;
     int lx, ly;
     M::at(tid, lx, ly);
     const int cx0 = tile.tx * M::TW + lx, cy = tile.ty * M::TH + ly;
+    if constexpr (!FULL && SPLIT) {      // a wave tile that lies outside the grid altogether (the lower half of a bottom tile): nothing to do, no window starts in it
+        if (__builtin_amdgcn_ballot_w64(cx0 < g.lw && cy < g.lh) == 0) return;
+    }
     const int wx = cx0 >> a.cur.log2w, wy = cy >> a.cur.log2w;
     const bool win_in = FULL || ((wx << a.cur.log2w) < g.lw && (wy << a.cur.log2w) < g.lh);   // whole lane group agrees
 
@@ -828,7 +853,7 @@ __device__ __forceinline__ void flow_level_small_body(const Geom& g, const FlowS
         }
         if (!from_lds) {
 #pragma unroll
-            for (int r = 0; r < M::NR; r++) strip_sads<PX, G == 64, FULL>(sad, g, a, strip[r], off[0], off[1], axis);
+            for (int r = 0; r < M::NR; r++) strip_sads<PX, G == 64, FULL, false, R16>(sad, g, a, strip[r], off[0], off[1], axis);
         }
         int first = group_reduce<G, M::XM>(sad, lane);
         if constexpr (WS == 32) {   // four waves share the window
@@ -836,7 +861,7 @@ __device__ __forceinline__ void flow_level_small_body(const Geom& g, const FlowS
             __syncthreads();
             sad[0] = s_part[axis][0][first] + s_part[axis][1][first] + s_part[axis][2][first] + s_part[axis][3][first];
         }
-        const int best = group_argmin<G, FULL, M::XM>(sad, first, a, off[axis], axis ? wc.nby : wc.nbx, wc.npix, cap_cz,
+        const int best = group_argmin<G, R16, M::XM>(sad, first, a, off[axis], axis ? wc.nby : wc.nbx, wc.npix, cap_cz,
                                                       axis == 0 && a.capture_delta, captured, lane);
         off[axis] = (int)(int16_t)(off[axis] + rel_offset(best, R));   // adjustOffsetArrayKernelSDR.h:13-19
     }
@@ -847,6 +872,280 @@ __device__ __forceinline__ void flow_level_small_body(const Geom& g, const FlowS
         a.cur.tx[wy * a.cur.nwx + wx] = (int16_t)off[0];
         a.cur.ty[wy * a.cur.nwx + wx] = (int16_t)off[1];
         if (a.capture_delta && wx == 0 && wy == 0) *a.total_delta = captured / a.delta_divisor;   // opticalFlowCalcSDR.cpp:91-94
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// SAD TABLES: exact reuse of candidate SADs across steps
+// ------------------------------------------------------------------------------------------
+// The reference recomputes every candidate SAD at every one of its 16 steps (opticalFlowCalcSDR.cpp:72-111, calcDeltaSumsKernelSDR.h:61-101).
+// But the per-pixel SAD of candidate cz depends only on the pixel, the axis and the window's (ox, oy) BEFORE the step -- the bias terms are
+// per-window constants (restructuring 2 above) -- so a window of step s samples exactly the positions step s - 2 sampled (same axis, parent
+// level) whenever the two steps in between, s - 2 and s - 1, both chose d = 0 for it:
+//     X step of level k:  X and Y of level k - 1 chose 0 for the parent window                (zx && zy)
+//     Y step of level k:  Y of level k - 1 chose 0 for the parent, X of level k for the window (zy && own X choice == 0)
+// (what a window chose is read off the level tables: parent's offset == grandparent's).  Once the global motion is found that is most
+// windows (bench scene: 74-96 % of the pixels at every step of levels 16 .. 2, tests/flow_reuse_model.py).  So every step that COMPUTES
+// candidate SADs leaves them per 2 x 2 grid block -- the finest window -- in a table per axis: 16 candidates x u16 (a block's SAD is at
+// most 4 x 765) = 32 bytes per block, 1.04 MB per pair and axis at 480 x 270; a window that may reuse sums its blocks' vectors -- 8 bytes per
+// pixel of coalesced reads instead of 64 bytes per pixel of gathers -- and leaves the entries as they are: they stay valid until somebody's
+// offsets change, and whoever's do recomputes and refreshes them.  Lane l of a window holds the vector of ONE block either way (computed:
+// its strip's two 2-pixel halves + the row partner's, transposed; reused: loaded), and ONE packed butterfly sums them: u16 pairs stay exact
+// up to 16 blocks (48,960), wider sums continue in 32 bits -- the same integers as the per-pixel order of the reference (sums of
+// non-negative terms, no wrap before the shift by deltaScalar; wrap-around of (sum << delta) + npix * bias as before).
+// Applies to tiles that lie fully inside the grid at the full search radius (the only ones whose SADs have a regular block form); the
+// first small level of a chain always computes.  HF_FLAG_NO_SAD_REUSE: no tables, every step computes (A-B, tests).
+
+// v[8]: candidates (2j, 2j + 1) of one block per lane as u16 pairs.  Sums them over the G lanes of a window; afterwards each lane owns
+// Owned<G>::n consecutive candidates starting at the returned index, totals in tot[].
+template <int G, int XM>
+__device__ __forceinline__ int packed_reduce(uint32_t* v, uint32_t* tot, int lane) {
+    if constexpr (G == 64) {
+        butterfly_level<8, 32>(v, lane); butterfly_level<4, 16>(v, lane); butterfly_level<2, 8>(v, lane);   // 8 blocks per half
+        const uint32_t w = v[0] + lane_xor<4>(v[0], lane);                                               // 16 blocks: <= 48,960
+        uint32_t t = (lane & 4) ? w >> 16 : w & 0xFFFFu;
+        t += lane_xor<2>(t, lane);
+        t += lane_xor<1>(t, lane);
+        tot[0] = t;
+        return ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+    } else if constexpr (G == 16) {
+        butterfly_level<8, 8>(v, lane); butterfly_level<4, 4>(v, lane); butterfly_level<2, 2>(v, lane);
+        const uint32_t w = v[0] + lane_xor<1>(v[0], lane);
+        tot[0] = (lane & 1) ? w >> 16 : w & 0xFFFFu;
+        return ((lane >> 3) & 1) * 8 + ((lane >> 2) & 1) * 4 + ((lane >> 1) & 1) * 2 + (lane & 1);
+    } else if constexpr (G == 4) {
+        butterfly_level<8, 2>(v, lane); butterfly_level<4, 1>(v, lane);
+        tot[0] = v[0] & 0xFFFFu; tot[1] = v[0] >> 16; tot[2] = v[1] & 0xFFFFu; tot[3] = v[1] >> 16;
+        return ((lane >> 1) & 1) * 8 + (lane & 1) * 4;
+    } else {
+        static_assert(G == 2, "windows of 64, 16, 4 or 2 lanes");
+        butterfly_level<8, XM>(v, lane);
+#pragma unroll
+        for (int j = 0; j < 4; j++) { tot[2 * j] = v[j] & 0xFFFFu; tot[2 * j + 1] = v[j] >> 16; }
+        return (lane & XM) ? 8 : 0;
+    }
+}
+
+__device__ __forceinline__ void unpack_u16x8(const flow_v4& q, uint32_t* o) {
+    o[0] = q.x & 0xFFFFu; o[1] = q.x >> 16; o[2] = q.y & 0xFFFFu; o[3] = q.y >> 16;
+    o[4] = q.z & 0xFFFFu; o[5] = q.z >> 16; o[6] = q.w & 0xFFFFu; o[7] = q.w >> 16;
+}
+
+// One level, X step then Y step, windows <= 32, of windows in tiles that lie fully inside the grid at R == 16, with the SAD tables.
+// A reusing window is a short chain of dependent memory rounds -- kernel arguments, then ONE round with everything whose address does not
+// depend on data: the window's constants, the grandparent's offsets and the table vectors of BOTH axes (whether they may be used is only
+// known later) -- and ~40 registers; a computing window keeps 16 candidates x 16 bytes in flight (100-170 registers) and several rounds.
+// Three forms of the same body:
+//   kFused  one launch per level: every lane decides per axis (batches of up to 4 pairs, where launches count, and the chain's first small
+//           level, which always computes);
+//   kLean   reuse only: 36-54 registers, 8 waves per SIMD, no computing code in the kernel at all (the computing path in the same kernel costs
+//           the reusing waves half their speed: occupancy and instruction cache).  Windows that cannot finish both steps from the tables
+//           append themselves to the launch's WORK LIST (entry: member, window, "X is done");
+//   kFresh  the work list, compacted: lane groups take windows from the list instead of from their position, compute what the entry still
+//           needs (the Y step may still reuse when the computed X step chose 0) and refresh the tables.
+enum { kFused = 0, kLean = 1, kFresh = 2 };
+// Work lists: the full tiles of a member form groups of kTilesPerGroup (consecutive in row-major order); every group has one list per
+// level -- dense enough that the compacted launch runs full waves (a tile of level 2 alone lists ~67 of its 256 windows on the bench scene: one
+// full wave and one nearly empty one), few enough writers per counter that the lean launch's atomics do not queue up (one per wave: 64 per
+// counter and launch; a single counter per member took 540 and doubled the launch's time).
+//   work[(slot * groups + group) * 64]                     entry counter of the level with that slot, one per 256-byte line (the atomics of a launch
+//                                                          spread over the L2 channels); zeroed by the chain's first small level
+//   work[16 * groups * 64 + group * kGroupCapacity + i]    entry i:  xdone << 31 | wy << 13 | wx   (window coordinates at the level)
+constexpr int kTilesPerGroup = 16, kGroupCapacity = kTilesPerGroup * 256, kCounterStride = 64;
+constexpr int kFreshPassDivider = 4;     // the compacted launch starts capacity / 4 passes per group: every listed window in one round up to 25 %
+__device__ __forceinline__ uint32_t work_entry(int wx, int wy, bool xdone) {
+    return (xdone ? 0x80000000u : 0u) | ((uint32_t)wy << 13) | (uint32_t)wx;
+}
+// the lanes with `want` append their entry; one atomic per wave
+__device__ __forceinline__ void work_push(uint32_t* counter, uint32_t* entries, bool want, uint32_t entry) {
+    const uint64_t m = __builtin_amdgcn_ballot_w64(want);
+    if (m == 0) return;
+    uint32_t base = 0;
+    const int first_lane = __builtin_ctzll(m);
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    if (lane == first_lane) base = atomicAdd(counter, (uint32_t)__builtin_popcountll(m));
+    base = __builtin_amdgcn_readlane(base, first_lane);
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    HF_DBG_CHECK(!want || base + rank < (uint32_t)kGroupCapacity, 112);
+    if (want) entries[base + rank] = entry;
+}
+
+// (cx0, cy): first grid pixel of the lane; (lx, ly): its position inside the tile (kFused: WS == 32 needs the tile origin); group: the tile's
+// work list (kLean); xdone (kFresh): the lean launch already took this window's X step, its result is in the level table.
+template <int WS, bool SPLIT, bool ROWS1, int MODE>
+__device__ __forceinline__ void flow_level_tab_body(const Geom& g, const FlowStep& a, int cx0, int cy, int lx, int ly, int tid, int group, bool xdone,
+                                                    const TileId* tile, uint32_t (*s_part)[4][16], [[maybe_unused]] uint32_t* s_rows) {
+    using M = typename MapSel<WS, ROWS1>::type;
+    constexpr int PX = M::PX, G = M::G, NR = M::NR, NOWN = Owned<G>::n;
+    constexpr int NV = (PX == 4 && NR == 2) ? 4 : (PX == 2 && NR == 1) ? 1 : 2;     // 16-byte vectors of a lane per axis
+    static_assert(MODE == kFused || (WS < 32 && !ROWS1), "lean / compacted launches: windows of 16 and less, block mappings");
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wx = cx0 >> a.cur.log2w, wy = cy >> a.cur.log2w;
+
+    WinConst wc = load_win_const(g, a, wx, wy, false);
+    // the lane's block(s) of the tables: 4 x 1 strips pair up with the row partner (even rows keep the left block, odd rows the right one);
+    // the two lanes of a MapRow<2> window take half a block each
+    const int nblk = a.sad_nbx * a.sad_nby;
+    const int blk = (cy >> 1) * a.sad_nbx + (cx0 >> 1) + ((PX == 4 && NR == 1) ? (cy & 1) : 0);
+    HF_DBG_CHECK(blk >= 0 && blk + (PX == 4 && NR == 2 ? 1 : 0) < nblk, 110);
+    flow_v4* const tab0 = (flow_v4*)a.sadtab + (size_t)blk * 2 + ((PX == 2 && NR == 1 && (lane & M::XM)) ? 1 : 0);
+    const size_t tab_axis = (size_t)nblk * 2;
+    // what the parent window chose at the previous level: its offsets against its own parent's
+    bool zx = false, zy = false;
+    flow_v4 pre[2][NV];
+    int done_x = 0;
+    if (WS < 32 && a.sad_read) {
+        int gx = 0, gy = 0;
+        if (a.prev2.tx) {
+            gx = table_at(a.prev2.tx, a.prev2, wx << a.cur.log2w, wy << a.cur.log2w);
+            gy = table_at(a.prev2.ty, a.prev2, wx << a.cur.log2w, wy << a.cur.log2w);
+        }
+        if constexpr (MODE == kFresh) done_x = a.cur.tx[wy * a.cur.nwx + wx];      // (only meaningful with xdone)
+#pragma unroll
+        for (int ax = 0; ax < 2; ax++)
+#pragma unroll
+            for (int v = 0; v < NV; v++) pre[ax][v] = tab0[ax * tab_axis + v];
+        zx = wc.ox == gx; zy = wc.oy == gy;
+    }
+    if constexpr (MODE == kFused) {
+        if (a.pend.active) {   // the last large-window step (Y of the previous level) is resolved here
+            const int tx0 = tile->tx * M::TW, ty0 = tile->ty * M::TH;
+            const bool leader = tid == 0 && (tx0 & (a.pend.lvl.window - 1)) == 0 && (ty0 & (a.pend.lvl.window - 1)) == 0;
+            const int v = resolve_pending(g, a, tx0, ty0, lane, leader);
+            if (a.pend.axis) wc.oy = v; else wc.ox = v;
+        }
+    }
+    const int cap_cz = 7;
+    uint32_t captured = 0;
+    int off[2] = {wc.ox, wc.oy};
+    bool lean_x = false, lean_y = false;    // kLean: the step was taken from the tables
+
+#pragma unroll
+    for (int axis = 0; axis < 2; axis++) {
+        bool reuse = zy && (axis == 0 ? zx : off[0] == wc.ox);
+        if constexpr (MODE == kLean) {
+            if (axis == 0) lean_x = reuse; else lean_y = reuse = reuse && lean_x;
+            reuse = true;                     // (lanes that may not reuse run along on whatever the tables hold; their result is dropped)
+        }
+        if constexpr (MODE == kFresh) {
+            if (axis == 0) reuse = xdone;     // the lean launch took the X step: pass through (its result replaces this one below)
+        }
+        if constexpr (G == 64) reuse = __builtin_amdgcn_readfirstlane((int)reuse) != 0;      // one window per wave
+        flow_v4* const tab = tab0 + axis * tab_axis;
+        uint32_t tot[NOWN];
+        int first = 0;
+        if constexpr (PX == 4 && NR == 1) {
+            uint32_t W[8];
+            if (MODE != kLean && !reuse) {
+                Strip<PX> strip[NR];          // frame-N samples of the lane: only windows that compute read them
+#pragma unroll
+                for (int r = 0; r < NR; r++) strip[r] = load_strip<PX, true>(g, a, cx0, cy + r);
+                uint32_t p[16];
+#pragma unroll
+                for (int cz = 0; cz < 16; cz++) p[cz] = 0u;
+                bool from_lds = false;
+                if constexpr (WS == 16 && SPLIT) {
+                    if (axis == 1) from_lds = ysads_tile_try<16, 4, 1, true>(p, g, a, strip[0].ref, off[0], off[1], cx0, cy, lane, s_rows);
+                } else if constexpr (WS == 8 && SPLIT) {
+                    if (axis == 1) from_lds = ysads_win8_try<true>(p, g, a, strip[0].ref, off[0], off[1], cx0, cy, lane, s_rows);
+                } else if constexpr (WS == 32) {
+                    if (axis == 1) from_lds = ysads_tile_try<32, 8, 4, true>(p, g, a, strip[0].ref, off[0], off[1], cx0 - lx, cy - ly, tid, s_rows);
+                }
+                if (!from_lds) strip_sads<4, G == 64, true, true>(p, g, a, strip[0], off[0], off[1], axis);
+                const uint32_t selw = (cy & 1) ? 0x07060302u : 0x05040100u;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const uint32_t q0 = p[2 * j] + lane_xor<M::RM>(p[2 * j], lane);               // both rows of the two blocks: left | right << 16
+                    const uint32_t q1 = p[2 * j + 1] + lane_xor<M::RM>(p[2 * j + 1], lane);
+                    W[j] = __builtin_amdgcn_perm(q1, q0, selw);                                  // this lane's block: candidates 2j, 2j + 1
+                }
+                if (a.sad_write) { tab[0] = flow_v4{W[0], W[1], W[2], W[3]}; tab[1] = flow_v4{W[4], W[5], W[6], W[7]}; }
+            } else {
+                const flow_v4 lo = pre[axis][0], hi = pre[axis][1];
+                W[0] = lo.x; W[1] = lo.y; W[2] = lo.z; W[3] = lo.w; W[4] = hi.x; W[5] = hi.y; W[6] = hi.z; W[7] = hi.w;
+            }
+            first = packed_reduce<G, M::XM>(W, tot, lane);
+        } else if constexpr (PX == 4) {      // Map<4>: a 4 x 2 block pair per lane
+            uint32_t V[8];
+            if (MODE != kLean && !reuse) {
+                Strip<PX> strip[NR];          // frame-N samples of the lane: only windows that compute read them
+#pragma unroll
+                for (int r = 0; r < NR; r++) strip[r] = load_strip<PX, true>(g, a, cx0, cy + r);
+                uint32_t p[16];
+#pragma unroll
+                for (int cz = 0; cz < 16; cz++) p[cz] = 0u;
+#pragma unroll
+                for (int r = 0; r < NR; r++) strip_sads<4, false, true, true>(p, g, a, strip[r], off[0], off[1], axis);
+                uint32_t W0[8], W1[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    W0[j] = __builtin_amdgcn_perm(p[2 * j + 1], p[2 * j], 0x05040100u);
+                    W1[j] = __builtin_amdgcn_perm(p[2 * j + 1], p[2 * j], 0x07060302u);
+                    V[j] = W0[j] + W1[j];
+                }
+                if (a.sad_write) {
+                    tab[0] = flow_v4{W0[0], W0[1], W0[2], W0[3]}; tab[1] = flow_v4{W0[4], W0[5], W0[6], W0[7]};
+                    tab[2] = flow_v4{W1[0], W1[1], W1[2], W1[3]}; tab[3] = flow_v4{W1[4], W1[5], W1[6], W1[7]};
+                }
+            } else {
+                const flow_v4 a0 = pre[axis][0], a1 = pre[axis][1], b0 = pre[axis][2 % NV], b1 = pre[axis][3 % NV];
+                V[0] = a0.x + b0.x; V[1] = a0.y + b0.y; V[2] = a0.z + b0.z; V[3] = a0.w + b0.w;
+                V[4] = a1.x + b1.x; V[5] = a1.y + b1.y; V[6] = a1.z + b1.z; V[7] = a1.w + b1.w;
+            }
+            first = packed_reduce<G, M::XM>(V, tot, lane);
+        } else if constexpr (NR == 2) {      // Map<2>: the lane IS a block
+            if (MODE != kLean && !reuse) {
+                Strip<PX> strip[NR];          // frame-N samples of the lane: only windows that compute read them
+#pragma unroll
+                for (int r = 0; r < NR; r++) strip[r] = load_strip<PX, true>(g, a, cx0, cy + r);
+#pragma unroll
+                for (int cz = 0; cz < 16; cz++) tot[cz] = 0u;
+#pragma unroll
+                for (int r = 0; r < NR; r++) strip_sads<PX, false, true>(tot, g, a, strip[r], off[0], off[1], axis);
+            } else {
+                unpack_u16x8(pre[axis][0], tot); unpack_u16x8(pre[axis][1 % NV], tot + 8);
+            }
+        } else {                             // MapRow<2>: two lanes, a row each
+            if (MODE != kLean && !reuse) {
+                Strip<PX> strip[NR];          // frame-N samples of the lane: only windows that compute read them
+#pragma unroll
+                for (int r = 0; r < NR; r++) strip[r] = load_strip<PX, true>(g, a, cx0, cy + r);
+                uint32_t sad[16];
+#pragma unroll
+                for (int cz = 0; cz < 16; cz++) sad[cz] = 0u;
+                strip_sads<PX, false, true>(sad, g, a, strip[0], off[0], off[1], axis);
+                butterfly_level<16, M::XM>(sad, lane);
+#pragma unroll
+                for (int k = 0; k < 8; k++) tot[k] = sad[k];
+            } else {
+                unpack_u16x8(pre[axis][0], tot);
+            }
+            first = (lane & M::XM) ? 8 : 0;
+        }
+        if constexpr (WS == 32) {   // four waves share the window
+            if ((lane & 3) == 0) s_part[axis][wave][first] = tot[0];
+            __syncthreads();
+            tot[0] = s_part[axis][0][first] + s_part[axis][1][first] + s_part[axis][2][first] + s_part[axis][3][first];
+        }
+        const int best = group_argmin<G, true, M::XM>(tot, first, a, off[axis], axis ? wc.nby : wc.nbx, wc.npix, cap_cz,
+                                                      MODE == kFused && axis == 0 && a.capture_delta, captured, lane);
+        off[axis] = (int)(int16_t)(off[axis] + rel_offset(best, 16));   // adjustOffsetArrayKernelSDR.h:13-19
+        if constexpr (MODE == kFresh) {
+            if (axis == 0 && xdone) off[0] = done_x;
+        }
+    }
+
+    const bool leader = WS == 32 ? tid == 0 : G == 2 ? (lane & M::XM) == 0 : (lane & (G - 1)) == 0;
+    HF_DBG_CHECK(wx >= 0 && wy >= 0 && wx < a.cur.nwx && wy < a.cur.nwy, 105);
+    if constexpr (MODE == kLean) {
+        if (leader && lean_x) a.cur.tx[wy * a.cur.nwx + wx] = (int16_t)off[0];
+        if (leader && lean_y) a.cur.ty[wy * a.cur.nwx + wx] = (int16_t)off[1];
+        work_push(a.work + (a.work_slot * a.work_groups + group) * kCounterStride, a.work + 16 * a.work_groups * kCounterStride + (size_t)group * kGroupCapacity, leader && !lean_y,
+                  work_entry(wx, wy, lean_x));
+    } else if (leader) {
+        a.cur.tx[wy * a.cur.nwx + wx] = (int16_t)off[0];
+        a.cur.ty[wy * a.cur.nwx + wx] = (int16_t)off[1];
+        if (MODE == kFused && a.capture_delta && wx == 0 && wy == 0) *a.total_delta = captured / a.delta_divisor;   // opticalFlowCalcSDR.cpp:91-94
     }
 }
 
@@ -865,16 +1164,93 @@ __global__ __launch_bounds__(SPLIT ? 64 : 256) void flow_level_small_kernel(cons
     //  the one-row levels and the partial kernel at 72 -- 8 candidates in flight -- lets a chain wave fit beside the period warp's five waves
     //  per SIMD: inside the pipeline the warp launch then got 11 % shorter and the chain 39 % longer, the same frames/s; DESIGN.md appendix D.)
     const bool full = a.R == 16 && (tile.tx + 1) * M::TW <= g.lw && (tile.ty + 1) * M::TH <= g.lh;
-    if (full) flow_level_small_body<WS, SPLIT, true, ROWS1>(g, a, tile, s_part, s_rows);
+    // SAD tables: tiles whose 32 x 32 tile lies inside the grid (the 16-wide tiles of MapRow<2> answer for the tile around them: its
+    // entries are what the previous level left)
+#ifdef HF_EXP_NO_TAB
+    const bool tab = false;
+#else
+    const bool tab = full && a.sadtab && (a.sad_read || a.sad_write) && (M::TW == 32 || ((tile.tx * M::TW) | 31) < g.lw);
+#endif
+    if (a.work && !a.sad_read && tile.tx == 0 && tile.ty == 0 && tile.wave == 0)   // the chain's first small level: empty work lists for the lean launches behind it
+        for (int i = (int)threadIdx.x; i < 16 * a.work_groups; i += (int)blockDim.x) a.work[i * kCounterStride] = 0u;
+    if (tab) {
+        const int tid = SPLIT ? (int)(tile.wave * 64 + threadIdx.x) : (int)threadIdx.x;
+        int lx, ly;
+        M::at(tid, lx, ly);
+        flow_level_tab_body<WS, SPLIT, ROWS1, kFused>(g, a, tile.tx * M::TW + lx, tile.ty * M::TH + ly, lx, ly, tid, tile.pair, false, &tile, s_part, s_rows);
+    }
+    else if (full) flow_level_small_body<WS, SPLIT, true, ROWS1>(g, a, tile, s_part, s_rows);
+    else if (a.R == 16) flow_level_small_body<WS, SPLIT, false, ROWS1, true>(g, a, tile, s_part, s_rows);
     else flow_level_small_body<WS, SPLIT, false, ROWS1>(g, a, tile, s_part, s_rows);
+}
+
+// The lean launch of a level (kLean above): the full tiles only, a one-wave workgroup per wave tile.
+template <int WS>
+__global__ __launch_bounds__(64) void flow_level_lean_kernel(const Geom g, const FlowBatchArgs batch) {
+    using M = Map<WS>;
+    const TileId tile = decode_tile<M::WAVES>(batch, g.lw / 32, g.lh / 32);
+    if (!tile.valid) return;
+    const FlowStep a = member_step(batch, tile.pair);
+    const int tid = (int)(tile.wave * 64 + threadIdx.x);
+    int lx, ly;
+    M::at(tid, lx, ly);
+    flow_level_tab_body<WS, true, false, kLean>(g, a, tile.tx * 32 + lx, tile.ty * 32 + ly, lx, ly, tid, (tile.ty * (g.lw / 32) + tile.tx) / kTilesPerGroup, false,
+                                                nullptr, nullptr, nullptr);
+}
+
+// The compacted launch of a level (kFresh above).  One-wave workgroups: first one per wave tile of the tiles that hang over the grid's
+// edge (generic body), then one per (member, tile group, pass) -- pass p takes entries [p, p + 1) * (64 / G) of the group's list and leaves at
+// once when the list is shorter.
+template <int WS>
+__global__ __launch_bounds__(64) void flow_level_fresh_kernel(const Geom g, const FlowBatchArgs batch) {
+    using M = Map<WS>;
+    constexpr int G = M::G, WPW = 64 / G, PPG = kTilesPerGroup * M::WAVES;     // windows per pass, passes per group (its capacity at this level)
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_rows[];
+    const int groups = batch.common.work_groups;
+    constexpr int LP = PPG / kFreshPassDivider;              // launched passes per group; lists longer than a quarter of the capacity loop
+    const int tiles_x = (g.lw + 31) / 32, tiles_y = (g.lh + 31) / 32, full_x = g.lw / 32, full_y = g.lh / 32;
+    const int n_bottom = tiles_x * (tiles_y - full_y), n_partial = n_bottom + (tiles_x - full_x) * full_y;
+    const int n_edge = n_partial * M::WAVES * batch.n;       // the partial tiles go first: they are the launch's longest waves
+    if ((int)blockIdx.x < n_edge) {                          // bottom tile rows, then the right tile columns of the full rows
+        __shared__ uint32_t s_part[1][4][16];
+        const int u = (int)blockIdx.x;
+        const int v = u / M::WAVES, pair = v / n_partial, j = v - pair * n_partial;
+        const int q = j - n_bottom, w = max(tiles_x - full_x, 1);
+        const TileId t{pair, j < n_bottom ? j % tiles_x : full_x + q % w, j < n_bottom ? full_y + j / tiles_x : q / w, u % M::WAVES, true};
+        const FlowStep a = member_step(batch, t.pair);
+        flow_level_small_body<WS, true, false, false, true>(g, a, t, s_part, s_rows);    // (this launch only exists at R == 16)
+        return;
+    }
+    const int lb = (int)blockIdx.x - n_edge;
+    const int pass0 = lb % LP, v = lb / LP, group = v % groups, member = v / groups;
+    if (member >= batch.n) return;
+    const FlowStep a = member_step(batch, member);
+    const uint32_t count = a.work[(a.work_slot * groups + group) * kCounterStride];
+    if ((uint32_t)(pass0 * WPW) >= count) return;
+    const int lane = (int)threadIdx.x;
+    // the lane's window of the pass and its place inside that window (the lane maps of Map<WS> with the window as the tile)
+    int wi, px, py;
+    if constexpr (WS == 16) { wi = 0; px = (lane & 3) * 4; py = lane >> 2; }
+    else if constexpr (WS == 8) { wi = lane >> 4; px = (lane & 1) * 4; py = (lane & 15) >> 1; }
+    else if constexpr (WS == 4) { wi = (lane >> 4) * 8 + (lane & 7); px = 0; py = ((lane >> 3) & 1) * 2; }
+    else { wi = lane; px = 0; py = 0; }
+    for (int pass = pass0; (uint32_t)(pass * WPW) < count; pass += LP) {
+        const uint32_t e = (uint32_t)(pass * WPW + wi);
+        if (e < count) {                                     // (whole windows: the lanes of a window share e)
+            const uint32_t entry = a.work[16 * groups * kCounterStride + (size_t)group * kGroupCapacity + e];
+            const int wx = (int)(entry & 0x1FFFu), wy = (int)((entry >> 13) & 0x1FFFu);
+            HF_DBG_CHECK(wx < a.cur.nwx && wy < a.cur.nwy, 111);
+            flow_level_tab_body<WS, true, false, kFresh>(g, a, wx * WS + px, wy * WS + py, px, py, lane, group, (entry >> 31) != 0, nullptr, nullptr, s_rows);
+        }
+    }
 }
 
 // Windows > 32, one axis: raw SAD sums of a 32 x (8 * WPB) tile -> one atomic per candidate.
 // WPB = waves per workgroup.  Fewer waves per workgroup = more workgroups for the 256 CUs (a 480x270 grid has 135
 // 32x32 tiles) at the price of more atomics on the same R addresses of each window.
-template <int WPB, bool FULL>
+template <int WPB, bool FULL, bool R16 = FULL>
 __device__ __forceinline__ void flow_big_partial_body(const Geom& g, const FlowStep& a, const TileId& tile, uint32_t (*s_part)[16], [[maybe_unused]] uint32_t* s_rows) {
-    const int R = FULL ? 16 : a.R;
+    const int R = R16 ? 16 : a.R;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // wave = 64 grid pixels x 4 rows: the 16 lanes the texture addresser handles together read 256 contiguous bytes of ONE
     // phase row (a 16-lane group that spans several rows costs one L1 tag lookup per row and 64-byte block)
@@ -900,7 +1276,7 @@ __device__ __forceinline__ void flow_big_partial_body(const Geom& g, const FlowS
     for (int cz = 0; cz < 16; cz++) sad[cz] = 0u;
     bool from_lds = false;
     if constexpr (FULL && WPB == 4) if (a.axis == 1) from_lds = ysads_tile_try<16, 16, 4>(sad, g, a, strip.ref, ox, oy, tx0, ty0, tid, s_rows);
-    if (!from_lds) strip_sads<4, true, FULL>(sad, g, a, strip, ox, oy, a.axis);
+    if (!from_lds) strip_sads<4, true, FULL, false, R16>(sad, g, a, strip, ox, oy, a.axis);
     const int first = group_reduce<64>(sad, lane);
     HF_DBG_CHECK(wx >= 0 && wy >= 0 && wx < a.cur.nwx && wy < a.cur.nwy, 106);
     uint32_t* dst = &a.sums[(wy * a.cur.nwx + wx) * 16];
@@ -927,6 +1303,7 @@ __global__ __launch_bounds__(64 * WPB) void flow_big_partial_kernel(const Geom g
     extern __shared__ __attribute__((aligned(16))) uint32_t s_rows[];   // Y launches: candidate rows (launch_flow_big_partial)
     const bool full = a.R == 16 && (tile.tx + 1) * 64 <= g.lw && (tile.ty + 1) * (4 * WPB) <= g.lh;   // see flow_level_small_kernel
     if (full) flow_big_partial_body<WPB, true>(g, a, tile, s_part, s_rows);
+    else if (a.R == 16) flow_big_partial_body<WPB, false, true>(g, a, tile, s_part, s_rows);
     else flow_big_partial_body<WPB, false>(g, a, tile, s_part, s_rows);
 }
 
@@ -1043,6 +1420,9 @@ void launch_prep_frame(const Geom& g, const PhaseLayout& pl, const void* frame, 
 // Batches up to this size run the two finest levels with one row per lane (MapRow).  Chain alone, us per batched chain with a block /
 // a row per lane: 1 pair 79.5 / 71.3, 2 pairs 94.6 / 86.8, 4 pairs 122.4 / 119.2, 8 pairs 169.3 / 173.8.
 constexpr int kRowPerLaneMaxBatch = 4;
+#ifndef HF_EXP_SPLIT_MIN_BATCH
+#define HF_EXP_SPLIT_MIN_BATCH 99
+#endif
 void launch_flow_level_small(const Geom& g, const FlowBatch& b, hipStream_t stream) {
     const int ws = b.s[0].cur.window;
     const bool rows1 = b.n <= kRowPerLaneMaxBatch && ws <= 4;
@@ -1051,6 +1431,27 @@ void launch_flow_level_small(const Geom& g, const FlowBatch& b, hipStream_t stre
     const FlowBatchArgs kb = pack_batch(b, tiles_x, tiles_y);
     // dynamic LDS: the candidate rows of the Y step (full tiles only exist at the full search radius)
     const size_t lds = b.s[0].R != 16 ? 0 : ws == 32 ? ystage_bytes<32, 8, 4>(g.rs) : ws == 16 ? ystage_bytes<16, 4, 1>(g.rs) : ws == 8 ? win8_stage_bytes(g.rs) : 0;
+    // Batches of more than 4 pairs behind a level that left SAD tables: a LEAN launch that only reuses (full tiles; windows that cannot
+    // finish from the tables go to their member's work list) and a COMPACTED launch that computes the listed windows and the partial tiles.
+    const int full_x = g.lw / 32, full_y = g.lh / 32;
+    if (b.n >= HF_EXP_SPLIT_MIN_BATCH && ws <= 16 && b.s[0].sad_read && b.s[0].sadtab && b.s[0].work && b.s[0].R == 16 && full_x > 0 && full_y > 0 &&
+        b.s[0].work_groups == (full_x * full_y + kTilesPerGroup - 1) / kTilesPerGroup && g.lw < (1 << 14) && g.lh < (1 << 14)) {
+        const FlowBatchArgs kl = pack_batch(b, full_x, full_y);
+        const int n_partial = tiles_x * tiles_y - full_x * full_y;
+        const int waves = ws == 4 ? Map<4>::WAVES : 4;
+        const dim3 lgrd(xcd_grid(full_x, full_y, waves, b.n)), fgrd(b.n * b.s[0].work_groups * (kTilesPerGroup * waves / kFreshPassDivider) + n_partial * waves * b.n);
+        switch (ws) {
+            case 16: HF_LAUNCH("level_16_reuse", (flow_level_lean_kernel<16>), lgrd, dim3(64), 0, stream, g, kl);
+                     HF_LAUNCH("level_16_compute", (flow_level_fresh_kernel<16>), fgrd, dim3(64), lds, stream, g, kl); break;
+            case 8:  HF_LAUNCH("level_8_reuse", (flow_level_lean_kernel<8>), lgrd, dim3(64), 0, stream, g, kl);
+                     HF_LAUNCH("level_8_compute", (flow_level_fresh_kernel<8>), fgrd, dim3(64), lds, stream, g, kl); break;
+            case 4:  HF_LAUNCH("level_4_reuse", (flow_level_lean_kernel<4>), lgrd, dim3(64), 0, stream, g, kl);
+                     HF_LAUNCH("level_4_compute", (flow_level_fresh_kernel<4>), fgrd, dim3(64), lds, stream, g, kl); break;
+            default: HF_LAUNCH("level_2_reuse", (flow_level_lean_kernel<2>), lgrd, dim3(64), 0, stream, g, kl);
+                     HF_LAUNCH("level_2_compute", (flow_level_fresh_kernel<2>), fgrd, dim3(64), lds, stream, g, kl); break;
+        }
+        return;
+    }
     // windows <= 16 never span waves: one-wave workgroups (SPLIT), see flow_level_small_kernel
     const dim3 grd(xcd_grid(tiles_x, tiles_y, 1, b.n));
     auto split = [&](int waves) { return dim3(xcd_grid(tiles_x, tiles_y, waves, b.n)); };

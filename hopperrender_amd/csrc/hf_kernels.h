@@ -142,6 +142,19 @@ struct FlowStep {
     int capture_delta;       // first step of the chain: emit m_totalFrameDelta
     uint32_t delta_divisor;  // lh*lw*10 (SDR) / lh*lw*6 (HDR)
     PendingArgmin pend;      // previous large-window step still to be resolved (see above)
+    // ---- SAD tables: exact reuse of candidate SADs across steps (hf_flow.hip "SAD TABLES") ----
+    FlowLevel prev2;         // the level before `prev` (tx == nullptr: none, all zero): prev - prev2 = what the parent window chose
+    uint32_t* sadtab;        // [2 axes][sad_nby][sad_nbx][8]: the 16 candidate SADs (u16 pairs) of every 2x2 grid block as the last step
+                             // of that axis that computed them left them; nullptr: reuse off (HF_FLAG_NO_SAD_REUSE)
+    int sad_nbx, sad_nby;
+    int sad_read;            // the previous level's launch left valid tables for every full tile (this is not the chain's first small level)
+    int sad_write;           // this launch refreshes them where it computes (windows 32 .. 4)
+    uint32_t* work;          // work list of the lean / compacted launches (one per batch): counters + entries, nullptr: one fused launch per level
+    int work_slot;           // this level's counters
+    int work_groups;         // tile groups of the work lists = ceil(full tiles / 16) (layout: hf_flow.hip "Work lists")
+    // allocation bases of the per-level tables and of the window sums: a batched launch carries member 0's FlowStep and rebases it
+    int16_t* tables_base;
+    uint32_t* sums_base;
 };
 
 // The refinement chains of up to kMaxFlowBatch independent frame pairs of the SAME geometry and parameters run as

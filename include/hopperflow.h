@@ -67,6 +67,8 @@ typedef enum hf_output_mode {
 #define HF_FLAG_BATCH_EAGER_PLANES 0x1000 /* on the leader passed to hf_batch_create: hf_batch_run_period builds every phase plane in
                                               full when its frame arrives (default for large frames: grid samples only, the full
                                               plane comes out of the next period's warp launch -- see hf_batch_run_period) */
+#define HF_FLAG_NO_SAD_REUSE 0x2000 /* flow chain: recompute every candidate SAD at every step, as the reference does, instead of summing the per-block SAD
+                                     * tables of the last step that sampled the same positions (same results; debug / A-B timing) */
 #define HF_FLAG_NO_TIMING 0x200 /* do not record the events behind m_ofcCalcTime / m_warpCalcTime (hf_stats times stay 0).
                                    Every timing event is a barrier packet on the stream: measured 5-6 us each between
                                    back-to-back kernels, ~15 us per source period in a throughput pipeline */
