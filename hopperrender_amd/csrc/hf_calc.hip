@@ -33,7 +33,7 @@ int enqueue_flow_chain(hf_ctx* const* cs, int n, hipStream_t s) {
         f.delta_scalar = c->p.delta_scalar;
         f.neighbor_scalar = c->p.neighbor_scalar;
         f.delta_divisor = (uint32_t)(g.lh * g.lw * (g.hdr ? 6 : 10));  // :93 / HDR :93
-        f.sadtab = m->sadtab; f.sad_nbx = m->sad_nbx; f.sad_nby = m->sad_nby; f.work = m->work; f.work_groups = m->work_groups;
+        f.sadtab = m->sadtab; f.sad_nbx = m->sad_nbx; f.sad_nby = m->sad_nby;
         f.tables_base = m->tables; f.sums_base = m->sums;
     }
     hf::FlowLevel none{};
@@ -65,7 +65,6 @@ int enqueue_flow_chain(hf_ctx* const* cs, int n, hipStream_t s) {
                 f.prev2 = k > 1 ? m->levels[k - 2] : none;
                 // SAD tables: written by every small level that has a successor's worth of blocks (windows 32 .. 4), read by every small
                 // level behind a small level
-                f.work_slot = k & 15;
                 f.sad_write = m->sadtab && small && m->levels[k].window >= 4;
                 f.sad_read = m->sadtab && small && k > 0 && m->levels[k - 1].window <= 32;
                 f.use_neighbors = use_neighbors;

@@ -235,8 +235,6 @@ int hf_create(const hf_config* cfg, hf_ctx** out_ctx) {
     // SAD tables of the chain (hf_flow.hip): 16 candidates x u16 per 2x2 grid block and axis
     c->sad_nbx = (g.lw + 1) / 2; c->sad_nby = (g.lh + 1) / 2;
     c->sadtab_bytes = (cfg->flags & HF_FLAG_NO_SAD_REUSE) ? 0 : 2 * (size_t)c->sad_nbx * c->sad_nby * 32;
-    c->work_groups = ((g.lw / 32) * (g.lh / 32) + 15) / 16;                                       // groups of 16 full tiles, 4,096 entries each
-    c->work_bytes = c->sadtab_bytes && c->work_groups ? (size_t)c->work_groups * (16 * 64 + 4096) * sizeof(uint32_t) : 0;   // counters on 256-byte lines
     int rc = HF_OK;
     auto bail = [&](int code) { std::string e = c->err; hf_destroy(c); g_create_error = e; return code; };
     {   // detectDevices (opticalFlowCalc.cpp:45-109): the device must offer the memory, LDS and workgroup size the calculator
@@ -244,7 +242,7 @@ int hf_create(const hf_config* cfg, hf_ctx** out_ctx) {
         // memory and takes the FIRST device that qualifies; this build keeps 3 frames + 3 phase planes + 1 output frame + small
         // tables, priced exactly, and additionally requires that much memory to be FREE on the device it settles on.
         // device_index >= 0 pins the ordinal (one process per GPU); -1 scans like the reference.
-        const uint64_t required = 3 * c->in_bytes + 3 * c->pl.bytes + c->out_bytes + c->tables_bytes + c->sums_bytes + c->sadtab_bytes + c->work_bytes +
+        const uint64_t required = 3 * c->in_bytes + 3 * c->pl.bytes + c->out_bytes + c->tables_bytes + c->sums_bytes + c->sadtab_bytes +
                                   2 * c->plane_elems * sizeof(int16_t) * 3 + 2 * c->plane_elems * sizeof(uint32_t);
         std::vector<hf_device_caps> caps((size_t)ndev);
         for (int d = 0; d < ndev; d++) {
@@ -314,10 +312,6 @@ int hf_create(const hf_config* cfg, hf_ctx** out_ctx) {
         HF_TRY(hipMemsetAsync(c->blurred_xy[i], 0, c->plane_elems * sizeof(uint32_t), c->stream));
     }
     if (c->sadtab_bytes) HF_TRY(hipMalloc((void**)&c->sadtab, c->sadtab_bytes));   // (every entry is written before it is read inside a chain)
-    if (c->work_bytes) {
-        HF_TRY(hipMalloc((void**)&c->work, c->work_bytes));
-        HF_TRY(hipMemsetAsync(c->work, 0, c->work_bytes, c->stream));
-    }
     HF_TRY(hipMalloc((void**)&c->sums, c->sums_bytes));
     HF_TRY(hipMemsetAsync(c->sums, 0, c->sums_bytes, c->stream));
     HF_TRY(hipMalloc((void**)&c->d_probe, 64 * sizeof(float)));
@@ -350,7 +344,6 @@ void hf_destroy(hf_ctx* c) {
     for (int i = 0; i < 2; i++) { if (c->blurred[i]) hipFree(c->blurred[i]); if (c->blurred_xy[i]) hipFree(c->blurred_xy[i]); }
     if (c->sums) hipFree(c->sums);
     if (c->sadtab) hipFree(c->sadtab);
-    if (c->work) hipFree(c->work);
     if (c->d_probe) hipFree(c->d_probe);
     if (c->h_total_delta) hipHostFree(c->h_total_delta);
     for (auto& sp : c->spans) { hipEventDestroy(sp.b); hipEventDestroy(sp.e); }

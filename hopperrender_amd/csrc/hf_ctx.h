@@ -89,9 +89,6 @@ struct hf_ctx {
     uint32_t* blurred_xy[2] = {nullptr, nullptr};      // the same flow packed x | y << 16 (fast warp path)
     uint32_t* sadtab = nullptr;                        // SAD tables (hf_flow.hip): [2][sad_nby][sad_nbx][8] u16 pairs; nullptr: HF_FLAG_NO_SAD_REUSE
     size_t sadtab_bytes = 0;
-    uint32_t* work = nullptr;                          // work list of the lean / compacted chain launches: 16 counters + one entry per finest window
-    size_t work_bytes = 0;
-    int work_groups = 0;
     int sad_nbx = 0, sad_nby = 0;
     uint32_t* sums = nullptr;                          // [kMaxSteps][n_windows_max][16]
     size_t sums_bytes = 0;

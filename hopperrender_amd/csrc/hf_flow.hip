@@ -253,10 +253,15 @@ __device__ __forceinline__ uint32_t sad4(const uint32_t* c, uint32_t sel, const 
 // R16 (here and below): the search radius is 16 although the tile may hang over the grid's edge (FULL false): the candidate loops are
 // unconditional and only the validity masks remain -- the partial tiles of a launch (the bottom tile row of a 480 x 270 grid) are its
 // longest waves, and with a run-time radius every candidate sits behind its own test
-template <int PX, bool UNI, bool FULL, bool PACK = false, bool R16 = FULL>
+// NH: the candidates are fetched and scored in NH groups of 16 / NH, one after the other -- 16 / NH loads in flight per lane instead of 16:
+// registers for round trips.  The table bodies (most of whose waves only reuse) take 2: their launches are as fast as their lean waves are
+// many, and those are as many as the registers of the computing path allow.
+template <int PX, bool UNI, bool FULL, bool PACK = false, bool R16 = FULL, int NH = 1>
 __device__ __forceinline__ void strip_sads(uint32_t* sad, const Geom& g, const FlowStep& a, const Strip<PX>& s,
                                            int ox, int oy, int axis) {
     static_assert(!PACK || (PX == 4 && FULL), "the packed per-block form exists for full tiles of 4-pixel strips");
+    static_assert(NH == 1 || NH == 2 || NH == 4, "groups of 16, 8 or 4 candidates");
+    constexpr int NC = 16 / NH;
     const PhaseLayout& pl = a.pl;
     const int sy = s.cy << g.rs;
     const bool ragged = !FULL && (g.lw & (PX - 1)) != 0;              // kernel-uniform: some strip hangs over the right grid edge
@@ -266,63 +271,70 @@ __device__ __forceinline__ void strip_sads(uint32_t* sad, const Geom& g, const F
     if (UNI) { ox = __builtin_amdgcn_readfirstlane(ox); oy = __builtin_amdgcn_readfirstlane(oy); }
     const int searched0 = axis ? oy : ox;
     const unsigned row_el = (unsigned)(pl.nph2 * pl.lwp);             // elements per full-res row
-    Elems<PX> c1[16];
-    uint32_t sel[16];
-    if (!axis) {
-        // (the margin mx goes into the window part: it keeps that part >= 0, as a scalar buffer offset has to be)
-        const unsigned lane_off = (__umul24((unsigned)mirror_clamp(sy + oy, g.H), row_el) + (unsigned)s.cx0) * 4u;
+    // Y step: rows -- the reflection of calcDeltaSumsKernelSDR.h:86-95 only acts within 64 rows of the frame edge
+    const int ph0 = ox & (pl.nph - 1);
+    const unsigned col = (unsigned)((ph0 >> 1) * pl.lwp + pl.mx + s.cx0 + (ox >> g.rs));
+    const unsigned selc = 0x03020c00u | (unsigned)(ph0 & 1);
+    const int cmin = searched0 + rel_offset(0, R), cmax = searched0 + rel_offset(R - 1, R);
+    const bool inside = !any || (sy + cmin >= 0 && sy + cmax <= g.H - 1);
+    const bool y_direct = axis && __builtin_amdgcn_ballot_w64(!inside) == 0;
 #pragma unroll
-        for (int cz = 0; cz < 16; cz++) {
-            if (cz < R && any) {                                  // R is uniform
-                const int c = searched0 + rel_offset(cz, R);
-                const int ph = c & (pl.nph - 1);
-                const unsigned coff = (unsigned)((ph >> 1) * pl.lwp + (c >> g.rs) + pl.mx) * 4u;
-                c1[cz] = UNI ? buffer_elems<PX>(rsrc, lane_off + 0u, coff, pl.bytes) : buffer_elems<PX>(rsrc, lane_off + coff, 0u, pl.bytes);
-                sel[cz] = 0x03020c00u | (unsigned)(ph & 1);           // v_perm_b32: luma byte of this phase, 0, U, V
+    for (int h = 0; h < NH; h++) {
+        Elems<PX> c1[NC];
+        uint32_t sel[NC];
+        if (!axis) {
+            // (the margin mx goes into the window part: it keeps that part >= 0, as a scalar buffer offset has to be)
+            const unsigned lane_off = (__umul24((unsigned)mirror_clamp(sy + oy, g.H), row_el) + (unsigned)s.cx0) * 4u;
+#pragma unroll
+            for (int k = 0; k < NC; k++) {
+                const int cz = h * NC + k;
+                if (cz < R && any) {                                  // R is uniform
+                    const int c = searched0 + rel_offset(cz, R);
+                    const int ph = c & (pl.nph - 1);
+                    const unsigned coff = (unsigned)((ph >> 1) * pl.lwp + (c >> g.rs) + pl.mx) * 4u;
+                    c1[k] = UNI ? buffer_elems<PX>(rsrc, lane_off + 0u, coff, pl.bytes) : buffer_elems<PX>(rsrc, lane_off + coff, 0u, pl.bytes);
+                    sel[k] = 0x03020c00u | (unsigned)(ph & 1);        // v_perm_b32: luma byte of this phase, 0, U, V
+                }
             }
-        }
-    } else {
-        const int ph0 = ox & (pl.nph - 1);
-        const unsigned col = (unsigned)((ph0 >> 1) * pl.lwp + pl.mx + s.cx0 + (ox >> g.rs));
-        const unsigned selc = 0x03020c00u | (unsigned)(ph0 & 1);
-        // rows: the reflection of calcDeltaSumsKernelSDR.h:86-95 only acts within 64 rows of the frame edge
-        const int cmin = searched0 + rel_offset(0, R), cmax = searched0 + rel_offset(R - 1, R);
-        const bool inside = !any || (sy + cmin >= 0 && sy + cmax <= g.H - 1);
-        if (__builtin_amdgcn_ballot_w64(!inside) == 0) {
+        } else if (y_direct) {
             const unsigned lane_off = (__umul24((unsigned)(sy + cmin), row_el) + col) * 4u;   // row of the lowest candidate
 #pragma unroll
-            for (int cz = 0; cz < 16; cz++) {
+            for (int k = 0; k < NC; k++) {
+                const int cz = h * NC + k;
                 if (cz < R && any) {
                     const unsigned coff = __umul24((unsigned)(rel_offset(cz, R) - rel_offset(0, R)), row_el) * 4u;   // >= 0, wave-uniform
-                    c1[cz] = buffer_elems<PX>(rsrc, lane_off, coff, pl.bytes);
-                    sel[cz] = selc;
+                    c1[k] = buffer_elems<PX>(rsrc, lane_off, coff, pl.bytes);
+                    sel[k] = selc;
                 }
             }
         } else {
 #pragma unroll
-            for (int cz = 0; cz < 16; cz++) {
+            for (int k = 0; k < NC; k++) {
+                const int cz = h * NC + k;
                 if (cz < R && any) {
                     const int ny = mirror_clamp(sy + searched0 + rel_offset(cz, R), g.H);
-                    c1[cz] = buffer_elems<PX>(rsrc, (__umul24((unsigned)ny, row_el) + col) * 4u, 0u, pl.bytes);
-                    sel[cz] = selc;
+                    c1[k] = buffer_elems<PX>(rsrc, (__umul24((unsigned)ny, row_el) + col) * 4u, 0u, pl.bytes);
+                    sel[k] = selc;
                 }
             }
         }
-    }
 #pragma unroll
-    for (int cz = 0; cz < 16; cz++) {
-        uint32_t t = sad[cz];
-        if constexpr (PACK) {
-            t = sad4<true>(c1[cz].d, sel[cz], s.ref, t);
-        } else if (cz < R && any) {
+        for (int k = 0; k < NC; k++) {
+            const int cz = h * NC + k;
+            uint32_t t = sad[cz];
+            if constexpr (PACK) {
+                t = sad4<true>(c1[k].d, sel[k], s.ref, t);
+            } else if (cz < R && any) {
 #pragma unroll
-            for (int i = 0; i < PX; i++) {
-                uint32_t v = __builtin_amdgcn_perm(c1[cz].d[i], c1[cz].d[i], sel[cz]);
-                if (ragged) v &= s.vm[i];
-                t = __builtin_amdgcn_sad_u8(v, s.ref[i], t);
+                for (int i = 0; i < PX; i++) {
+                    uint32_t v = __builtin_amdgcn_perm(c1[k].d[i], c1[k].d[i], sel[k]);
+                    if (ragged) v &= s.vm[i];
+                    t = __builtin_amdgcn_sad_u8(v, s.ref[i], t);
+                }
             }
+            sad[cz] = t;
         }
-        sad[cz] = t;
+        if constexpr (NH > 1) __builtin_amdgcn_sched_barrier(0);      // (keep the groups apart: the scheduler would hoist every load to the top)
     }
 }
 
@@ -380,7 +392,7 @@ template <int WROWS, int LPR, int NW> constexpr size_t ystage_bytes(int rs) {
 
 // tid: thread of the workgroup, row-major over the tile (tile row tid / LPR); (wx0, cy0): first grid column / row of the tile; ref: the thread's
 // four frame-N samples.  Workgroup-uniform call (contains a barrier when NW > 1).
-template <int RS, int WROWS, int LPR, int NW, bool PACK = false>
+template <int RS, int WROWS, int LPR, int NW, bool PACK = false, int NH = 1>
 __device__ __forceinline__ void ysads_tile_lds(uint32_t* sad, const FlowStep& a, const uint32_t* ref, int ox, int oy, int wx0, int cy0, int tid, uint32_t* stage) {
     using Y = YRows<RS, WROWS, LPR, NW>;
     typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -413,31 +425,35 @@ __device__ __forceinline__ void ysads_tile_lds(uint32_t* sad, const FlowStep& a,
     const uint32_t sel = 0x03020c00u | (unsigned)(ph0 & 1);
     typedef __attribute__((address_space(3))) const flow_v4* lds_chunks;
     const lds_chunks mine = (lds_chunks)stage + tid;           // tile row r of a class lies LPR r chunks behind the class's row for tile row 0
-    flow_v4 c1[16];
-    static_for<16>([&](auto CZ) {
-        constexpr int cz = decltype(CZ)::value, chunk = Y::row0(cz) * LPR;
-        c1[cz] = mine[chunk];
-    });
+    static_for<NH>([&](auto H) {        // (PACK: the table bodies read their candidates in NH groups, see strip_sads)
+        constexpr int h = decltype(H)::value, NC = 16 / NH;
+        flow_v4 c1[NC];
+        static_for<NC>([&](auto K) {
+            constexpr int k = decltype(K)::value, cz = h * NC + k, chunk = Y::row0(cz) * LPR;
+            c1[k] = mine[chunk];
+        });
 #pragma unroll
-    for (int cz = 0; cz < 16; cz++) {
-        const uint32_t c[4] = {c1[cz][0], c1[cz][1], c1[cz][2], c1[cz][3]};
-        sad[cz] = sad4<PACK>(c, sel, ref, sad[cz]);
-    }
+        for (int k = 0; k < NC; k++) {
+            const uint32_t c[4] = {c1[k][0], c1[k][1], c1[k][2], c1[k][3]};
+            sad[h * NC + k] = sad4<PACK>(c, sel, ref, sad[h * NC + k]);
+        }
+        if constexpr (NH > 1) __builtin_amdgcn_sched_barrier(0);
+    });
 }
 
 // The staged form applies to full tiles (R = 16) of planes with rs <= 4 whose candidate rows need no reflection.  ox, oy: the window's.
-template <int WROWS, int LPR, int NW, bool PACK = false>
+template <int WROWS, int LPR, int NW, bool PACK = false, int NH = 1>
 __device__ __forceinline__ bool ysads_tile_try(uint32_t* sad, const Geom& g, const FlowStep& a, const uint32_t* ref, int ox, int oy, int wx0, int cy0, int tid, uint32_t* stage) {
     ox = __builtin_amdgcn_readfirstlane(ox); oy = __builtin_amdgcn_readfirstlane(oy);
     wx0 = __builtin_amdgcn_readfirstlane(wx0); cy0 = __builtin_amdgcn_readfirstlane(cy0);
     if (g.rs < 0 || g.rs > 4) return false;               // (kernel-uniform; such a launch has no dynamic LDS)
     if ((cy0 << g.rs) + oy + rel16(0) < 0 || ((cy0 + WROWS - 1) << g.rs) + oy + rel16(15) > g.H - 1) return false;
     switch (g.rs) {
-        case 0: ysads_tile_lds<0, WROWS, LPR, NW, PACK>(sad, a, ref, ox, oy, wx0, cy0, tid, stage); break;
-        case 1: ysads_tile_lds<1, WROWS, LPR, NW, PACK>(sad, a, ref, ox, oy, wx0, cy0, tid, stage); break;
-        case 2: ysads_tile_lds<2, WROWS, LPR, NW, PACK>(sad, a, ref, ox, oy, wx0, cy0, tid, stage); break;
-        case 3: ysads_tile_lds<3, WROWS, LPR, NW, PACK>(sad, a, ref, ox, oy, wx0, cy0, tid, stage); break;
-        default: ysads_tile_lds<4, WROWS, LPR, NW, PACK>(sad, a, ref, ox, oy, wx0, cy0, tid, stage); break;
+        case 0: ysads_tile_lds<0, WROWS, LPR, NW, PACK, NH>(sad, a, ref, ox, oy, wx0, cy0, tid, stage); break;
+        case 1: ysads_tile_lds<1, WROWS, LPR, NW, PACK, NH>(sad, a, ref, ox, oy, wx0, cy0, tid, stage); break;
+        case 2: ysads_tile_lds<2, WROWS, LPR, NW, PACK, NH>(sad, a, ref, ox, oy, wx0, cy0, tid, stage); break;
+        case 3: ysads_tile_lds<3, WROWS, LPR, NW, PACK, NH>(sad, a, ref, ox, oy, wx0, cy0, tid, stage); break;
+        default: ysads_tile_lds<4, WROWS, LPR, NW, PACK, NH>(sad, a, ref, ox, oy, wx0, cy0, tid, stage); break;
     }
     return true;
 }
@@ -445,7 +461,7 @@ __device__ __forceinline__ bool ysads_tile_try(uint32_t* sad, const Geom& g, con
 // The same for 8 x 8 windows, four per wave (Map<8>: 16 lanes = one window, lane i of it = tile row i / 2, column group i & 1): every window
 // has its own offsets, so each 16-lane group copies ITS 63 (rs = 3) / 73 (rs = 2) rows of 32 bytes -- 128 row segments per window before --
 // with per-lane addresses.  A copy instruction lands lane-contiguous in LDS: slot t of window w lies at 1,024 (t / 16) + 256 w + 16 (t % 16).
-template <int RS, bool PACK = false>
+template <int RS, bool PACK = false, int NH = 1>
 __device__ __forceinline__ void ysads_win8_lds(uint32_t* sad, const FlowStep& a, const uint32_t* ref, int ox, int oy, int cx0, int cy, int lane, uint32_t* stage) {
     using Y = YRows<RS, 8, 2, 1>;
     constexpr int kCopies = (Y::kTotal * 2 + 15) / 16;
@@ -477,17 +493,21 @@ __device__ __forceinline__ void ysads_win8_lds(uint32_t* sad, const FlowStep& a,
     const uint32_t sel = 0x03020c00u | (unsigned)(ph0 & 1);
     typedef __attribute__((address_space(3))) const flow_v4* lds_chunks;
     const lds_chunks mine = (lds_chunks)stage + (lane >> 4) * 16;   // the window's 16 chunks of copy 0
-    flow_v4 c1[16];
-    static_for<16>([&](auto CZ) {
-        constexpr int cz = decltype(CZ)::value, c2 = Y::row0(cz) * 2, A = c2 & 15;
-        const int u = A + i16;                                  // slot c2 + i16 = copy (c2 / 16) + (u / 16), chunk u % 16
-        c1[cz] = mine[(c2 >> 4) * 64 + u + (A != 0 && u >= 16 ? 48 : 0)];
-    });
+    static_for<NH>([&](auto H) {
+        constexpr int h = decltype(H)::value, NC = 16 / NH;
+        flow_v4 c1[NC];
+        static_for<NC>([&](auto K) {
+            constexpr int k = decltype(K)::value, cz = h * NC + k, c2 = Y::row0(cz) * 2, A = c2 & 15;
+            const int u = A + i16;                              // slot c2 + i16 = copy (c2 / 16) + (u / 16), chunk u % 16
+            c1[k] = mine[(c2 >> 4) * 64 + u + (A != 0 && u >= 16 ? 48 : 0)];
+        });
 #pragma unroll
-    for (int cz = 0; cz < 16; cz++) {
-        const uint32_t c[4] = {c1[cz][0], c1[cz][1], c1[cz][2], c1[cz][3]};
-        sad[cz] = sad4<PACK>(c, sel, ref, sad[cz]);
-    }
+        for (int k = 0; k < NC; k++) {
+            const uint32_t c[4] = {c1[k][0], c1[k][1], c1[k][2], c1[k][3]};
+            sad[h * NC + k] = sad4<PACK>(c, sel, ref, sad[h * NC + k]);
+        }
+        if constexpr (NH > 1) __builtin_amdgcn_sched_barrier(0);
+    });
 }
 template <int RS> constexpr size_t win8_stage_bytes_of() { return (size_t)((YRows<RS, 8, 2, 1>::kTotal * 2 + 15) / 16) * 1024; }
 constexpr size_t win8_stage_bytes(int rs) {
@@ -496,18 +516,18 @@ constexpr size_t win8_stage_bytes(int rs) {
 }
 
 // cx0, cy, ox, oy: the lane's own (per window).  Taken only if all four windows of the wave need no reflection.
-template <bool PACK = false>
+template <bool PACK = false, int NH = 1>
 __device__ __forceinline__ bool ysads_win8_try(uint32_t* sad, const Geom& g, const FlowStep& a, const uint32_t* ref, int ox, int oy, int cx0, int cy, int lane, uint32_t* stage) {
     if (g.rs < 0 || g.rs > 4) return false;
     const int cy0 = cy - ((lane & 15) >> 1);
     const bool outside = (cy0 << g.rs) + oy + rel16(0) < 0 || ((cy0 + 7) << g.rs) + oy + rel16(15) > g.H - 1;
     if (__builtin_amdgcn_ballot_w64(outside) != 0) return false;
     switch (g.rs) {
-        case 0: ysads_win8_lds<0, PACK>(sad, a, ref, ox, oy, cx0, cy, lane, stage); break;
-        case 1: ysads_win8_lds<1, PACK>(sad, a, ref, ox, oy, cx0, cy, lane, stage); break;
-        case 2: ysads_win8_lds<2, PACK>(sad, a, ref, ox, oy, cx0, cy, lane, stage); break;
-        case 3: ysads_win8_lds<3, PACK>(sad, a, ref, ox, oy, cx0, cy, lane, stage); break;
-        default: ysads_win8_lds<4, PACK>(sad, a, ref, ox, oy, cx0, cy, lane, stage); break;
+        case 0: ysads_win8_lds<0, PACK, NH>(sad, a, ref, ox, oy, cx0, cy, lane, stage); break;
+        case 1: ysads_win8_lds<1, PACK, NH>(sad, a, ref, ox, oy, cx0, cy, lane, stage); break;
+        case 2: ysads_win8_lds<2, PACK, NH>(sad, a, ref, ox, oy, cx0, cy, lane, stage); break;
+        case 3: ysads_win8_lds<3, PACK, NH>(sad, a, ref, ox, oy, cx0, cy, lane, stage); break;
+        default: ysads_win8_lds<4, PACK, NH>(sad, a, ref, ox, oy, cx0, cy, lane, stage); break;
     }
     return true;
 }
@@ -682,7 +702,7 @@ __device__ __forceinline__ int resolve_pending(const Geom& g, const FlowStep& a,
 struct FlowPtrs {           // what differs between the members of a batch: six allocations (every table / sum pointer is member 0's + a rebase)
     const uint32_t *pp1, *pp2;
     int16_t* tables;
-    uint32_t *sums, *total_delta, *sadtab, *work;
+    uint32_t *sums, *total_delta, *sadtab;
 };
 struct FlowBatchArgs {
     int n;
@@ -701,14 +721,14 @@ static FlowBatchArgs pack_batch(const FlowBatch& b, int tiles_x, int tiles_y) {
     k.common = b.s[0];
     for (int i = 0; i < b.n; i++) {
         const FlowStep& f = b.s[i];
-        k.m[i] = FlowPtrs{f.pp1, f.pp2, f.tables_base, f.sums_base, f.total_delta, f.sadtab, f.work};
+        k.m[i] = FlowPtrs{f.pp1, f.pp2, f.tables_base, f.sums_base, f.total_delta, f.sadtab};
     }
     return k;
 }
 __device__ __forceinline__ FlowStep member_step(const FlowBatchArgs& k, int i) {
     FlowStep a = k.common;
     const FlowPtrs& p = k.m[i];
-    a.pp1 = p.pp1; a.pp2 = p.pp2; a.total_delta = p.total_delta; a.sadtab = p.sadtab; a.work = p.work;
+    a.pp1 = p.pp1; a.pp2 = p.pp2; a.total_delta = p.total_delta; a.sadtab = p.sadtab;
     const ptrdiff_t dt = p.tables - a.tables_base, ds = p.sums - a.sums_base;   // (scalar arithmetic; null stays null)
     auto rt = [dt](int16_t* x) { return x ? x + dt : x; };
     a.cur.tx = rt(a.cur.tx); a.cur.ty = rt(a.cur.ty); a.prev.tx = rt(a.prev.tx); a.prev.ty = rt(a.prev.ty);
@@ -808,7 +828,7 @@ template <int WS> struct MapSel<WS, true> { using type = MapRow<WS>; };
 // SPLIT (windows <= 16, where a window never spans waves): the four waves of a tile are four one-wave workgroups
 // (TileId::wave).  A 480x270 grid has only 135 tiles for 256 CUs; split, every CU's L1 takes a share of the
 // candidate rows' cache lines (a Y step pulls ~16 x 8 row segments per wave, 32 useful bytes per 128-byte line).
-template <int WS, bool SPLIT, bool FULL, bool ROWS1, bool R16 = FULL>
+template <int WS, bool SPLIT, bool FULL, bool ROWS1, bool R16 = FULL, int NH = 1>
 __device__ __forceinline__ void flow_level_small_body(const Geom& g, const FlowStep& a, const TileId& tile, uint32_t (*s_part)[4][16], [[maybe_unused]] uint32_t* s_rows) {
     using M = typename MapSel<WS, ROWS1>::type;
     constexpr int PX = M::PX, G = M::G;
@@ -853,7 +873,7 @@ __device__ __forceinline__ void flow_level_small_body(const Geom& g, const FlowS
         }
         if (!from_lds) {
 #pragma unroll
-            for (int r = 0; r < M::NR; r++) strip_sads<PX, G == 64, FULL, false, R16>(sad, g, a, strip[r], off[0], off[1], axis);
+            for (int r = 0; r < M::NR; r++) strip_sads<PX, G == 64, FULL, false, R16, NH>(sad, g, a, strip[r], off[0], off[1], axis);
         }
         int first = group_reduce<G, M::XM>(sad, lane);
         if constexpr (WS == 32) {   // four waves share the window
@@ -931,54 +951,19 @@ __device__ __forceinline__ void unpack_u16x8(const flow_v4& q, uint32_t* o) {
     o[4] = q.z & 0xFFFFu; o[5] = q.z >> 16; o[6] = q.w & 0xFFFFu; o[7] = q.w >> 16;
 }
 
+// candidate groups of the table kernels (strip_sads NH): 8 candidates in flight.  Groups of 4: 3 % slower stand-alone, no faster in the pipeline.
+constexpr int kTabGroups = 2;
 // One level, X step then Y step, windows <= 32, of windows in tiles that lie fully inside the grid at R == 16, with the SAD tables.
 // A reusing window is a short chain of dependent memory rounds -- kernel arguments, then ONE round with everything whose address does not
 // depend on data: the window's constants, the grandparent's offsets and the table vectors of BOTH axes (whether they may be used is only
 // known later) -- and ~40 registers; a computing window keeps 16 candidates x 16 bytes in flight (100-170 registers) and several rounds.
-// Three forms of the same body:
-//   kFused  one launch per level: every lane decides per axis (batches of up to 4 pairs, where launches count, and the chain's first small
-//           level, which always computes);
-//   kLean   reuse only: 36-54 registers, 8 waves per SIMD, no computing code in the kernel at all (the computing path in the same kernel costs
-//           the reusing waves half their speed: occupancy and instruction cache).  Windows that cannot finish both steps from the tables
-//           append themselves to the launch's WORK LIST (entry: member, window, "X is done");
-//   kFresh  the work list, compacted: lane groups take windows from the list instead of from their position, compute what the entry still
-//           needs (the Y step may still reuse when the computed X step chose 0) and refresh the tables.
-enum { kFused = 0, kLean = 1, kFresh = 2 };
-// Work lists: the full tiles of a member form groups of kTilesPerGroup (consecutive in row-major order); every group has one list per
-// level -- dense enough that the compacted launch runs full waves (a tile of level 2 alone lists ~67 of its 256 windows on the bench scene: one
-// full wave and one nearly empty one), few enough writers per counter that the lean launch's atomics do not queue up (one per wave: 64 per
-// counter and launch; a single counter per member took 540 and doubled the launch's time).
-//   work[(slot * groups + group) * 64]                     entry counter of the level with that slot, one per 256-byte line (the atomics of a launch
-//                                                          spread over the L2 channels); zeroed by the chain's first small level
-//   work[16 * groups * 64 + group * kGroupCapacity + i]    entry i:  xdone << 31 | wy << 13 | wx   (window coordinates at the level)
-constexpr int kTilesPerGroup = 16, kGroupCapacity = kTilesPerGroup * 256, kCounterStride = 64;
-constexpr int kFreshPassDivider = 4;     // the compacted launch starts capacity / 4 passes per group: every listed window in one round up to 25 %
-__device__ __forceinline__ uint32_t work_entry(int wx, int wy, bool xdone) {
-    return (xdone ? 0x80000000u : 0u) | ((uint32_t)wy << 13) | (uint32_t)wx;
-}
-// the lanes with `want` append their entry; one atomic per wave
-__device__ __forceinline__ void work_push(uint32_t* counter, uint32_t* entries, bool want, uint32_t entry) {
-    const uint64_t m = __builtin_amdgcn_ballot_w64(want);
-    if (m == 0) return;
-    uint32_t base = 0;
-    const int first_lane = __builtin_ctzll(m);
-    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    if (lane == first_lane) base = atomicAdd(counter, (uint32_t)__builtin_popcountll(m));
-    base = __builtin_amdgcn_readlane(base, first_lane);
-    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-    HF_DBG_CHECK(!want || base + rank < (uint32_t)kGroupCapacity, 112);
-    if (want) entries[base + rank] = entry;
-}
-
-// (cx0, cy): first grid pixel of the lane; (lx, ly): its position inside the tile (kFused: WS == 32 needs the tile origin); group: the tile's
-// work list (kLean); xdone (kFresh): the lean launch already took this window's X step, its result is in the level table.
-template <int WS, bool SPLIT, bool ROWS1, int MODE>
-__device__ __forceinline__ void flow_level_tab_body(const Geom& g, const FlowStep& a, int cx0, int cy, int lx, int ly, int tid, int group, bool xdone,
-                                                    const TileId* tile, uint32_t (*s_part)[4][16], [[maybe_unused]] uint32_t* s_rows) {
+// (cx0, cy): first grid pixel of the lane; (lx, ly): its position inside the tile (WS == 32 needs the tile origin).
+template <int WS, bool SPLIT, bool ROWS1>
+__device__ __forceinline__ void flow_level_tab_body(const Geom& g, const FlowStep& a, int cx0, int cy, int lx, int ly, int tid, const TileId& tile,
+                                                    uint32_t (*s_part)[4][16], [[maybe_unused]] uint32_t* s_rows) {
     using M = typename MapSel<WS, ROWS1>::type;
     constexpr int PX = M::PX, G = M::G, NR = M::NR, NOWN = Owned<G>::n;
     constexpr int NV = (PX == 4 && NR == 2) ? 4 : (PX == 2 && NR == 1) ? 1 : 2;     // 16-byte vectors of a lane per axis
-    static_assert(MODE == kFused || (WS < 32 && !ROWS1), "lean / compacted launches: windows of 16 and less, block mappings");
     const int wave = tid >> 6, lane = tid & 63;
     const int wx = cx0 >> a.cur.log2w, wy = cy >> a.cur.log2w;
 
@@ -993,50 +978,38 @@ __device__ __forceinline__ void flow_level_tab_body(const Geom& g, const FlowSte
     // what the parent window chose at the previous level: its offsets against its own parent's
     bool zx = false, zy = false;
     flow_v4 pre[2][NV];
-    int done_x = 0;
     if (WS < 32 && a.sad_read) {
         int gx = 0, gy = 0;
         if (a.prev2.tx) {
             gx = table_at(a.prev2.tx, a.prev2, wx << a.cur.log2w, wy << a.cur.log2w);
             gy = table_at(a.prev2.ty, a.prev2, wx << a.cur.log2w, wy << a.cur.log2w);
         }
-        if constexpr (MODE == kFresh) done_x = a.cur.tx[wy * a.cur.nwx + wx];      // (only meaningful with xdone)
 #pragma unroll
         for (int ax = 0; ax < 2; ax++)
 #pragma unroll
             for (int v = 0; v < NV; v++) pre[ax][v] = tab0[ax * tab_axis + v];
         zx = wc.ox == gx; zy = wc.oy == gy;
     }
-    if constexpr (MODE == kFused) {
-        if (a.pend.active) {   // the last large-window step (Y of the previous level) is resolved here
-            const int tx0 = tile->tx * M::TW, ty0 = tile->ty * M::TH;
-            const bool leader = tid == 0 && (tx0 & (a.pend.lvl.window - 1)) == 0 && (ty0 & (a.pend.lvl.window - 1)) == 0;
-            const int v = resolve_pending(g, a, tx0, ty0, lane, leader);
-            if (a.pend.axis) wc.oy = v; else wc.ox = v;
-        }
+    if (a.pend.active) {   // the last large-window step (Y of the previous level) is resolved here
+        const int tx0 = tile.tx * M::TW, ty0 = tile.ty * M::TH;
+        const bool leader = tid == 0 && (tx0 & (a.pend.lvl.window - 1)) == 0 && (ty0 & (a.pend.lvl.window - 1)) == 0;
+        const int v = resolve_pending(g, a, tx0, ty0, lane, leader);
+        if (a.pend.axis) wc.oy = v; else wc.ox = v;
     }
     const int cap_cz = 7;
     uint32_t captured = 0;
     int off[2] = {wc.ox, wc.oy};
-    bool lean_x = false, lean_y = false;    // kLean: the step was taken from the tables
 
 #pragma unroll
     for (int axis = 0; axis < 2; axis++) {
         bool reuse = zy && (axis == 0 ? zx : off[0] == wc.ox);
-        if constexpr (MODE == kLean) {
-            if (axis == 0) lean_x = reuse; else lean_y = reuse = reuse && lean_x;
-            reuse = true;                     // (lanes that may not reuse run along on whatever the tables hold; their result is dropped)
-        }
-        if constexpr (MODE == kFresh) {
-            if (axis == 0) reuse = xdone;     // the lean launch took the X step: pass through (its result replaces this one below)
-        }
         if constexpr (G == 64) reuse = __builtin_amdgcn_readfirstlane((int)reuse) != 0;      // one window per wave
         flow_v4* const tab = tab0 + axis * tab_axis;
         uint32_t tot[NOWN];
         int first = 0;
         if constexpr (PX == 4 && NR == 1) {
             uint32_t W[8];
-            if (MODE != kLean && !reuse) {
+            if (!reuse) {
                 Strip<PX> strip[NR];          // frame-N samples of the lane: only windows that compute read them
 #pragma unroll
                 for (int r = 0; r < NR; r++) strip[r] = load_strip<PX, true>(g, a, cx0, cy + r);
@@ -1045,13 +1018,13 @@ __device__ __forceinline__ void flow_level_tab_body(const Geom& g, const FlowSte
                 for (int cz = 0; cz < 16; cz++) p[cz] = 0u;
                 bool from_lds = false;
                 if constexpr (WS == 16 && SPLIT) {
-                    if (axis == 1) from_lds = ysads_tile_try<16, 4, 1, true>(p, g, a, strip[0].ref, off[0], off[1], cx0, cy, lane, s_rows);
+                    if (axis == 1) from_lds = ysads_tile_try<16, 4, 1, true, kTabGroups>(p, g, a, strip[0].ref, off[0], off[1], cx0, cy, lane, s_rows);
                 } else if constexpr (WS == 8 && SPLIT) {
-                    if (axis == 1) from_lds = ysads_win8_try<true>(p, g, a, strip[0].ref, off[0], off[1], cx0, cy, lane, s_rows);
+                    if (axis == 1) from_lds = ysads_win8_try<true, kTabGroups>(p, g, a, strip[0].ref, off[0], off[1], cx0, cy, lane, s_rows);
                 } else if constexpr (WS == 32) {
-                    if (axis == 1) from_lds = ysads_tile_try<32, 8, 4, true>(p, g, a, strip[0].ref, off[0], off[1], cx0 - lx, cy - ly, tid, s_rows);
+                    if (axis == 1) from_lds = ysads_tile_try<32, 8, 4, true, kTabGroups>(p, g, a, strip[0].ref, off[0], off[1], cx0 - lx, cy - ly, tid, s_rows);
                 }
-                if (!from_lds) strip_sads<4, G == 64, true, true>(p, g, a, strip[0], off[0], off[1], axis);
+                if (!from_lds) strip_sads<4, G == 64, true, true, true, kTabGroups>(p, g, a, strip[0], off[0], off[1], axis);
                 const uint32_t selw = (cy & 1) ? 0x07060302u : 0x05040100u;
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
@@ -1067,7 +1040,7 @@ __device__ __forceinline__ void flow_level_tab_body(const Geom& g, const FlowSte
             first = packed_reduce<G, M::XM>(W, tot, lane);
         } else if constexpr (PX == 4) {      // Map<4>: a 4 x 2 block pair per lane
             uint32_t V[8];
-            if (MODE != kLean && !reuse) {
+            if (!reuse) {
                 Strip<PX> strip[NR];          // frame-N samples of the lane: only windows that compute read them
 #pragma unroll
                 for (int r = 0; r < NR; r++) strip[r] = load_strip<PX, true>(g, a, cx0, cy + r);
@@ -1075,7 +1048,7 @@ __device__ __forceinline__ void flow_level_tab_body(const Geom& g, const FlowSte
 #pragma unroll
                 for (int cz = 0; cz < 16; cz++) p[cz] = 0u;
 #pragma unroll
-                for (int r = 0; r < NR; r++) strip_sads<4, false, true, true>(p, g, a, strip[r], off[0], off[1], axis);
+                for (int r = 0; r < NR; r++) strip_sads<4, false, true, true, true, kTabGroups>(p, g, a, strip[r], off[0], off[1], axis);
                 uint32_t W0[8], W1[8];
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
@@ -1094,26 +1067,26 @@ __device__ __forceinline__ void flow_level_tab_body(const Geom& g, const FlowSte
             }
             first = packed_reduce<G, M::XM>(V, tot, lane);
         } else if constexpr (NR == 2) {      // Map<2>: the lane IS a block
-            if (MODE != kLean && !reuse) {
+            if (!reuse) {
                 Strip<PX> strip[NR];          // frame-N samples of the lane: only windows that compute read them
 #pragma unroll
                 for (int r = 0; r < NR; r++) strip[r] = load_strip<PX, true>(g, a, cx0, cy + r);
 #pragma unroll
                 for (int cz = 0; cz < 16; cz++) tot[cz] = 0u;
 #pragma unroll
-                for (int r = 0; r < NR; r++) strip_sads<PX, false, true>(tot, g, a, strip[r], off[0], off[1], axis);
+                for (int r = 0; r < NR; r++) strip_sads<PX, false, true, false, true, kTabGroups>(tot, g, a, strip[r], off[0], off[1], axis);
             } else {
                 unpack_u16x8(pre[axis][0], tot); unpack_u16x8(pre[axis][1 % NV], tot + 8);
             }
         } else {                             // MapRow<2>: two lanes, a row each
-            if (MODE != kLean && !reuse) {
+            if (!reuse) {
                 Strip<PX> strip[NR];          // frame-N samples of the lane: only windows that compute read them
 #pragma unroll
                 for (int r = 0; r < NR; r++) strip[r] = load_strip<PX, true>(g, a, cx0, cy + r);
                 uint32_t sad[16];
 #pragma unroll
                 for (int cz = 0; cz < 16; cz++) sad[cz] = 0u;
-                strip_sads<PX, false, true>(sad, g, a, strip[0], off[0], off[1], axis);
+                strip_sads<PX, false, true, false, true, kTabGroups>(sad, g, a, strip[0], off[0], off[1], axis);
                 butterfly_level<16, M::XM>(sad, lane);
 #pragma unroll
                 for (int k = 0; k < 8; k++) tot[k] = sad[k];
@@ -1128,28 +1101,23 @@ __device__ __forceinline__ void flow_level_tab_body(const Geom& g, const FlowSte
             tot[0] = s_part[axis][0][first] + s_part[axis][1][first] + s_part[axis][2][first] + s_part[axis][3][first];
         }
         const int best = group_argmin<G, true, M::XM>(tot, first, a, off[axis], axis ? wc.nby : wc.nbx, wc.npix, cap_cz,
-                                                      MODE == kFused && axis == 0 && a.capture_delta, captured, lane);
+                                                      axis == 0 && a.capture_delta, captured, lane);
         off[axis] = (int)(int16_t)(off[axis] + rel_offset(best, 16));   // adjustOffsetArrayKernelSDR.h:13-19
-        if constexpr (MODE == kFresh) {
-            if (axis == 0 && xdone) off[0] = done_x;
-        }
     }
 
     const bool leader = WS == 32 ? tid == 0 : G == 2 ? (lane & M::XM) == 0 : (lane & (G - 1)) == 0;
     HF_DBG_CHECK(wx >= 0 && wy >= 0 && wx < a.cur.nwx && wy < a.cur.nwy, 105);
-    if constexpr (MODE == kLean) {
-        if (leader && lean_x) a.cur.tx[wy * a.cur.nwx + wx] = (int16_t)off[0];
-        if (leader && lean_y) a.cur.ty[wy * a.cur.nwx + wx] = (int16_t)off[1];
-        work_push(a.work + (a.work_slot * a.work_groups + group) * kCounterStride, a.work + 16 * a.work_groups * kCounterStride + (size_t)group * kGroupCapacity, leader && !lean_y,
-                  work_entry(wx, wy, lean_x));
-    } else if (leader) {
+    if (leader) {
         a.cur.tx[wy * a.cur.nwx + wx] = (int16_t)off[0];
         a.cur.ty[wy * a.cur.nwx + wx] = (int16_t)off[1];
-        if (MODE == kFused && a.capture_delta && wx == 0 && wy == 0) *a.total_delta = captured / a.delta_divisor;   // opticalFlowCalcSDR.cpp:91-94
+        if (a.capture_delta && wx == 0 && wy == 0) *a.total_delta = captured / a.delta_divisor;   // opticalFlowCalcSDR.cpp:91-94
     }
 }
 
-template <int WS, bool SPLIT, bool ROWS1 = false>
+// TABK: the launch's chain keeps SAD tables at R == 16 -- full tiles take the table body, tiles over the grid's edge the generic one, both with
+// the candidates in groups of 8 (kTabGroups).  The kernel's register allocation is that of its fattest body, so the launches without tables
+// (16 candidates in flight everywhere) are instantiations of their own.
+template <int WS, bool SPLIT, bool ROWS1 = false, bool TABK = false>
 __global__ __launch_bounds__(SPLIT ? 64 : 256) void flow_level_small_kernel(const Geom g, const FlowBatchArgs batch) {
     using M = typename MapSel<WS, ROWS1>::type;
     const TileId tile = decode_tile<SPLIT ? M::WAVES : 1>(batch, (g.lw + M::TW - 1) / M::TW, (g.lh + M::TH - 1) / M::TH);
@@ -1166,83 +1134,20 @@ __global__ __launch_bounds__(SPLIT ? 64 : 256) void flow_level_small_kernel(cons
     const bool full = a.R == 16 && (tile.tx + 1) * M::TW <= g.lw && (tile.ty + 1) * M::TH <= g.lh;
     // SAD tables: tiles whose 32 x 32 tile lies inside the grid (the 16-wide tiles of MapRow<2> answer for the tile around them: its
     // entries are what the previous level left)
-#ifdef HF_EXP_NO_TAB
-    const bool tab = false;
-#else
-    const bool tab = full && a.sadtab && (a.sad_read || a.sad_write) && (M::TW == 32 || ((tile.tx * M::TW) | 31) < g.lw);
-#endif
-    if (a.work && !a.sad_read && tile.tx == 0 && tile.ty == 0 && tile.wave == 0)   // the chain's first small level: empty work lists for the lean launches behind it
-        for (int i = (int)threadIdx.x; i < 16 * a.work_groups; i += (int)blockDim.x) a.work[i * kCounterStride] = 0u;
-    if (tab) {
-        const int tid = SPLIT ? (int)(tile.wave * 64 + threadIdx.x) : (int)threadIdx.x;
-        int lx, ly;
-        M::at(tid, lx, ly);
-        flow_level_tab_body<WS, SPLIT, ROWS1, kFused>(g, a, tile.tx * M::TW + lx, tile.ty * M::TH + ly, lx, ly, tid, tile.pair, false, &tile, s_part, s_rows);
+    if constexpr (TABK) {      // (launch_flow_level_small: a.sadtab, a.R == 16 and a.sad_read || a.sad_write)
+        const bool tab = full && (M::TW == 32 || ((tile.tx * M::TW) | 31) < g.lw);
+        if (tab) {
+            const int tid = SPLIT ? (int)(tile.wave * 64 + threadIdx.x) : (int)threadIdx.x;
+            int lx, ly;
+            M::at(tid, lx, ly);
+            flow_level_tab_body<WS, SPLIT, ROWS1>(g, a, tile.tx * M::TW + lx, tile.ty * M::TH + ly, lx, ly, tid, tile, s_part, s_rows);
+        }
+        else if (full) flow_level_small_body<WS, SPLIT, true, ROWS1, true, kTabGroups>(g, a, tile, s_part, s_rows);
+        else flow_level_small_body<WS, SPLIT, false, ROWS1, true, kTabGroups>(g, a, tile, s_part, s_rows);
     }
     else if (full) flow_level_small_body<WS, SPLIT, true, ROWS1>(g, a, tile, s_part, s_rows);
     else if (a.R == 16) flow_level_small_body<WS, SPLIT, false, ROWS1, true>(g, a, tile, s_part, s_rows);
     else flow_level_small_body<WS, SPLIT, false, ROWS1>(g, a, tile, s_part, s_rows);
-}
-
-// The lean launch of a level (kLean above): the full tiles only, a one-wave workgroup per wave tile.
-template <int WS>
-__global__ __launch_bounds__(64) void flow_level_lean_kernel(const Geom g, const FlowBatchArgs batch) {
-    using M = Map<WS>;
-    const TileId tile = decode_tile<M::WAVES>(batch, g.lw / 32, g.lh / 32);
-    if (!tile.valid) return;
-    const FlowStep a = member_step(batch, tile.pair);
-    const int tid = (int)(tile.wave * 64 + threadIdx.x);
-    int lx, ly;
-    M::at(tid, lx, ly);
-    flow_level_tab_body<WS, true, false, kLean>(g, a, tile.tx * 32 + lx, tile.ty * 32 + ly, lx, ly, tid, (tile.ty * (g.lw / 32) + tile.tx) / kTilesPerGroup, false,
-                                                nullptr, nullptr, nullptr);
-}
-
-// The compacted launch of a level (kFresh above).  One-wave workgroups: first one per wave tile of the tiles that hang over the grid's
-// edge (generic body), then one per (member, tile group, pass) -- pass p takes entries [p, p + 1) * (64 / G) of the group's list and leaves at
-// once when the list is shorter.
-template <int WS>
-__global__ __launch_bounds__(64) void flow_level_fresh_kernel(const Geom g, const FlowBatchArgs batch) {
-    using M = Map<WS>;
-    constexpr int G = M::G, WPW = 64 / G, PPG = kTilesPerGroup * M::WAVES;     // windows per pass, passes per group (its capacity at this level)
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_rows[];
-    const int groups = batch.common.work_groups;
-    constexpr int LP = PPG / kFreshPassDivider;              // launched passes per group; lists longer than a quarter of the capacity loop
-    const int tiles_x = (g.lw + 31) / 32, tiles_y = (g.lh + 31) / 32, full_x = g.lw / 32, full_y = g.lh / 32;
-    const int n_bottom = tiles_x * (tiles_y - full_y), n_partial = n_bottom + (tiles_x - full_x) * full_y;
-    const int n_edge = n_partial * M::WAVES * batch.n;       // the partial tiles go first: they are the launch's longest waves
-    if ((int)blockIdx.x < n_edge) {                          // bottom tile rows, then the right tile columns of the full rows
-        __shared__ uint32_t s_part[1][4][16];
-        const int u = (int)blockIdx.x;
-        const int v = u / M::WAVES, pair = v / n_partial, j = v - pair * n_partial;
-        const int q = j - n_bottom, w = max(tiles_x - full_x, 1);
-        const TileId t{pair, j < n_bottom ? j % tiles_x : full_x + q % w, j < n_bottom ? full_y + j / tiles_x : q / w, u % M::WAVES, true};
-        const FlowStep a = member_step(batch, t.pair);
-        flow_level_small_body<WS, true, false, false, true>(g, a, t, s_part, s_rows);    // (this launch only exists at R == 16)
-        return;
-    }
-    const int lb = (int)blockIdx.x - n_edge;
-    const int pass0 = lb % LP, v = lb / LP, group = v % groups, member = v / groups;
-    if (member >= batch.n) return;
-    const FlowStep a = member_step(batch, member);
-    const uint32_t count = a.work[(a.work_slot * groups + group) * kCounterStride];
-    if ((uint32_t)(pass0 * WPW) >= count) return;
-    const int lane = (int)threadIdx.x;
-    // the lane's window of the pass and its place inside that window (the lane maps of Map<WS> with the window as the tile)
-    int wi, px, py;
-    if constexpr (WS == 16) { wi = 0; px = (lane & 3) * 4; py = lane >> 2; }
-    else if constexpr (WS == 8) { wi = lane >> 4; px = (lane & 1) * 4; py = (lane & 15) >> 1; }
-    else if constexpr (WS == 4) { wi = (lane >> 4) * 8 + (lane & 7); px = 0; py = ((lane >> 3) & 1) * 2; }
-    else { wi = lane; px = 0; py = 0; }
-    for (int pass = pass0; (uint32_t)(pass * WPW) < count; pass += LP) {
-        const uint32_t e = (uint32_t)(pass * WPW + wi);
-        if (e < count) {                                     // (whole windows: the lanes of a window share e)
-            const uint32_t entry = a.work[16 * groups * kCounterStride + (size_t)group * kGroupCapacity + e];
-            const int wx = (int)(entry & 0x1FFFu), wy = (int)((entry >> 13) & 0x1FFFu);
-            HF_DBG_CHECK(wx < a.cur.nwx && wy < a.cur.nwy, 111);
-            flow_level_tab_body<WS, true, false, kFresh>(g, a, wx * WS + px, wy * WS + py, px, py, lane, group, (entry >> 31) != 0, nullptr, nullptr, s_rows);
-        }
-    }
 }
 
 // Windows > 32, one axis: raw SAD sums of a 32 x (8 * WPB) tile -> one atomic per candidate.
@@ -1420,9 +1325,6 @@ void launch_prep_frame(const Geom& g, const PhaseLayout& pl, const void* frame, 
 // Batches up to this size run the two finest levels with one row per lane (MapRow).  Chain alone, us per batched chain with a block /
 // a row per lane: 1 pair 79.5 / 71.3, 2 pairs 94.6 / 86.8, 4 pairs 122.4 / 119.2, 8 pairs 169.3 / 173.8.
 constexpr int kRowPerLaneMaxBatch = 4;
-#ifndef HF_EXP_SPLIT_MIN_BATCH
-#define HF_EXP_SPLIT_MIN_BATCH 99
-#endif
 void launch_flow_level_small(const Geom& g, const FlowBatch& b, hipStream_t stream) {
     const int ws = b.s[0].cur.window;
     const bool rows1 = b.n <= kRowPerLaneMaxBatch && ws <= 4;
@@ -1431,43 +1333,29 @@ void launch_flow_level_small(const Geom& g, const FlowBatch& b, hipStream_t stre
     const FlowBatchArgs kb = pack_batch(b, tiles_x, tiles_y);
     // dynamic LDS: the candidate rows of the Y step (full tiles only exist at the full search radius)
     const size_t lds = b.s[0].R != 16 ? 0 : ws == 32 ? ystage_bytes<32, 8, 4>(g.rs) : ws == 16 ? ystage_bytes<16, 4, 1>(g.rs) : ws == 8 ? win8_stage_bytes(g.rs) : 0;
-    // Batches of more than 4 pairs behind a level that left SAD tables: a LEAN launch that only reuses (full tiles; windows that cannot
-    // finish from the tables go to their member's work list) and a COMPACTED launch that computes the listed windows and the partial tiles.
-    const int full_x = g.lw / 32, full_y = g.lh / 32;
-    if (b.n >= HF_EXP_SPLIT_MIN_BATCH && ws <= 16 && b.s[0].sad_read && b.s[0].sadtab && b.s[0].work && b.s[0].R == 16 && full_x > 0 && full_y > 0 &&
-        b.s[0].work_groups == (full_x * full_y + kTilesPerGroup - 1) / kTilesPerGroup && g.lw < (1 << 14) && g.lh < (1 << 14)) {
-        const FlowBatchArgs kl = pack_batch(b, full_x, full_y);
-        const int n_partial = tiles_x * tiles_y - full_x * full_y;
-        const int waves = ws == 4 ? Map<4>::WAVES : 4;
-        const dim3 lgrd(xcd_grid(full_x, full_y, waves, b.n)), fgrd(b.n * b.s[0].work_groups * (kTilesPerGroup * waves / kFreshPassDivider) + n_partial * waves * b.n);
-        switch (ws) {
-            case 16: HF_LAUNCH("level_16_reuse", (flow_level_lean_kernel<16>), lgrd, dim3(64), 0, stream, g, kl);
-                     HF_LAUNCH("level_16_compute", (flow_level_fresh_kernel<16>), fgrd, dim3(64), lds, stream, g, kl); break;
-            case 8:  HF_LAUNCH("level_8_reuse", (flow_level_lean_kernel<8>), lgrd, dim3(64), 0, stream, g, kl);
-                     HF_LAUNCH("level_8_compute", (flow_level_fresh_kernel<8>), fgrd, dim3(64), lds, stream, g, kl); break;
-            case 4:  HF_LAUNCH("level_4_reuse", (flow_level_lean_kernel<4>), lgrd, dim3(64), 0, stream, g, kl);
-                     HF_LAUNCH("level_4_compute", (flow_level_fresh_kernel<4>), fgrd, dim3(64), lds, stream, g, kl); break;
-            default: HF_LAUNCH("level_2_reuse", (flow_level_lean_kernel<2>), lgrd, dim3(64), 0, stream, g, kl);
-                     HF_LAUNCH("level_2_compute", (flow_level_fresh_kernel<2>), fgrd, dim3(64), lds, stream, g, kl); break;
-        }
-        return;
-    }
     // windows <= 16 never span waves: one-wave workgroups (SPLIT), see flow_level_small_kernel
     const dim3 grd(xcd_grid(tiles_x, tiles_y, 1, b.n));
     auto split = [&](int waves) { return dim3(xcd_grid(tiles_x, tiles_y, waves, b.n)); };
+    const bool tabk = b.s[0].sadtab && b.s[0].R == 16 && (b.s[0].sad_read || b.s[0].sad_write);
+#define HF_LEVEL(NAME, WS_, SPLIT_, ROWS1_, GRID, BLOCK, LDS)                                                                            \
+    do {                                                                                                                                 \
+        if (tabk) HF_LAUNCH(NAME, (flow_level_small_kernel<WS_, SPLIT_, ROWS1_, true>), GRID, BLOCK, LDS, stream, g, kb);                \
+        else HF_LAUNCH(NAME, (flow_level_small_kernel<WS_, SPLIT_, ROWS1_, false>), GRID, BLOCK, LDS, stream, g, kb);                    \
+    } while (0)
     switch (ws) {
-        case 32: HF_LAUNCH("level_32", (flow_level_small_kernel<32, false>), grd, dim3(256), lds, stream, g, kb); break;
-        case 16: HF_LAUNCH("level_16", (flow_level_small_kernel<16, true>), split(Map<16>::WAVES), dim3(64), lds, stream, g, kb); break;
-        case 8: HF_LAUNCH("level_8", (flow_level_small_kernel<8, true>), split(Map<8>::WAVES), dim3(64), lds, stream, g, kb); break;
+        case 32: HF_LEVEL("level_32", 32, false, false, grd, dim3(256), lds); break;
+        case 16: HF_LEVEL("level_16", 16, true, false, split(Map<16>::WAVES), dim3(64), lds); break;
+        case 8: HF_LEVEL("level_8", 8, true, false, split(Map<8>::WAVES), dim3(64), lds); break;
         case 4:
-            if (rows1) HF_LAUNCH("level_4", (flow_level_small_kernel<4, true, true>), split(MapRow<4>::WAVES), dim3(64), 0, stream, g, kb);
-            else HF_LAUNCH("level_4", (flow_level_small_kernel<4, true>), split(Map<4>::WAVES), dim3(64), 0, stream, g, kb);
+            if (rows1) HF_LEVEL("level_4", 4, true, true, split(MapRow<4>::WAVES), dim3(64), 0);
+            else HF_LEVEL("level_4", 4, true, false, split(Map<4>::WAVES), dim3(64), 0);
             break;
         default:
-            if (rows1) HF_LAUNCH("level_2", (flow_level_small_kernel<2, true, true>), split(MapRow<2>::WAVES), dim3(64), 0, stream, g, kb);
-            else HF_LAUNCH("level_2", (flow_level_small_kernel<2, true>), split(Map<2>::WAVES), dim3(64), 0, stream, g, kb);
+            if (rows1) HF_LEVEL("level_2", 2, true, true, split(MapRow<2>::WAVES), dim3(64), 0);
+            else HF_LEVEL("level_2", 2, true, false, split(Map<2>::WAVES), dim3(64), 0);
             break;
     }
+#undef HF_LEVEL
 }
 
 constexpr int kBigWavesPerBlock = 4;   // measured on MI355X (2160p HDR chain): 4 waves per workgroup 108.2 us, 2: 109.0 us, 1: 111.9 us (more atomics)

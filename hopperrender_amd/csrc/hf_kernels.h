@@ -149,9 +149,6 @@ struct FlowStep {
     int sad_nbx, sad_nby;
     int sad_read;            // the previous level's launch left valid tables for every full tile (this is not the chain's first small level)
     int sad_write;           // this launch refreshes them where it computes (windows 32 .. 4)
-    uint32_t* work;          // work list of the lean / compacted launches (one per batch): counters + entries, nullptr: one fused launch per level
-    int work_slot;           // this level's counters
-    int work_groups;         // tile groups of the work lists = ceil(full tiles / 16) (layout: hf_flow.hip "Work lists")
     // allocation bases of the per-level tables and of the window sums: a batched launch carries member 0's FlowStep and rebases it
     int16_t* tables_base;
     uint32_t* sums_base;
