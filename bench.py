@@ -47,6 +47,9 @@ WORKLOADS = {
     "hdr2160_24to60": (1, 2160, 3840, 166667, "3840x2160 HDR (P010), 24->60 fps"),
     "sdr1080_24to120": (0, 1080, 1920, 83333, "1920x1080 SDR (NV12), 24->120 fps"),
     "sdr360_24to60": (0, 360, 640, 166667, "640x360 SDR, 24->60 fps (plumbing size)"),
+    # north_star: "synthetic 1080p/2160p SDR+HDR pairs" -- the two size / depth combinations BASELINE's configs do not name
+    "hdr1080_24to120": (1, 1080, 1920, 83333, "1920x1080 HDR (P010), 24->120 fps, R=16, full pyramid, blend"),
+    "sdr2160_24to60": (0, 2160, 3840, 166667, "3840x2160 SDR (NV12), 24->60 fps, R=16, full pyramid, blend"),
     # BASELINE config 4: 64 independent 1080p SDR frame pairs in flight, sharded over the ranks (64 / world pair streams per GPU,
     # one hf_batch per GPU up to 32 members); BASELINE config 5: 2160p HDR with the neighbour scalar and the blur radius turned up
     "sdr1080_64pairs": (0, 1080, 1920, 166667, "1920x1080 SDR, 64 independent frame pairs sharded across the GPUs, 24->60 fps (BASELINE config 4)"),
@@ -57,16 +60,21 @@ WORKLOADS = {
 # + 2.3 %, 5 or 6 streams and batches of 13-14 lose), three of 12 at 1080p (+ 4 %) -- with the faster chain and warp launches of this round
 # more, smaller batches in flight fill the device better; four is also the number of hardware queues the batch streams can have.
 OPERATING_POINT = {"hdr2160_24to120": (48, 12), "hdr2160_24to60": (48, 12), "sdr1080_24to60": (36, 12), "sdr1080_24to120": (36, 12),
-                   "sdr360_24to60": (32, 16), "hdr2160_nb10_blur32": (48, 12)}
+                   "sdr360_24to60": (32, 16), "hdr2160_nb10_blur32": (48, 12), "hdr1080_24to120": (36, 12), "sdr2160_24to60": (48, 12)}
 WORKLOAD_PARAMS = {"hdr2160_nb10_blur32": {"neighbor": 10, "blur_radius": 32}}   # overrides of --neighbor / --blur-radius
 TOTAL_PAIRS = {"sdr1080_64pairs": 64}                                            # pair streams of the whole JOB (strong-scaled over ranks)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 # the dominant kernel of the batched pipeline: 2160p HDR (one flow cell per 16-byte thread) runs the LDS-staged period warp
 # (one window per workgroup of 4 wave tiles), 1080p SDR the global-path kernel
 # (template prefix: the full symbol -- waves per workgroup, rows per thread -- is read from the shipped binary, see warp_symbol())
-WARP_SYMBOL_PREFIX = {1: "warp_wg_kernel<unsigned short, 2,", 0: "warp_fast_kernel<unsigned char, 4, 2, 2, 8, true>"}
+# keyed by (hdr, frame larger than 1080p): frames above 1080p take the staged period warp, the others the global-path kernel of their element size
+WARP_SYMBOL_PREFIX = {(1, True): "warp_wg_kernel<unsigned short, 2,", (0, False): "warp_fast_kernel<unsigned char, 4, 2, 2, 8, true>",
+                      (0, True): "warp_wg_kernel<unsigned char, 2,", (1, False): "warp_fast_kernel<unsigned short, 4, 2, 2, 8, true>"}
 # the other BASELINE configs, run as short legs behind the timed region of the default workload (fresh child processes, never `value`)
-OTHER_WORKLOADS = {"sdr1080_24to60": 24, "sdr1080_64pairs": 24, "hdr2160_nb10_blur32": 8}   # name: steps (about 1 s timed each)
+OTHER_WORKLOADS = {"sdr1080_24to60": 24, "sdr1080_64pairs": 24, "hdr2160_nb10_blur32": 8, "hdr1080_24to120": 12, "sdr2160_24to60": 8}   # name: steps (about 1 s timed each)
+# Content classes (hopperrender_amd/synth.py ContentScene; SURVEY.md 8(d) "extra cases"): the reference's cost does not depend on the pixels,
+# this build's does (staged-warp window fit, SAD reuse, gather coherence), so the line says what content it ran on and what the others cost
+CONTENT_LEGS = {"hdr2160_24to120": 6, "sdr1080_24to60": 16}                                   # workload: steps of each scene's leg
 
 
 def _read(path):
@@ -175,19 +183,21 @@ def device_block(dev_index, sysfs, start, end):
     d["vbios"] = _read(os.path.join(sysfs, "vbios_version")) if sysfs else None
     d["at_start_of_timed_region"] = start
     d["at_end_of_timed_region"] = end
-    d["note"] = ("sclk / mclk = the pp_dpm level in force when sampled (the host has just issued / just drained the timed steps); power_cap_w = "
+    d["note"] = ("sclk / mclk = the pp_dpm level in force when sampled: right before the timed region (behind the warm-up's synchronisation) and right behind "
+                 "its final synchronisation, never inside it; power_cap_w = "
                  "hwmon power1_cap; the chip lowers its clock under load (MI355X_MICROARCH.md 'DVFS give-back'), and devices of the pool differ")
     return d
 
 
-def warp_symbol(hdr):
+def warp_symbol(hdr, H=2160, W=3840):
     """Name of the dominant kernel as `rocprofv3 --kernel-trace` prints it, taken from the symbol table of the library this process
     loaded (nm -C), so that the bench line can never name a kernel the binary does not contain."""
     from hopperrender_amd import capi
+    prefix = WARP_SYMBOL_PREFIX[(1 if hdr else 0, H * W > 1920 * 1088)]
     try:
-        return capi.kernel_symbol(WARP_SYMBOL_PREFIX[hdr])
+        return capi.kernel_symbol(prefix)
     except Exception as e:   # (no `nm` on the box: the measurement must not die for a label)
-        return WARP_SYMBOL_PREFIX[hdr] + " ...> (symbol table not readable: %s)" % type(e).__name__
+        return prefix + " ...> (symbol table not readable: %s)" % type(e).__name__
 
 
 def parse_args():
@@ -205,11 +215,15 @@ def parse_args():
                     help="pair streams per hf_batch: their phase planes, refinement chains and period warps run as one set of launches on "
                          "one HIP stream; streams/batch batches run side by side (0: the workload's operating point; 1: no batching)")
     ap.add_argument("--pool", type=int, default=6, help="distinct synthetic source frames resident in HBM, per pair stream")
+    ap.add_argument("--pool-order", default="pingpong", choices=["pingpong", "wrap"],
+                    help="how a stream walks its pool: pingpong (0 .. n-1 .. 0: every pair = consecutive frames of the scene) or wrap (p mod n: rounds 1-5, "
+                         "a jump of n - 1 frames every n-th pair)")
     ap.add_argument("--py-period-calls", action="store_true", help="A-B: three C calls per batch and period, marshalled inside the timed loop (round 2)")
     ap.add_argument("--member-warps", action="store_true", help="A-B: one fused warp launch and one phase-plane launch per member instead of per batch")
     ap.add_argument("--dual-stream-contexts", action="store_true", help="A-B: HF_FLAG_DUAL_STREAM members (warps overlap the context's own chain)")
     ap.add_argument("--no-fused-warp", action="store_true", help="A-B: one warp launch per output frame instead of one per source period")
     ap.add_argument("--eager-planes", action="store_true", help="A-B: HF_FLAG_BATCH_EAGER_PLANES, every phase plane built by the stand-alone kernel when its frame arrives")
+    ap.add_argument("--no-sad-reuse", action="store_true", help="A-B: HF_FLAG_NO_SAD_REUSE, every refinement step recomputes its candidate SADs as the reference does")
     ap.add_argument("--no-lazy-argmin", action="store_true", help="A-B: HF_FLAG_NO_LAZY_ARGMIN, 6 more (tiny) launches per flow chain")
     ap.add_argument("--timing-events", action="store_true",
                     help="keep the reference's per-call timing events (m_ofcCalcTime, m_warpCalcTime); default off in the bench")
@@ -233,6 +247,13 @@ def parse_args():
     ap.add_argument("--no-host-io", action="store_true")
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the short legs of the other BASELINE configs behind the default workload")
     ap.add_argument("--cpu-sample-pairs", type=int, default=8)
+    ap.add_argument("--scene", default="bench", choices=["bench", "static", "pan64", "chaotic", "cut"],
+                    help="content class of the synthetic source frames (hopperrender_amd/synth.py ContentScene): bench = global (+7, -3) px per frame + "
+                         "12 rectangles up to +-48 px; static; pan64 = pure 64 px pan; chaotic = every 16x16 block its own motion up to +-96 px on "
+                         "full-range noise; cut = every pair a hard cut")
+    ap.add_argument("--content-counters", action="store_true", help="behind the timed region: device-side counters of a few periods (share of staged / "
+                    "global / generic warp workgroups, share of windows that reused their SADs per level; include/hopperflow_diag.h)")
+    ap.add_argument("--no-content-legs", action="store_true", help="skip the short legs of the other content classes behind the default workload")
     return ap.parse_args()
 
 
@@ -326,7 +347,7 @@ def host_io_block(hdr, H, W, target, n_periods=24, device=0, async_only=False):
     return res
 
 
-def other_workloads(a, budget_s=150.0):
+def other_workloads(a, budget_s=200.0):
     """BASELINE configs 2, 4 and 5 as ~1 s legs of this same script in fresh child processes (their own HIP runtime and hardware
     queues), AFTER the timed region of the default workload: what the driver's one bench line would otherwise never show.  Reported
     next to `value`, never part of it.  ONE shared deadline (`budget_s`) bounds what the legs add to the run; a leg that fails or does
@@ -336,7 +357,7 @@ def other_workloads(a, budget_s=150.0):
     deadline = time.monotonic() + budget_s
     for name, steps in OTHER_WORKLOADS.items():
         cmd = [sys.executable, os.path.abspath(__file__), "--workload", name, "--steps", str(steps), "--warmup", "2", "--radius", str(a.radius),
-               "--no-cpu-baseline", "--no-reference", "--no-host-io", "--no-other-workloads"]
+               "--no-cpu-baseline", "--no-reference", "--no-host-io", "--no-other-workloads", "--no-content-legs"]
         left = deadline - time.monotonic()
         try:
             if left < 20.0:
@@ -356,6 +377,42 @@ def other_workloads(a, budget_s=150.0):
             failed.append(name)
             print(f"bench.py: other_workloads leg {name} failed: {e!r}"[:500], file=sys.stderr)
     res["failed"] = failed
+    return res
+
+
+def content_legs(a, budget_s=200.0):
+    """The other content classes as ~1 s legs of this same script (fresh child processes behind the timed region of the default workload), at
+    2160p HDR and 1080p SDR: frames/s, chain us per pair (in the pipeline and alone), and the device-side counters of what the kernels decided.
+    Reported next to `value`, never part of it."""
+    import subprocess
+    res, failed = {}, []
+    deadline = time.monotonic() + budget_s
+    for wl, steps in CONTENT_LEGS.items():
+        res[wl] = {}
+        for scene in ("bench", "bench_wrap6", "static", "pan64", "chaotic", "cut"):
+            cmd = [sys.executable, os.path.abspath(__file__), "--workload", wl, "--scene", scene.split("_")[0], "--steps", str(steps), "--warmup", "2", "--radius", str(a.radius),
+                   "--content-counters", "--no-cpu-baseline", "--no-reference", "--no-host-io", "--no-other-workloads", "--no-content-legs"]
+            if scene == "bench_wrap6":
+                cmd += ["--pool-order", "wrap", "--pool", "6"]      # the frame sequence of the bench lines of rounds 1-5
+            left = deadline - time.monotonic()
+            try:
+                if left < 15.0:
+                    raise TimeoutError(f"skipped: {left:.0f} s of the legs' shared {budget_s:.0f} s budget left")
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=left)
+                if r.returncode != 0:
+                    raise RuntimeError(f"exit status {r.returncode}: {r.stderr[-300:]}")
+                d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+                res[wl][scene] = {"value": d["value"], "unit": d["unit"], "us_per_flow_calc_in_pipeline": round(1e3 * (d["ms_per_flow_calc"] or 0), 2),
+                                  "us_per_flow_calc_alone": round(1e3 * (d["ms_per_flow_calc_isolated"] or 0), 2), "steps": d["steps"],
+                                  "counters": d.get("content_counters")}
+            except Exception as e:
+                res[wl][scene] = {"error": repr(e)[:300]}
+                failed.append(f"{wl}/{scene}")
+                print(f"bench.py: content leg {wl}/{scene} failed: {e!r}"[:500], file=sys.stderr)
+    res["failed"] = failed
+    res["note"] = ("bench = this line's scene; bench_wrap6 = the same scene in the frame order of rounds 1-5 (pool of 6 walked modulo: a 5-frame jump every 6th pair); per content class: whole-job frames/s of a short run, flow chain device time per pair, and counters of 4 periods of one batch: warp_staged_share = "
+                   "workgroups of the fused period warp that staged their window in LDS (the rest: interior global path / generic body), reuse_share[window][axis] = "
+                   "windows of full tiles that summed their blocks' SAD vectors instead of gathering (csrc/hf_flow.hip)")
     return res
 
 
@@ -422,7 +479,7 @@ def main():
         raise SystemExit("--streams must be a multiple of --batch")
 
     # ---- synthetic source frames, resident in HBM before the timed region ----
-    scene = synth.Scene(H, W, bool(hdr), seed=1234 + rank)
+    scene = synth.ContentScene(a.scene, H, W, bool(hdr), seed=1234 + rank)     # (bench: the synth.Scene of rounds 1-5, frame for frame)
     host_frames = [scene.frame(k) for k in range(a.pool)]
     # every pair stream gets its OWN device copies (no artificial cache sharing between streams); the
     # streams start at different frames of the sequence
@@ -435,6 +492,16 @@ def main():
             bufs.append(b)
         pools.append(bufs)
 
+    def pool_index(p):
+        """Frame of the pool a stream shows at period p.  pingpong (default): 0 1 .. n-1 n-2 .. 1 0 1 ..: EVERY pair is a pair of consecutive frames of
+        the scene, forwards or backwards, as SURVEY.md 8(d) defines the synthetic pairs.  wrap (rounds 1-5): p mod n -- every n-th pair (5 -> 0) jumps
+        n - 1 frames back: a hard cut every sixth period that no earlier bench line mentioned (content leg "bench_wrap6" keeps it measured)."""
+        n = a.pool
+        if a.pool_order == "wrap" or n < 3:
+            return p % n
+        q = p % (2 * (n - 1))
+        return q if q < n else 2 * (n - 1) - q
+
     flags = capi.HF_FLAG_ASYNC | (0 if a.no_profile else capi.HF_FLAG_PROFILE)
     if not a.timing_events:
         flags |= capi.HF_FLAG_NO_TIMING   # the m_ofcCalcTime / m_warpCalcTime events are barrier packets between the kernels
@@ -444,6 +511,8 @@ def main():
         flags |= capi.HF_FLAG_DUAL_STREAM
     if a.no_lazy_argmin:
         flags |= capi.HF_FLAG_NO_LAZY_ARGMIN
+    if a.no_sad_reuse:
+        flags |= capi.HF_FLAG_NO_SAD_REUSE
     if a.eager_planes:
         flags |= capi.HF_FLAG_BATCH_EAGER_PLANES
     cls = OpticalFlowCalcHDR if hdr else OpticalFlowCalcSDR
@@ -462,7 +531,7 @@ def main():
         outbufs.append([DeviceBuffer(c.output_frame_bytes, dev) for _ in range(max_out)])
         plans.append(schedule)
         for k in range(3):  # prime the 3-frame ring and the previous-flow slot (m_frameCount >= 3)
-            c.updateFrameDeviceRef(pools[s][(s + k) % a.pool].ptr)
+            c.updateFrameDeviceRef(pools[s][pool_index(s + k)].ptr)
         c.calculateOpticalFlow()
         c.sync()
 
@@ -470,7 +539,7 @@ def main():
     batches = [FlowBatch(calcs[k:k + a.batch]) for k in range(0, a.streams, a.batch)] if a.batch > 1 else []
 
     def src_ptr(s, i):
-        return pools[s][(s + 3 + i) % a.pool].ptr
+        return pools[s][pool_index(s + 3 + i)].ptr
 
     # The schedule of a throughput driver is known ahead of time: the arguments of every hf_batch_run_period call (ONE native
     # call per batch and source period -- include/hopperflow.h) are marshalled before the timed region, as a C host's would be.
@@ -574,16 +643,16 @@ def main():
             c.resetProfile()
 
     sysfs = device_sysfs(dev_index) if rank == 0 else None
+    # clock levels / board power right before and right behind the timed region, never inside it: the sysfs reads are SMU queries of up to
+    # milliseconds, and only rank 0 makes them (what the device sustains UNDER the load is the clock probe's figure, taken behind the warm-up)
+    dev_mid = [device_sample(sysfs)] if rank == 0 else []
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     frames_out = 0
-    dev_mid = []
     for k in range(a.warmup, a.warmup + a.steps):
         frames_out += run_step(k)
-        if rank == 0 and k in (a.warmup, a.warmup + a.steps - 1):   # two sysfs reads (~0.1 ms) while the queues are full: first and last step
-            dev_mid.append(device_sample(sysfs))
     host_issue_wall_s = time.perf_counter() - t0   # the host is done issuing; the GPU may still be busy.  NOT the host's cost:
                                                    # once the hardware queues are full every further call blocks until the GPU
                                                    # has retired a packet, so this wall time tracks the GPU's
@@ -592,6 +661,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if rank == 0:
+        dev_mid.append(device_sample(sysfs))
     # What the host loop itself costs: BURST periods issued into EMPTY queues (nothing blocks), per native call
     tb = time.perf_counter()
     for i in range((a.warmup + a.steps) * P, (a.warmup + a.steps) * P + BURST):
@@ -599,6 +670,27 @@ def main():
     host_call_s = (time.perf_counter() - tb) / BURST     # per source period of all streams of this rank
     sync_all()
     host_enqueue_s = host_call_s * P * a.steps
+
+    content_counters = None
+    if a.content_counters and rank == 0 and batches:
+        # what the kernels decided on THIS content: counters of 4 periods of the first batch (device-side atomics, include/hopperflow_diag.h);
+        # behind the timed region, because the counting waves issue atomics
+        lead = calcs[0]
+        lead.countersEnable(True)
+        b0 = batches[0]
+        base = (a.warmup + a.steps) * P + BURST
+        sched_c = BlendSchedule(SOURCE_24, target).plan(base + 8)[base:]
+        for i in range(4):
+            b0.runPeriod(b0.preparePeriod([src_ptr(s, base + i) for s in range(a.batch)], [sched_c[i] for _ in range(a.batch)], out_ptrs[:a.batch], 2))
+        b0.sync()
+        cc = lead.counters()
+        lead.countersEnable(False)
+        wg = cc["warp_workgroups"]
+        tot_wg = max(sum(wg.values()), 1)
+        st_lead = lead.stats()
+        content_counters = {"sad_tables": st_lead["sad_tables"], "still_share_of_32_windows": round(st_lead["still_share"], 4), "warp_workgroups": wg, "warp_staged_share": round(wg["staged"] / tot_wg, 4) if sum(wg.values()) else None,
+                            "reuse_share": {str(w): {ax: round(v[1] / max(v[0], 1), 4) for ax, v in lv.items()} for w, lv in sorted(cc["levels"].items(), reverse=True)},
+                            "windows_counted": {str(w): lv["X"][0] for w, lv in sorted(cc["levels"].items(), reverse=True)}, "periods": 4, "members": a.batch}
 
     red_dev = "cuda" if backend == "nccl" else "cpu"
     tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
@@ -646,13 +738,13 @@ def main():
             x.setProfileInterval(1, 1)
             x.resetProfile()
         for i in range(12):                            # the chain of ONE pair alone, each behind a host synchronisation (an idle device)
-            c.updateFrameDeviceRef(pools[0][i % a.pool].ptr)
+            c.updateFrameDeviceRef(pools[0][pool_index(i)].ptr)
             c.calculateOpticalFlow()
             c.sync()
         flow_us_after_sync = 1e3 * c.profile()["flow_ms"] / max(c.profile()["flow_chains"], 1)
         c.resetProfile()
         for i in range(48):                            # ... and back to back: device time of each chain (still a new frame, i.e. a cold plane, every time)
-            c.updateFrameDeviceRef(pools[0][i % a.pool].ptr)
+            c.updateFrameDeviceRef(pools[0][pool_index(i)].ptr)
             c.calculateOpticalFlow()
         c.sync()
         flow_us = 1e3 * c.profile()["flow_ms"] / max(c.profile()["flow_chains"], 1)
@@ -665,10 +757,10 @@ def main():
                 # one whole period per call, as in the pipeline, one batch stream only: its launches run one after the other, so
                 # the fused warp launch (with the plane-building workgroups of a deferred-plane batch) has the GPU to itself; the
                 # profile spans time the dispatch, not the call
-                small.runPeriod(small.preparePeriod([pools[s][(i + s) % a.pool].ptr for s in range(nb)], ts, out_ptrs[:nb], 2))
+                small.runPeriod(small.preparePeriod([pools[s][pool_index(i + s)].ptr for s in range(nb)], ts, out_ptrs[:nb], 2))
                 small.sync()
             else:
-                c.updateFrameDeviceRef(pools[0][i % a.pool].ptr); c.calculateOpticalFlow(); c.sync()
+                c.updateFrameDeviceRef(pools[0][pool_index(i)].ptr); c.calculateOpticalFlow(); c.sync()
                 c.interpolateOnly(ts[0], out_ptrs[0], 2); c.sync()
         p = c.profile()                                # the leader's profile carries the batch's warp launches
         if small:
@@ -736,6 +828,7 @@ def main():
         roof = {"bound": "hbm", "achieved": round(physical_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(physical_gbs / HBM_PEAK_GBS, 4), "frac_of_measured_copy_bw_6290": round(physical_gbs / 6290.0, 4),
                 "definition": "physical: frames/s per GPU x HBM bytes the pipeline moves per output frame (all kernels)",
+                "traffic_record_commit": (traffic or {}).get("git_commit") if pipe else None,
                 "traffic_pipeline": {"hbm_bytes_per_output_frame": int(bytes_per_frame), "basis": basis,
                                      "per_kernel_bytes_per_pair_and_period": pipe.get("per_kernel_bytes_per_pair_and_period")},
                 "frac_narrow_gathers_x1": round(value / n_gpus * bytes_per_frame_x1 / 1e9 / HBM_PEAK_GBS, 4) if bytes_per_frame_x1 else None,
@@ -750,7 +843,7 @@ def main():
                 "algorithmic_definition": "SURVEY.md 8(d): frames/s per GPU x B_out, B_out = 3F + 4N bytes per output frame",
                 "algorithmic_bytes_per_unit": b_out,
                 "traffic": None, "traffic_note": None,
-                "kernel": warp_symbol(hdr)}
+                "kernel": warp_symbol(hdr, H, W)}
         # HBM bytes of ONE launch of the dominant kernel as the pipeline issues it (a.batch members): PMC pass over the pipeline, else
         # the pass over single-member launches
         per_k = (pipe.get("per_kernel_bytes_per_pair_and_period") or {})
@@ -805,7 +898,7 @@ def main():
             "host_issue_wall_ms_per_step": round(1e3 * host_issue_wall_s / a.steps, 4),
             "higher_is_better": True, "scaling": "strong" if a.workload in TOTAL_PAIRS else "weak", "vs_baseline": None,
             "dtype": "u16" if hdr else "u8", "data": "synthetic",
-            "config": {"workload": a.workload, "description": desc, "search_radius": a.radius,
+            "config": {"workload": a.workload, "description": desc, "scene": a.scene, "pool_frames": a.pool, "pool_order": a.pool_order, "search_radius": a.radius,
                        "delta_scalar": 8, "neighbor_scalar": a.neighbor, "blur_radius": a.blur_radius,
                        "pair_streams_per_gpu": a.streams, "pair_streams_total": a.streams * n_gpus,
                        "host_calls_per_batch_and_period": 1 if one_call else 3, "flow_batch": a.batch, "batch_streams_per_gpu": a.streams // a.batch,
@@ -840,8 +933,12 @@ def main():
                 "errors": [r.get("error") for r in host_io_ranks if r and "error" in r],
                 "note": "every rank at the same time: one asynchronous context per GPU (child process), pinned host buffers, H2D / D2H on side "
                         "streams, every output frame returned to the host (PCIe-inclusive; never the bench `value`)"}
+        if content_counters:
+            out["content_counters"] = content_counters
         if world == 1 and a.workload == "hdr2160_24to120" and not a.no_other_workloads:
             out["other_workloads"] = other_workloads(a)
+        if world == 1 and a.workload == "hdr2160_24to120" and a.scene == "bench" and not a.no_content_legs:
+            out["content"] = content_legs(a)
         if not a.no_host_io and world == 1:
             try:
                 out["host_io"] = host_io_block(hdr, H, W, target)

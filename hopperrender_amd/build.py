@@ -53,7 +53,7 @@ def build_flow(force=False, debug_bounds=False):
     if debug_bounds:
         extra = extra + ["-DHF_DEBUG_BOUNDS"]
     srcs = [os.path.join(CSRC, f) for f in FLOW_SOURCES]
-    deps = srcs + [os.path.join(CSRC, f) for f in FLOW_HEADERS] + [os.path.join(INCLUDE, "hopperflow.h"), os.path.join(INCLUDE, "config.h")]
+    deps = srcs + [os.path.join(CSRC, f) for f in FLOW_HEADERS] + [os.path.join(INCLUDE, "hopperflow.h"), os.path.join(INCLUDE, "hopperflow_diag.h"), os.path.join(INCLUDE, "config.h")]
     if force or _stale(target, deps):
         objs = []
         hdrs = deps[len(srcs):]
@@ -76,7 +76,7 @@ def build_adapter(force=False):
     src = os.path.join(CSRC, "opticalFlowCalc.cpp")
     if not os.path.exists(src):
         return None
-    deps = [src, os.path.join(INCLUDE, "opticalFlowCalc.h"), os.path.join(INCLUDE, "hopperflow.h"), os.path.join(INCLUDE, "config.h")]
+    deps = [src, os.path.join(INCLUDE, "opticalFlowCalc.h"), os.path.join(INCLUDE, "hopperflow.h"), os.path.join(INCLUDE, "hopperflow_diag.h"), os.path.join(INCLUDE, "config.h")]
     if force or _stale(LIB_ADAPTER, deps + [LIB_FLOW]):
         _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", "-I", INCLUDE, src, "-o", LIB_ADAPTER,
               "-L", LIBDIR, "-lhopperflow", "-Wl,-rpath,$ORIGIN", "-Wl,--no-undefined"])

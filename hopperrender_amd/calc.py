@@ -224,6 +224,21 @@ class OpticalFlowCalc:
         capi.check(self._lib.hf_device_rcp(self._ctx, _ptr(x), _ptr(y), len(x)), self._ctx)
         return y
 
+    def countersEnable(self, on=True):
+        """hopperflow_diag.h hf_debug_counters_enable: device-side counters of the kernels' per-window / per-workgroup decisions."""
+        capi.check(self._lib.hf_debug_counters_enable(self._ctx, 1 if on else 0), self._ctx)
+
+    def counters(self, reset=False):
+        """{'warp_workgroups': {staged, interior_global, generic}, 'levels': {window: {'X': (windows, reused), 'Y': ...}}}"""
+        cc = capi.HfDebugCounters()
+        capi.check(self._lib.hf_debug_counters_read(self._ctx, C.byref(cc), 1 if reset else 0), self._ctx)
+        lv = {}
+        for k in range(16):
+            if cc.level_window_size[k] and (cc.level_windows[k][0] or cc.level_windows[k][1]):
+                lv[int(cc.level_window_size[k])] = {"X": (int(cc.level_windows[k][0]), int(cc.level_reused[k][0])),
+                                                     "Y": (int(cc.level_windows[k][1]), int(cc.level_reused[k][1]))}
+        return {"warp_workgroups": dict(zip(("staged", "interior_global", "generic"), [int(x) for x in cc.warp_workgroups])), "levels": lv}
+
     def stats(self):
         s = self._stats()
         return {k: getattr(s, k) for k, _ in s._fields_}
@@ -381,7 +396,7 @@ class FlowBatch:
             return []
         recs = (capi.HfTimelineRecord * n.value)()
         self._check(self._lib.hf_batch_timeline_read(self._b, recs, n.value, C.byref(n)))
-        return [(r.kernel.decode(), r.period, r.start_ms, r.end_ms) for r in recs[:n.value]]
+        return [(r.kernel.decode(), r.period, r.start_ms, r.start_ms + r.duration_ms) for r in recs[:n.value] if not (r.flags & 1)]
 
     def __len__(self):
         return self._lib.hf_batch_size(self._b)

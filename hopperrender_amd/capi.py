@@ -1,4 +1,4 @@
-"""ctypes binding of the C ABI (include/hopperflow.h) -- the same symbols a cgo/JNI/N-API host binds.
+"""ctypes binding of the C ABI (include/hopperflow.h + the diagnostics of include/hopperflow_diag.h) -- the same symbols a cgo/JNI/N-API host binds.
 
 There is NO fallback: if libhopperflow.so is missing or cannot be loaded, importing the product
 path raises (the library is built in-tree by hopperrender_amd.build / __graft_entry__.build()).
@@ -18,6 +18,7 @@ HF_FLAG_NO_TIMING = 0x200
 HF_FLAG_BATCH_NORMAL_PRIORITY = 0x800
 HF_FLAG_BATCH_EAGER_PLANES = 0x1000
 HF_FLAG_NO_SAD_REUSE = 0x2000
+HF_FLAG_SAD_REUSE_ALWAYS = 0x4000
 HF_MAX_PERIOD_OUTPUTS = 6
 
 (HF_OK, HF_ERR_INVALID_ARGUMENT, HF_ERR_NO_DEVICE, HF_ERR_OUT_OF_MEMORY, HF_ERR_HIP, HF_ERR_STATE) = (0, -1, -2, -3, -4, -5)
@@ -63,11 +64,18 @@ class HfStats(C.Structure):
                 ("res_scalar", C.c_int32), ("low_width", C.c_int32), ("low_height", C.c_int32),
                 ("frame_width", C.c_int32), ("frame_height", C.c_int32), ("input_stride", C.c_int32),
                 ("output_stride", C.c_int32), ("iterations", C.c_int32), ("initial_window", C.c_int32),
-                ("input_frame_bytes", C.c_uint64), ("output_frame_bytes", C.c_uint64), ("phase_plane_bytes", C.c_uint64)]
+                ("input_frame_bytes", C.c_uint64), ("output_frame_bytes", C.c_uint64), ("phase_plane_bytes", C.c_uint64),
+                ("sad_tables", C.c_int32), ("still_share", C.c_float)]
 
 
 class HfTimelineRecord(C.Structure):
-    _fields_ = [("kernel", C.c_char * 32), ("period", C.c_int32), ("reserved", C.c_int32), ("start_ms", C.c_double), ("end_ms", C.c_double)]
+    _fields_ = [("kernel", C.c_char * 32), ("period", C.c_int32), ("flags", C.c_int32), ("start_ms", C.c_double), ("end_ms", C.c_double),
+                ("duration_ms", C.c_double)]
+
+
+class HfDebugCounters(C.Structure):
+    _fields_ = [("warp_workgroups", C.c_uint32 * 3), ("reserved", C.c_uint32), ("level_windows", (C.c_uint32 * 2) * 16),
+                ("level_reused", (C.c_uint32 * 2) * 16), ("level_window_size", C.c_int32 * 16)]
 
 
 class HfProfile(C.Structure):
@@ -126,6 +134,9 @@ SIGNATURES = {
     "hf_batch_size": (_i, [_vp]),
     "hf_batch_timeline_enable": (_i, [_vp, _i, _i]),
     "hf_batch_timeline_read": (_i, [_vp, C.POINTER(HfTimelineRecord), _i, C.POINTER(_i)]),
+    "hf_batch_timeline_dropped": (C.c_uint64, [_vp]),
+    "hf_debug_counters_enable": (_i, [_vp, _i]),
+    "hf_debug_counters_read": (_i, [_vp, C.POINTER(HfDebugCounters), _i]),
     "hf_batch_last_error": (C.c_char_p, [_vp]),
     "hf_download_frame_device": (_i, [_vp, _vp]),
     "hf_set_output_buffer": (_i, [_vp, _vp]),

@@ -229,7 +229,8 @@ int hf_batch_calculate_optical_flow(hf_batch* b) {
     const int n = (int)b->members.size();
     if (hipSetDevice(l->device) != hipSuccess) return batch_fail(b, HF_ERR_HIP, "hipSetDevice failed");
     if (int rc = batch_check_flow_params(b)) return rc;
-    std::vector<int> key = {l->p.search_radius, l->p.delta_scalar, l->p.neighbor_scalar};
+    l->tab_mode = choose_tab_mode(b->members.data(), n);
+    std::vector<int> key = {l->p.search_radius, l->p.delta_scalar, l->p.neighbor_scalar, (int)l->tab_mode};
     for (hf_ctx* m : b->members) {
         if (int rc = leave_warp_stream(m)) return batch_fail(b, rc, m->err);
         key.push_back(m->ring_phase * 2 + m->blur_phase);
@@ -325,7 +326,8 @@ int hf_batch_timeline_enable(hf_batch* b, int max_launches, int skip_periods) {
     if (!b) return batch_fail(nullptr, HF_ERR_INVALID_ARGUMENT, "null batch");
     hf_ctx* l = b->members[0];
     if (hipSetDevice(l->device) != hipSuccess) return batch_fail(b, HF_ERR_HIP, "hipSetDevice failed");
-    if (max_launches < 0 || max_launches > (1 << 20) || skip_periods < 0) return batch_fail(b, HF_ERR_INVALID_ARGUMENT, "hf_batch_timeline_enable: max_launches outside [0, 2^20] or skip_periods < 0");
+    if (max_launches < 0 || max_launches > (1 << 20) || skip_periods < 0 || (max_launches > 0 && max_launches < 32))
+        return batch_fail(b, HF_ERR_INVALID_ARGUMENT, "hf_batch_timeline_enable: max_launches must be 0 or in [32, 2^20] (a period needs up to 32 free records), skip_periods >= 0");
     if (hipStreamSynchronize(b->stream) != hipSuccess) return batch_fail(b, HF_ERR_HIP, "hipStreamSynchronize failed");
     b->tl.active = false;
     b->tl.recs.clear();
@@ -354,7 +356,7 @@ int hf_batch_timeline_enable(hf_batch* b, int max_launches, int skip_periods) {
     b->tl.recs.reserve((size_t)max_launches);
     b->tl.capacity = (size_t)max_launches;
     b->tl.skip = skip_periods;
-    b->tl.active = max_launches >= 32;
+    b->tl.active = true;
     return HF_OK;
 }
 
@@ -364,6 +366,8 @@ int hf_batch_timeline_read(hf_batch* b, hf_timeline_record* out, int capacity, i
     hf_ctx* l = b->members[0];
     if (hipSetDevice(l->device) != hipSuccess) return batch_fail(b, HF_ERR_HIP, "hipSetDevice failed");
     if (hipStreamSynchronize(b->stream) != hipSuccess) return batch_fail(b, HF_ERR_HIP, "hipStreamSynchronize failed");
+    for (hipStream_t ws : b->warp_streams)      // HF_FLAG_DUAL_STREAM members: the per-member warps of an observed period run there
+        if (hipStreamSynchronize(ws) != hipSuccess) return batch_fail(b, HF_ERR_HIP, "hipStreamSynchronize (warp stream) failed");
     hipEvent_t ref = nullptr;
     {
         std::lock_guard<std::mutex> lock(g_tl_mutex);
@@ -375,18 +379,25 @@ int hf_batch_timeline_read(hf_batch* b, hf_timeline_record* out, int capacity, i
     const int n = *n_records < capacity ? *n_records : capacity;
     for (int i = 0; i < n; i++) {
         const hf_timeline::Rec& r = b->tl.recs[(size_t)i];
-        float t0 = 0.f, t1 = 0.f;
-        if (hipEventElapsedTime(&t0, ref, r.b) != hipSuccess || hipEventElapsedTime(&t1, ref, r.e) != hipSuccess)
-            return batch_fail(b, HF_ERR_HIP, "hf_batch_timeline_read: hipEventElapsedTime failed (record " + std::to_string(i) + ")");
+        float t0 = 0.f, t1 = 0.f, d = 0.f;
         hf_timeline_record& o = out[i];
         std::memset(&o, 0, sizeof(o));
         std::strncpy(o.kernel, r.name, sizeof(o.kernel) - 1);
         o.period = r.period;
+        if (hipEventElapsedTime(&t0, ref, r.b) != hipSuccess || hipEventElapsedTime(&t1, ref, r.e) != hipSuccess ||
+            hipEventElapsedTime(&d, r.b, r.e) != hipSuccess) {
+            (void)hipGetLastError();      // events of a launch that failed or never ran: flag the record, keep the others
+            o.flags = 1;
+            continue;
+        }
         o.start_ms = (double)t0;
         o.end_ms = (double)t1;
+        o.duration_ms = (double)d;
     }
     return HF_OK;
 }
+
+uint64_t hf_batch_timeline_dropped(const hf_batch* b) { return b ? b->tl.dropped : 0; }
 
 int hf_batch_sync(hf_batch* b) {
     if (!b) return batch_fail(nullptr, HF_ERR_INVALID_ARGUMENT, "null batch");

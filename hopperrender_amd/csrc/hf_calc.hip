@@ -35,6 +35,8 @@ int enqueue_flow_chain(hf_ctx* const* cs, int n, hipStream_t s) {
         f.delta_divisor = (uint32_t)(g.lh * g.lw * (g.hdr ? 6 : 10));  // :93 / HDR :93
         f.sadtab = m->sadtab; f.sad_nbx = m->sad_nbx; f.sad_nby = m->sad_nby;
         f.tables_base = m->tables; f.sums_base = m->sums;
+        f.counters = c->counters;                                     // (a batch counts in its leader's)
+        f.still_count = m->still_count;
     }
     hf::FlowLevel none{};
     hf::PendingArgmin pending[hf::kMaxFlowBatch] = {};   // large-window step whose argmin the next launch takes (hf_kernels.h)
@@ -63,10 +65,11 @@ int enqueue_flow_chain(hf_ctx* const* cs, int n, hipStream_t s) {
                 f.cur = m->levels[k];
                 f.prev = k ? m->levels[k - 1] : none;             // :68-69: the chain starts from zero offsets
                 f.prev2 = k > 1 ? m->levels[k - 2] : none;
+                f.level_index = k;
                 // SAD tables: written by every small level that has a successor's worth of blocks (windows 32 .. 4), read by every small
                 // level behind a small level
-                f.sad_write = m->sadtab && small && m->levels[k].window >= 4;
-                f.sad_read = m->sadtab && small && k > 0 && m->levels[k - 1].window <= 32;
+                f.sad_write = c->tab_mode && m->sadtab && small && m->levels[k].window >= 4;
+                f.sad_read = c->tab_mode && m->sadtab && small && k > 0 && m->levels[k - 1].window <= 32;
                 f.use_neighbors = use_neighbors;
                 f.axis = axis;
                 f.capture_delta = (k == 0 && axis == 0);          // :91
@@ -99,6 +102,8 @@ int enqueue_flow_chain(hf_ctx* const* cs, int n, hipStream_t s) {
         bb.s[i].blurred = m->blurred[0];
         bb.s[i].packed = m->blurred_xy[0];
         bb.s[i].zero = any_big ? m->sums : nullptr;
+        bb.s[i].still_count = m->still_count;
+        bb.s[i].still_out = m->still_count ? m->d_total_delta + 1 : nullptr;
     }
     hf::launch_blur_flow(g, bb, c->cfg.blur_radius, (int)(c->sums_bytes / sizeof(uint32_t)), s);  // :115-116
     HF_HIP(c, hipGetLastError());
@@ -106,6 +111,34 @@ int enqueue_flow_chain(hf_ctx* const* cs, int n, hipStream_t s) {
 }
 
 int enqueue_flow_chain(hf_ctx* c) { return enqueue_flow_chain(&c, 1, c->stream); }
+
+// SAD tables or not for the NEXT chain of these contexts (one decision for a batch: its launches are shared).  The tables pay when most
+// windows keep their offsets from level to level (tests/flow_reuse_model.py: 74-96 % on the bench scene) and cost 10-15 % of the pipeline
+// when hardly any does (every 16 x 16 block its own motion, a hard cut).  Content is coherent in time, so the chain's last kernel reports how
+// many windows of the 32-level chose d = 0 on both axes -- what the next level's reuse depends on -- and the host reads whatever report has
+// arrived (mapped memory, no synchronisation: one or two periods old) when it issues the next chain.  Smoothed over chains (a cut every few
+// periods does not flip it), with hysteresis.  Results are identical either way; only the kernels differ.  HF_FLAG_SAD_REUSE_ALWAYS pins it on.
+bool choose_tab_mode(hf_ctx* const* cs, int n) {
+    hf_ctx* l = cs[0];
+    if (!l->sadtab) return false;
+    if (l->cfg.flags & HF_FLAG_SAD_REUSE_ALWAYS) return true;
+    float sum = 0.f;
+    int have = 0;
+    for (int i = 0; i < n; i++) {
+        hf_ctx* m = cs[i];
+        const uint32_t raw = m->h_total_delta ? ((volatile uint32_t*)m->h_total_delta)[1] : 0xFFFFFFFFu;
+        int n32 = 0;
+        for (const hf::FlowLevel& L : m->levels) if (L.window == 32) n32 = L.nwx * L.nwy;
+        if (raw != 0xFFFFFFFFu && n32 > 0) {
+            const float share = (float)raw / (float)n32;
+            m->still_share = m->still_share < 0.f ? share : 0.5f * m->still_share + 0.5f * share;
+        }
+        if (m->still_share >= 0.f) { sum += m->still_share; have++; }
+    }
+    if (!have) return l->tab_mode;
+    const float share = sum / (float)have;
+    return l->tab_mode ? share >= 0.30f : share >= 0.45f;
+}
 
 // Deferred phase planes (hf_batch_run_period): the chain reads the FULL plane of frame N-1.  Members whose pp[1] still holds only
 // the grid samples -- no warp launch took the build up -- get it from the stand-alone plane kernel now, in one launch.
@@ -261,6 +294,7 @@ void fill_period(hf_ctx* c, int n, const float* t, void* const* outs, hf::WarpPe
     p.flow = c->blurred[flow_index]; p.flow_xy = c->blurred_xy[flow_index];
     p.black = c->p.black_level * scale; p.white = c->p.white_level * scale;
     p.n_out = n;
+    p.counters = c->counters;
     for (int i = 0; i < n; i++) { p.ts[i] = t[i]; p.outs[i] = outs[i] ? outs[i] : c->out_frame; }
 }
 
@@ -310,10 +344,12 @@ int hf_calculate_optical_flow(hf_ctx* c) {
 
     int span = -1;
     if (c->cfg.flags & HF_FLAG_NO_GRAPH) {
+        c->tab_mode = choose_tab_mode(&c, 1);
         span = span_begin(c, 2);
         if (int rc = enqueue_flow_chain(c)) return rc;
     } else {
-        const auto key = std::make_tuple(c->ring_phase, c->blur_phase, c->p.search_radius, c->p.delta_scalar, c->p.neighbor_scalar);
+        c->tab_mode = choose_tab_mode(&c, 1);
+        const auto key = std::make_tuple(c->ring_phase, c->blur_phase, c->p.search_radius, c->p.delta_scalar, c->p.neighbor_scalar, (int)c->tab_mode);
         auto it = c->graphs.find(key);
         if (it == c->graphs.end()) {
             hipGraph_t graph = nullptr;

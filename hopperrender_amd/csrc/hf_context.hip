@@ -311,7 +311,11 @@ int hf_create(const hf_config* cfg, hf_ctx** out_ctx) {
         HF_TRY(hipMalloc((void**)&c->blurred_xy[i], c->plane_elems * sizeof(uint32_t)));
         HF_TRY(hipMemsetAsync(c->blurred_xy[i], 0, c->plane_elems * sizeof(uint32_t), c->stream));
     }
-    if (c->sadtab_bytes) HF_TRY(hipMalloc((void**)&c->sadtab, c->sadtab_bytes));   // (every entry is written before it is read inside a chain)
+    if (c->sadtab_bytes) {
+        HF_TRY(hipMalloc((void**)&c->sadtab, c->sadtab_bytes));
+        HF_TRY(hipMalloc((void**)&c->still_count, 64));
+        HF_TRY(hipMemsetAsync(c->still_count, 0, 64, c->stream));
+    }   // (every entry is written before it is read inside a chain)
     HF_TRY(hipMalloc((void**)&c->sums, c->sums_bytes));
     HF_TRY(hipMemsetAsync(c->sums, 0, c->sums_bytes, c->stream));
     HF_TRY(hipMalloc((void**)&c->d_probe, 64 * sizeof(float)));
@@ -319,6 +323,7 @@ int hf_create(const hf_config* cfg, hf_ctx** out_ctx) {
     // readback in the middle of the chain, opticalFlowCalcSDR.cpp:91-94)
     HF_TRY(hipHostMalloc((void**)&c->h_total_delta, 64, hipHostMallocMapped));
     *c->h_total_delta = 0;
+    c->h_total_delta[1] = 0xFFFFFFFFu;                  // (no chain has published its content hint yet)
     HF_TRY(hipHostGetDevicePointer((void**)&c->d_total_delta, c->h_total_delta, 0));
     HF_TRY(hipEventCreate(&c->ev_upload));
     HF_TRY(hipEventCreate(&c->ev_flow_end));
@@ -344,6 +349,8 @@ void hf_destroy(hf_ctx* c) {
     for (int i = 0; i < 2; i++) { if (c->blurred[i]) hipFree(c->blurred[i]); if (c->blurred_xy[i]) hipFree(c->blurred_xy[i]); }
     if (c->sums) hipFree(c->sums);
     if (c->sadtab) hipFree(c->sadtab);
+    if (c->still_count) hipFree(c->still_count);
+    if (c->counters) hipFree(c->counters);
     if (c->d_probe) hipFree(c->d_probe);
     if (c->h_total_delta) hipHostFree(c->h_total_delta);
     for (auto& sp : c->spans) { hipEventDestroy(sp.b); hipEventDestroy(sp.e); }
@@ -406,6 +413,8 @@ int hf_get_stats(hf_ctx* c, hf_stats* out) {
     out->input_frame_bytes = c->in_bytes;
     out->output_frame_bytes = c->out_bytes;
     out->phase_plane_bytes = c->pl.bytes;
+    out->sad_tables = c->sadtab && (c->batch ? c->batch->members[0]->tab_mode : c->tab_mode) ? 1 : 0;
+    out->still_share = c->still_share;
     return HF_OK;
 }
 
@@ -493,6 +502,47 @@ int hf_timer_end(hf_ctx* c, float* elapsed_ms) {
     HF_HIP(c, hipEventRecord(c->ev_user1, c->stream));
     HF_HIP(c, hipEventSynchronize(c->ev_user1));
     HF_HIP(c, hipEventElapsedTime(elapsed_ms, c->ev_user0, c->ev_user1));
+    return HF_OK;
+}
+
+int hf_debug_counters_enable(hf_ctx* c, int on) {
+    HF_CHECK_CTX(c);
+    if (int rc = set_device(c)) return rc;
+    if (int rc = sync_ctx(c)) return rc;
+    // the pointer is part of every captured launch: cached graphs of this context and of its batch are stale now
+    for (auto& kv : c->graphs) hipGraphExecDestroy(kv.second);
+    c->graphs.clear();
+    if (c->batch) {
+        for (auto& kv : c->batch->graphs) hipGraphExecDestroy(kv.second);
+        c->batch->graphs.clear();
+    }
+    if (on) {
+        if (!c->counters) HF_HIP(c, hipMalloc((void**)&c->counters, hf::kCounterWords * sizeof(uint32_t)));
+        HF_HIP(c, hipMemsetAsync(c->counters, 0, hf::kCounterWords * sizeof(uint32_t), c->stream));
+        return sync_ctx(c);
+    }
+    if (c->counters) { hipFree(c->counters); c->counters = nullptr; }
+    return HF_OK;
+}
+
+int hf_debug_counters_read(hf_ctx* c, hf_debug_counters* out, int reset) {
+    HF_CHECK_CTX(c);
+    if (!out) return fail(c, HF_ERR_INVALID_ARGUMENT, "hf_debug_counters_read: null");
+    if (!c->counters) return fail(c, HF_ERR_STATE, "hf_debug_counters_read: hf_debug_counters_enable(ctx, 1) first");
+    if (int rc = set_device(c)) return rc;
+    if (int rc = sync_ctx(c)) return rc;
+    uint32_t w[hf::kCounterWords];
+    HF_HIP(c, hipMemcpy(w, c->counters, sizeof(w), hipMemcpyDeviceToHost));
+    if (reset) HF_HIP(c, hipMemset(c->counters, 0, sizeof(w)));
+    memset(out, 0, sizeof(*out));
+    for (int i = 0; i < 3; i++) out->warp_workgroups[i] = w[hf::kCounterWarp + i];
+    for (int k = 0; k < 16; k++) {
+        for (int ax = 0; ax < 2; ax++) {
+            out->level_windows[k][ax] = w[hf::kCounterLevels + 4 * k + 2 * ax];
+            out->level_reused[k][ax] = w[hf::kCounterLevels + 4 * k + 2 * ax + 1];
+        }
+        out->level_window_size[k] = k < (int)c->levels.size() && k < c->last_iterations ? c->levels[(size_t)k].window : 0;
+    }
     return HF_OK;
 }
 

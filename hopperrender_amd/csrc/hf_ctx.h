@@ -35,6 +35,7 @@
 
 #include "../../include/config.h"
 #include "../../include/hopperflow.h"
+#include "../../include/hopperflow_diag.h"
 #include "hf_kernels.h"
 
 namespace hfi {
@@ -90,6 +91,12 @@ struct hf_ctx {
     uint32_t* sadtab = nullptr;                        // SAD tables (hf_flow.hip): [2][sad_nby][sad_nbx][8] u16 pairs; nullptr: HF_FLAG_NO_SAD_REUSE
     size_t sadtab_bytes = 0;
     int sad_nbx = 0, sad_nby = 0;
+    // Content hint of the SAD tables: how many windows of the 32-level chose d = 0 on both axes in the last chains (device counter, published
+    // by the chain's last kernel into h_total_delta[1]); below ~30 % of them the tables cost more than they return and the chain runs without
+    bool tab_mode = true;                              // the next chain keeps SAD tables
+    float still_share = -1.f;                          // smoothed share of such windows (< 0: no chain has reported yet)
+    uint32_t* still_count = nullptr;
+    uint32_t* counters = nullptr;                      // diagnostic counters (hf_debug_counters_enable), device, hf::kCounterWords u32
     uint32_t* sums = nullptr;                          // [kMaxSteps][n_windows_max][16]
     size_t sums_bytes = 0;
     size_t sums_stride = 0;                            // elements per step
@@ -125,7 +132,7 @@ struct hf_ctx {
     hipEvent_t ev_user0 = nullptr, ev_user1 = nullptr;
     bool upload_recorded = false, flow_timing_pending = false, warp_started = false;
 
-    std::map<std::tuple<int, int, int, int, int>, hipGraphExec_t> graphs;
+    std::map<std::tuple<int, int, int, int, int, int>, hipGraphExec_t> graphs;
 
     // HF_FLAG_PROFILE: event pairs around warp / copy / flow-chain launches
     struct Span { hipEvent_t b, e; int kind; hipStream_t stream; int frames = 1; };
@@ -190,6 +197,7 @@ int util_copy(int device_index, void* dst, const void* src, size_t bytes, hipMem
 // hf_calc.hip
 int enqueue_flow_chain(hf_ctx* const* cs, int n, hipStream_t s);
 int enqueue_flow_chain(hf_ctx* c);
+bool choose_tab_mode(hf_ctx* const* cs, int n);
 int ensure_older_planes(hf_ctx* const* cs, int n, hipStream_t s);
 void finish_flow_timing(hf_ctx* c);
 int enter_warp_stream(hf_ctx* c);

@@ -702,7 +702,7 @@ __device__ __forceinline__ int resolve_pending(const Geom& g, const FlowStep& a,
 struct FlowPtrs {           // what differs between the members of a batch: six allocations (every table / sum pointer is member 0's + a rebase)
     const uint32_t *pp1, *pp2;
     int16_t* tables;
-    uint32_t *sums, *total_delta, *sadtab;
+    uint32_t *sums, *total_delta, *sadtab, *still_count;
 };
 struct FlowBatchArgs {
     int n;
@@ -721,14 +721,14 @@ static FlowBatchArgs pack_batch(const FlowBatch& b, int tiles_x, int tiles_y) {
     k.common = b.s[0];
     for (int i = 0; i < b.n; i++) {
         const FlowStep& f = b.s[i];
-        k.m[i] = FlowPtrs{f.pp1, f.pp2, f.tables_base, f.sums_base, f.total_delta, f.sadtab};
+        k.m[i] = FlowPtrs{f.pp1, f.pp2, f.tables_base, f.sums_base, f.total_delta, f.sadtab, f.still_count};
     }
     return k;
 }
 __device__ __forceinline__ FlowStep member_step(const FlowBatchArgs& k, int i) {
     FlowStep a = k.common;
     const FlowPtrs& p = k.m[i];
-    a.pp1 = p.pp1; a.pp2 = p.pp2; a.total_delta = p.total_delta; a.sadtab = p.sadtab;
+    a.pp1 = p.pp1; a.pp2 = p.pp2; a.total_delta = p.total_delta; a.sadtab = p.sadtab; a.still_count = p.still_count;
     const ptrdiff_t dt = p.tables - a.tables_base, ds = p.sums - a.sums_base;   // (scalar arithmetic; null stays null)
     auto rt = [dt](int16_t* x) { return x ? x + dt : x; };
     a.cur.tx = rt(a.cur.tx); a.cur.ty = rt(a.cur.ty); a.prev.tx = rt(a.prev.tx); a.prev.ty = rt(a.prev.ty);
@@ -892,6 +892,7 @@ __device__ __forceinline__ void flow_level_small_body(const Geom& g, const FlowS
         a.cur.tx[wy * a.cur.nwx + wx] = (int16_t)off[0];
         a.cur.ty[wy * a.cur.nwx + wx] = (int16_t)off[1];
         if (a.capture_delta && wx == 0 && wy == 0) *a.total_delta = captured / a.delta_divisor;   // opticalFlowCalcSDR.cpp:91-94
+        if (WS == 32 && a.still_count && off[0] == wc.ox && off[1] == wc.oy) atomicAdd(a.still_count, 1u);   // content hint (hf_calc.hip)
     }
 }
 
@@ -1004,6 +1005,15 @@ __device__ __forceinline__ void flow_level_tab_body(const Geom& g, const FlowSte
     for (int axis = 0; axis < 2; axis++) {
         bool reuse = zy && (axis == 0 ? zx : off[0] == wc.ox);
         if constexpr (G == 64) reuse = __builtin_amdgcn_readfirstlane((int)reuse) != 0;      // one window per wave
+        if (a.counters) {     // diagnostics (hf_debug_counters): windows of this wave, those that reuse
+            const bool lead = WS == 32 ? tid == 0 : G == 2 ? (lane & M::XM) == 0 : (lane & (G - 1)) == 0;
+            const uint64_t mw = __builtin_amdgcn_ballot_w64(lead), mr = __builtin_amdgcn_ballot_w64(lead && reuse);
+            if (lane == 0 && mw) {
+                uint32_t* const c = a.counters + kCounterLevels + 4 * (a.level_index & 15) + 2 * axis;
+                atomicAdd(c, (uint32_t)__builtin_popcountll(mw));
+                if (mr) atomicAdd(c + 1, (uint32_t)__builtin_popcountll(mr));
+            }
+        }
         flow_v4* const tab = tab0 + axis * tab_axis;
         uint32_t tot[NOWN];
         int first = 0;
@@ -1110,6 +1120,7 @@ __device__ __forceinline__ void flow_level_tab_body(const Geom& g, const FlowSte
     if (leader) {
         a.cur.tx[wy * a.cur.nwx + wx] = (int16_t)off[0];
         a.cur.ty[wy * a.cur.nwx + wx] = (int16_t)off[1];
+        if (WS == 32 && a.still_count && off[0] == wc.ox && off[1] == wc.oy) atomicAdd(a.still_count, 1u);   // content hint (hf_calc.hip)
         if (a.capture_delta && wx == 0 && wy == 0) *a.total_delta = captured / a.delta_divisor;   // opticalFlowCalcSDR.cpp:91-94
     }
 }

@@ -84,6 +84,10 @@ inline FastDiv make_fastdiv(uint32_t d, uint64_t max_u) {
 __device__ __forceinline__ uint32_t fastdiv(uint32_t u, const FastDiv f) { return f.magic ? __umulhi(u, f.magic) : f.d > 1 ? u / f.d : u; }
 #endif
 
+// Device-side diagnostic counters of a context (hf_debug_counters_enable): u32 [kCounterWords]
+//   [0 .. 2]                       period-warp workgroups by path: staged window, interior-global, generic (warp_wg_kernel)
+//   [8 + 4 k + 2 axis + {0, 1}]    level k of the chain: windows of its table tiles, those of them that reused their SAD vectors
+constexpr int kCounterWarp = 0, kCounterLevels = 8, kCounterWords = 8 + 4 * 16;
 constexpr int kMaxFlowBatch = 32;      // contexts per hf_batch (FlowBatch below)
 constexpr int kMaxWarpBatch = 16;      // members per fused warp launch (its per-member arguments are 168 bytes; a launch carries 4 KB)
 constexpr int kMaxWarpOutputs = 6;     // outputs of one source period at 24 -> 120 fps (HopperRender.cpp:944-948)
@@ -149,6 +153,9 @@ struct FlowStep {
     int sad_nbx, sad_nby;
     int sad_read;            // the previous level's launch left valid tables for every full tile (this is not the chain's first small level)
     int sad_write;           // this launch refreshes them where it computes (windows 32 .. 4)
+    uint32_t* still_count;   // device: windows of the 32-level that chose d = 0 on both axes in this chain (the content hint, hf_calc.hip), or nullptr
+    uint32_t* counters;      // diagnostic counters (hopperflow_diag.h hf_debug_counters, layout kCounter* below), nullptr: none
+    int level_index;         // k of this level (its counter slot)
     // allocation bases of the per-level tables and of the window sums: a batched launch carries member 0's FlowStep and rebases it
     int16_t* tables_base;
     uint32_t* sums_base;
@@ -168,6 +175,8 @@ struct BlurItem {
     int16_t* blurred;        // out [2][lh][lw]
     uint32_t* packed;        // out x | y << 16 per grid point (what the fast warp kernel reads)
     uint32_t* zero;          // window sums the (last) kernel of the chain clears for the next chain, or nullptr
+    uint32_t* still_count;   // FlowStep::still_count of the chain: published to *still_out (mapped host memory) and cleared, or nullptr
+    uint32_t* still_out;
 };
 struct BlurBatch {
     int n;
@@ -210,6 +219,7 @@ struct WarpPeriod {
     float ts[kMaxWarpOutputs];
     float black, white;      // already scaled for HDR
     uint32_t* plane21 = nullptr;   // deferred phase plane: build the full plane of frame21 here if the launch can (see below)
+    uint32_t* counters = nullptr;  // diagnostic counters of the launch (member 0's are used), nullptr: none
 };
 // pl + planes_built[n] (optional): members whose period carries a plane21 pointer get the full phase plane of their frame21 built
 // by the launch itself when it is the workgroup-staged kernel and geometry / alignment allow (planes_built[m] says so); everyone

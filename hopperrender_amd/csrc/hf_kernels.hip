@@ -80,6 +80,10 @@ __global__ __launch_bounds__(256) void blur_flow_kernel(const BlurBatch batch, i
     uint32_t* __restrict__ packed = it.packed;
     uint32_t* __restrict__ zero = it.zero;
     const int r = RFIX ? RFIX : r_arg;
+    if (it.still_count && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {   // the chain's content hint: out to the host, cleared for the next chain
+        *it.still_out = *it.still_count;
+        *it.still_count = 0u;
+    }
     if (zero) {   // the refinement steps are done with the window sums: clear them for the next chain
         const int nthreads = gridDim.x * gridDim.y * 256;
         for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < zero_count; i += nthreads) zero[i] = 0u;
@@ -306,6 +310,7 @@ struct WarpArgs {
 // selects the member, so a batch of 8 pairs is one bandwidth-bound launch instead of 8 serialised ones.
 struct WarpBatchArgs {
     int n;
+    uint32_t* counters;     // diagnostic counters of the launch (hf_kernels.h kCounterWarp), nullptr: none
     WarpArgs s[kMaxWarpBatch];
 };
 
@@ -863,6 +868,7 @@ struct PlaneOut {
     PhaseLayout pl;
     int blocks;                          // plane-building workgroups per super row (0: the launch builds no planes)
     FastDiv per_member, per_sr, wpr;     // unit index -> (member, super row, block): scalar divisions (hf_kernels.h)
+    uint32_t* counters;                  // diagnostic counters (hf_kernels.h kCounterWarp), nullptr: none
 };
 template <typename E, int GROUP, int ROWS, int MODE, int VB, bool DW>
 __global__ __launch_bounds__(64 * warp_max_waves(sizeof(E), GROUP, VB)) void warp_fast_kernel(const Geom g, const WarpBatchArgs batch, int y_groups, int out_chunk, int n_chunks) {
@@ -973,7 +979,7 @@ struct WgShared {                                  // static LDS of warp_wg_kern
 
 template <typename E, int MODE, int CZ, int NW, int ROWS>
 __device__ __forceinline__ void warp_wg_body(const Geom& g, const WarpArgs& a, const int tx0, const int ty0, const bool lane_valid, const int wave,
-                                             unsigned char* const lds, WgShared<NW>& sh) {
+                                             unsigned char* const lds, WgShared<NW>& sh, uint32_t* const counters) {
     constexpr int VEC = 16 / (int)sizeof(E), NDW = 4, CHUNKS = wg_chunks(NW * ROWS / 2), SZ = (int)sizeof(E);
     constexpr int TW = kWarpTX * VEC, TH = NW * kWarpTY * ROWS, NT = 64 * NW;      // tile of the workgroup (elements x rows), its threads
     constexpr bool need_a = MODE != 1, need_b = MODE != 0;
@@ -1085,6 +1091,7 @@ __device__ __forceinline__ void warp_wg_body(const Geom& g, const WarpArgs& a, c
     const uint32_t base = ((uint32_t)(cy0 + kExtY) << 16) | (uint32_t)((cx0 + kExtX) * SZ);
     const int ci = (((cy0 - ty0) >> rs) << lgx) | ((cx0 - tx0) >> lcw);
     HF_DBG_CHECK(!wg_ok || (ci >= 0 && ci < kWgCells), 211);
+    if (counters && threadIdx.x == 0) atomicAdd(counters + kCounterWarp + (wg_ok ? 0 : (runs_ok && wg_in && full) ? 1 : 2), 1u);
     if (!wg_ok) {   // workgroup-uniform: no barrier follows
         if (runs_ok && wg_in && full) {
             // every run of the workgroup is interior, only its window does not fit (fast or diverging motion): the global path straight
@@ -1289,8 +1296,8 @@ __global__ __launch_bounds__(64 * NW) void warp_wg_kernel(const Geom g, const Wa
     const int cx0 = tx0 + (lane & (kWarpTX - 1)) * VEC;
     const int rg = trow * kWarpTY + (lane / kWarpTX);
     const bool lane_valid = trow < (chroma ? uv_tiles : y_tiles) && cx0 < g.W && rg < (chroma ? uv_groups : y_groups);
-    if (chroma) warp_wg_body<E, MODE, 1, NW, ROWS>(g, a, tx0, ty0, lane_valid, wave, wg_windows, sh);
-    else warp_wg_body<E, MODE, 0, NW, ROWS>(g, a, tx0, ty0, lane_valid, wave, wg_windows, sh);
+    if (chroma) warp_wg_body<E, MODE, 1, NW, ROWS>(g, a, tx0, ty0, lane_valid, wave, wg_windows, sh, po.counters);
+    else warp_wg_body<E, MODE, 0, NW, ROWS>(g, a, tx0, ty0, lane_valid, wave, wg_windows, sh, po.counters);
 }
 
 template <typename E, int VEC, bool ALIGNED>
@@ -1441,6 +1448,7 @@ static bool launch_warp_fast(const Geom& g, const WarpBatchArgs& b, hipStream_t 
         // deferred phase planes: members that ask for one (plane21) get it from this launch if geometry and alignment allow
         WarpBatchArgs bb = b;
         PlaneOut po{};
+        po.counters = b.counters;
         bool emit = pl && plane_emission_geometry(g, *pl);
         for (int m = 0; m < bb.n; m++)
             if (!emit || (((uintptr_t)bb.s[m].frame21) & 15) != 0) bb.s[m].plane21 = nullptr;
@@ -1506,7 +1514,7 @@ template <typename E>
 static void launch_warp_t(const Geom& g, const WarpArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
     constexpr int VEC = 16 / sizeof(E);  // generic kernel: 16-byte stores
     WarpBatchArgs b;
-    b.n = 1; b.s[0] = a;
+    b.n = 1; b.counters = nullptr; b.s[0] = a;
     if (launch_warp_fast_any<E>(g, b, stream, ev0, ev1)) return;
     const bool aligned = (g.out_stride % VEC) == 0 && (((uintptr_t)a.out) & 15) == 0;
     const dim3 grd((g.W + 64 * VEC - 1) / (64 * VEC), (g.H + (g.H >> 1) + 3) / 4);
@@ -1527,6 +1535,7 @@ void launch_warp(const Geom& g, const void* frame12, const void* frame21, const 
 // Launch arguments of members [first, first + b.n) of a set of periods; false: a member's n_out is out of range.
 static bool fill_warp_batch(const WarpPeriod* periods, int n, int first, int mode, WarpBatchArgs& b) {
     b.n = n - first < kMaxWarpBatch ? n - first : kMaxWarpBatch;
+    b.counters = periods[0].counters;
     for (int m = 0; m < b.n; m++) {
         const WarpPeriod& p = periods[first + m];
         if (p.n_out < 1 || p.n_out > kMaxWarpOutputs) return false;

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HF_ABI_VERSION 5
+#define HF_ABI_VERSION 6
 
 typedef struct hf_ctx hf_ctx;
 
@@ -69,6 +69,8 @@ typedef enum hf_output_mode {
                                               plane comes out of the next period's warp launch -- see hf_batch_run_period) */
 #define HF_FLAG_NO_SAD_REUSE 0x2000 /* flow chain: recompute every candidate SAD at every step, as the reference does, instead of summing the per-block SAD
                                      * tables of the last step that sampled the same positions (same results; debug / A-B timing) */
+#define HF_FLAG_SAD_REUSE_ALWAYS 0x4000 /* flow chain: keep the SAD tables whatever the content (default: the chain reports how many windows kept their
+                                         * offsets and the next chains drop the tables while hardly any does -- same results, other kernels) */
 #define HF_FLAG_NO_TIMING 0x200 /* do not record the events behind m_ofcCalcTime / m_warpCalcTime (hf_stats times stay 0).
                                    Every timing event is a barrier packet on the stream: measured 5-6 us each between
                                    back-to-back kernels, ~15 us per source period in a throughput pipeline */
@@ -124,6 +126,9 @@ typedef struct hf_stats {
     uint64_t input_frame_bytes; /* bytes updateFrame reads  = bpp*(H*S_in + (H/2)*S_in)  (:20) */
     uint64_t output_frame_bytes;/* bytes downloadFrame writes = bpp*(H*S_out + (H/2)*S_out) (:33) */
     uint64_t phase_plane_bytes; /* bytes of one phase plane (this build's re-laid copy of a frame) */
+    int32_t sad_tables;         /* 1: the last flow calc kept SAD tables (exact cross-step reuse, csrc/hf_flow.hip), 0: it recomputed every step */
+    float still_share;          /* smoothed share of 32-windows that chose d = 0 on both axes in the last chains (what switches the tables off on
+                                 * content where hardly any window keeps its offsets; < 0: no report yet) */
 } hf_stats;
 
 /* ---- lifecycle: constructor / destructor (opticalFlowCalcSDR.cpp:206-325, :185-204) ---- */
@@ -242,24 +247,6 @@ int hf_batch_run_period(hf_batch* batch, const void* const* device_frames, int c
 /* 1: hf_batch_run_period defers the phase planes of this batch (see above); 0: it builds them eagerly. */
 int hf_batch_defers_planes(const hf_batch* batch);
 int hf_batch_sync(hf_batch* batch);   /* hf_sync() of every member */
-/* Timeline of a batch WITHOUT a profiler: while it is on, every dispatch hf_batch_run_period issues (grid samples, fused period warp, each
- * launch of the refinement chain -- issued one by one instead of as a graph replay -- and the blur) carries the start / stop events of
- * the dispatch itself (hipExtLaunchKernelGGL), i.e. the timestamps a kernel trace would read, on the clock of the device and relative to
- * ONE reference per process and device, so the records of several batches (streams) line up.  (rocprofv3's kernel trace costs enough per
- * dispatch to make four batch streams host-bound: its timeline is not the un-profiled run's.)  The first skip_periods calls of
- * hf_batch_run_period after _enable pass unobserved (so a driver can arm the timeline before its timed region -- _enable synchronises the
- * batch's stream -- and have it record in the middle); it switches itself off when max_launches records are taken (a period needs
- * about 16).  hf_batch_timeline_enable(batch, 0, 0) switches it off and frees the events; _read
- * synchronises the batch's stream and returns the records taken so far (*n_records = how many exist; at most `capacity` are written). */
-typedef struct hf_timeline_record {
-    char kernel[32];      /* "grid_samples", "warp_period", "plane", "large_windows_x" / "_y", "level_32" ... "level_2", "blur" */
-    int32_t period;       /* hf_batch_run_period calls since the recording started */
-    int32_t reserved;
-    double start_ms;      /* start / end of the dispatch, milliseconds since the process's reference event on this device */
-    double end_ms;
-} hf_timeline_record;
-int hf_batch_timeline_enable(hf_batch* batch, int max_launches, int skip_periods);
-int hf_batch_timeline_read(hf_batch* batch, hf_timeline_record* out, int capacity, int* n_records);
 int hf_batch_size(const hf_batch* batch);
 const char* hf_batch_last_error(const hf_batch* batch);   /* batch == NULL: error of the last failed hf_batch_create (per thread) */
 
@@ -280,32 +267,6 @@ int hf_write_blurred_flow(hf_ctx* ctx, int idx, const int16_t* host_in);
  * copy of a frame that replaces the strided sampling of calcDeltaSumsKernelSDR.h:78-100).  *complete = 0: the
  * plane holds only its grid samples so far (deferred build, hf_batch_run_period). */
 int hf_read_phase_plane(hf_ctx* ctx, int ring_slot, void* host_out, int* complete);
-
-/* Device debug build (`python -m hopperrender_amd.build --debug-bounds` -> libhopperflow_dbg.so, -DHF_DEBUG_BOUNDS): every gather index of
- * the kernels -- frame, phase-plane, flow-table and LDS-window reads -- is checked against its buffer and violations are recorded on the
- * device (the only device-side memory check there can be where GPU AddressSanitizer is unavailable; the reference's own out-of-range
- * case is the single reflection of calcDeltaSumsKernelSDR.h:86-95).  hf_debug_bounds_violations synchronises the device and returns the
- * number of violations since the last reset and site / block / thread / source line of the first; hf_debug_bounds_selftest issues 64
- * out-of-range indices (site 999) and checks that exactly those were recorded.  Both return HF_ERR_STATE in the product build, which
- * compiles the checks away. */
-int hf_debug_bounds_violations(hf_ctx* ctx, uint32_t* count, uint32_t first[4], int reset);
-int hf_debug_bounds_selftest(hf_ctx* ctx);
-/* v_rcp_f32 of the device for n <= 32 values.  The reference's apply_levels* divide through it when
- * built by AMD OpenCL (x / y -> x * rcp(y)); CPU checkers use this to reproduce levels bit-exactly. */
-int hf_device_rcp(hf_ctx* ctx, const float* host_in, float* host_out, int n);
-
-/* Clock of the shader array RIGHT NOW, in MHz: one wave compares the shader-cycle counter with the 100 MHz reference counter over
- * duration_us microseconds, on a stream of its own, while whatever else the process has queued keeps running (blocks until the probe
- * has run).  The chip lowers its clock under load by a device-dependent amount; bench.py samples this behind its last warm-up step (the same load, outside the timed region)
- * so that lines from different boxes can be normalised. */
-int hf_clock_probe(int device_index, int duration_us, double* shader_mhz);
-/* What this device's HBM sustains for a plain streaming copy of `bytes` bytes (16 bytes per lane, non-temporal loads and stores; best of
- * `repeats` passes; read + write bytes per second, GB/s): the yardstick a bandwidth-bound pipeline should be held against on THIS box. */
-int hf_hbm_copy_probe(int device_index, size_t bytes, int repeats, double* read_plus_write_GBps);
-
-/* ---- measurement: HIP events on ctx's own stream (torch events cannot see this stream) ---- */
-int hf_timer_begin(hf_ctx* ctx);
-int hf_timer_end(hf_ctx* ctx, float* elapsed_ms); /* synchronises on the end event */
 
 /* Per-kernel device time accumulated since the last hf_reset_profile() (needs HF_FLAG_PROFILE). */
 typedef struct hf_profile {

@@ -1,4 +1,4 @@
-"""CPU: the C-ABI library builds, loads, and exports every symbol include/hopperflow.h declares; the ctypes
+"""CPU: the C-ABI library builds, loads, and exports every symbol include/hopperflow.h and include/hopperflow_diag.h declare; the ctypes
 table covers them all; no compute call is made (no GPU here)."""
 import ctypes
 import os
@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def declared_symbols():
-    src = open(os.path.join(ROOT, "include", "hopperflow.h")).read()
+    src = open(os.path.join(ROOT, "include", "hopperflow.h")).read() + open(os.path.join(ROOT, "include", "hopperflow_diag.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(hf_[a-z0-9_]+)\s*\(", src)))
 
@@ -26,7 +26,7 @@ def test_every_declared_symbol_is_exported_and_bound(native_lib):
     assert not (set(syms) - set(capi.SIGNATURES)), f"not bound in capi.py: {sorted(set(syms) - set(capi.SIGNATURES))}"
     for s in syms:
         assert getattr(native_lib, s) is not None
-    assert native_lib.hf_abi_version() == 5   # round 5: hf_batch_timeline_enable / _read, hf_clock_probe (round 4: hf_debug_bounds_*; round 3: hf_batch_run_period / hf_batch_sync, hf_select_device, device_index = -1)
+    assert native_lib.hf_abi_version() == 6   # round 6: hopperflow_diag.h (hf_debug_counters_*, hf_timeline_record.duration_ms); round 5: hf_batch_timeline_enable / _read, hf_clock_probe (round 4: hf_debug_bounds_*; round 3: hf_batch_run_period / hf_batch_sync, hf_select_device, device_index = -1)
 
 
 def test_struct_layouts_match_the_header(native_lib, tmp_path):
@@ -103,12 +103,12 @@ def test_bench_names_kernels_the_library_contains():
     import bench
     from hopperrender_amd import build, capi
     build.build_all()
-    for hdr, prefix in bench.WARP_SYMBOL_PREFIX.items():
-        name = bench.warp_symbol(hdr)
+    for (hdr, big), prefix in bench.WARP_SYMBOL_PREFIX.items():
+        name = bench.warp_symbol(hdr, *((2160, 3840) if big else (1080, 1920)))
         assert name.startswith(prefix) and name.endswith(">") and "(" not in name
         assert name in subprocess.run(["nm", "-C", capi.lib_path()], capture_output=True, text=True, check=True).stdout
     with pytest.raises(RuntimeError):
         capi.kernel_symbol("no_such_kernel<")
     with pytest.raises(RuntimeError):
         capi.kernel_symbol("warp_wg_kernel<")          # ambiguous: several instantiations
-    assert set(bench.OTHER_WORKLOADS) < set(bench.WORKLOADS)
+    assert set(bench.OTHER_WORKLOADS) < set(bench.WORKLOADS) and set(bench.CONTENT_LEGS) < set(bench.WORKLOADS)

@@ -93,11 +93,29 @@ def test_default_line_carries_the_other_baseline_configs():
     d = run_bench(["--no-profile"], 1, "hdr2160_24to120")
     o = dict(d["other_workloads"])
     assert o.pop("failed") == []          # a leg that fails (or does not fit the legs' shared deadline) is named at the top, not hidden in its entry
-    assert set(o) == {"sdr1080_24to60", "sdr1080_64pairs", "hdr2160_nb10_blur32"}
+    assert set(o) == {"sdr1080_24to60", "sdr1080_64pairs", "hdr2160_nb10_blur32", "hdr1080_24to120", "sdr2160_24to60"}
     for name, w in o.items():
         assert "error" not in w, (name, w)
         assert w["value"] > 0 and 0 < w["frac"] < 1 and w["frac_algorithmic"] > 0 and w["timed_region_s"] > 0.3, (name, w)
     assert o["sdr1080_64pairs"]["pair_streams"] == 64 and o["sdr1080_64pairs"]["flow_batch"] == 16
+    # ... and the other content classes at both sizes, each with the kernels' own counters
+    content = dict(d["content"])
+    assert content.pop("failed") == [] and content.pop("note")
+    assert set(content) == {"hdr2160_24to120", "sdr1080_24to60"}
+    for wl, legs in content.items():
+        assert set(legs) == {"bench", "bench_wrap6", "static", "pan64", "chaotic", "cut"}, (wl, sorted(legs))
+        for scene, leg in legs.items():
+            assert leg["value"] > 0 and leg["us_per_flow_calc_in_pipeline"] > 0, (wl, scene, leg)
+            cc = leg["counters"]
+            if cc["sad_tables"]:
+                assert set(cc["reuse_share"]) == {"32", "16", "8", "4", "2"} and cc["reuse_share"]["32"] == {"X": 0.0, "Y": 0.0}
+            else:     # hardly any window keeps its offsets: the chains of this content run without the tables (hf_calc.hip choose_tab_mode)
+                assert cc["reuse_share"] == {} and cc["still_share_of_32_windows"] < 0.45
+        assert all(v == {"X": 1.0, "Y": 1.0} for k, v in legs["static"]["counters"]["reuse_share"].items() if k != "32")
+        assert [legs[x]["counters"]["sad_tables"] for x in ("bench", "static", "pan64", "chaotic", "cut")] == [1, 1, 1, 0, 0]
+        assert legs["bench"]["counters"]["reuse_share"]["16"]["X"] > 0.8
+    assert content["hdr2160_24to120"]["static"]["counters"]["warp_staged_share"] > 0.95 > content["hdr2160_24to120"]["cut"]["counters"]["warp_staged_share"]
+    assert d["config"]["scene"] == "bench" and d["config"]["pool_order"] == "pingpong"
     r = d["roofline"]
     assert r["kernel"].startswith("warp_wg_kernel<unsigned short, 2,")
     # the line describes itself: compulsory bytes, both readings of FETCH_SIZE on the chain's gathers, and the device

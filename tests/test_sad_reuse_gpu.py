@@ -41,7 +41,9 @@ def _frames(kind, H, W, hdr, seed):
     return [sc.frame(i) for i in range(3)]
 
 
-def _run(cls, H, W, max_res, f, R=16, delta=8, nb=6, iterations=0, flags=0):
+def _run(cls, H, W, max_res, f, R=16, delta=8, nb=6, iterations=0, flags=None):
+    from hopperrender_amd import capi
+    flags = capi.HF_FLAG_SAD_REUSE_ALWAYS if flags is None else flags      # (the default would drop the tables on hostile content after a chain or two)
     c = cls(H, W, 0, 0, delta, nb, 0.0, 255.0, max_res, search_radius=R, iterations=iterations, flags=flags)
     for x in f:
         c.updateFrame(x)
@@ -107,7 +109,7 @@ def test_batches_with_reuse_match_oracle(native_lib, n):
     cs, fs = [], []
     for i, kind in enumerate(kinds):
         f = _frames(kind, H, W, False, seed=8200 + 31 * i)
-        c = OpticalFlowCalcSDR(H, W, 0, 0, 8, 6, 0.0, 255.0, 270, search_radius=16, flags=capi.HF_FLAG_ASYNC)
+        c = OpticalFlowCalcSDR(H, W, 0, 0, 8, 6, 0.0, 255.0, 270, search_radius=16, flags=capi.HF_FLAG_ASYNC | capi.HF_FLAG_SAD_REUSE_ALWAYS)
         for x in f:
             c.updateFrame(x)
         cs.append(c); fs.append(f)

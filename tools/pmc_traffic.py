@@ -86,6 +86,18 @@ def pipeline_entry(a):
     }
 
 
+def git_commit():
+    """Short hash of HEAD when the record is generated (the kernels whose bytes it holds); bench.py prints it beside roofline.frac."""
+    import subprocess
+    try:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        h = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, check=True).stdout.strip()
+        dirty = subprocess.run(["git", "-C", root, "status", "--porcelain", "--", "hopperrender_amd/csrc"], capture_output=True, text=True).stdout.strip()
+        return h + ("+uncommitted-kernel-changes" if dirty else "")
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("workload"); ap.add_argument("fetch_csv"); ap.add_argument("write_csv")
@@ -102,6 +114,7 @@ def main():
             raise SystemExit("--pipeline needs --frame-bytes")
         data = json.load(open(a.out)) if os.path.exists(a.out) else {}
         data.setdefault(a.workload, {})["pipeline"] = pipeline_entry(a)
+        data[a.workload]["git_commit"] = git_commit()
         json.dump(data, open(a.out, "w"), indent=1)
         print(json.dumps({a.workload: {"pipeline": data[a.workload]["pipeline"]}}, indent=1))
         return
@@ -140,6 +153,7 @@ def main():
             data = {}
     if "pipeline" in data.get(a.workload, {}):
         entry["pipeline"] = data[a.workload]["pipeline"]
+    entry["git_commit"] = git_commit()
     data[a.workload] = entry
     json.dump(data, open(a.out, "w"), indent=1)
     print(json.dumps({a.workload: entry}, indent=1))
