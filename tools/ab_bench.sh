@@ -2,7 +2,7 @@
 # tools/ab_bench.sh VARIANT... -- the default bench (short) for several builds of the library (hopperrender_amd/lib/exp/<v>/, see
 # tools/build_variant.sh), alternating, on ONE box: A-B of kernel variants inside the pipeline.  "product" = the in-tree build.
 export TMPDIR=/tmp
-Q="--steps 8 --warmup 2 --no-cpu-baseline --no-reference --no-host-io --no-other-workloads ${AB_ARGS}"
+Q="--steps 8 --warmup 2 --no-cpu-baseline --no-reference --no-host-io --no-other-workloads --no-content-legs ${AB_ARGS}"
 for rep in 1 2; do for v in "$@"; do
   if [ "$v" = product ]; then L=""; else L=$PWD/hopperrender_amd/lib/exp/$v/libhopperflow.so; fi
   HF_LIB=$L python bench.py $Q 2>/dev/null | python3 -c "

@@ -13,20 +13,26 @@ pairs = [("bench_default.json", "bench_default.json"), ("bench_sdr1080.json", "b
          ("stats_chain16/p_kernel_stats.csv", "chain_batch16_kernel_stats.csv"), ("pmc_warp_valu.txt", "pmc_warp_instructions.txt"),
          ("pmc_warp_wg_kernel.txt", "pmc_warp_wg_kernel.txt"), ("pmc_chain_batch16.txt", "pmc_chain_batch16.txt"), ("chain_beside_warp.txt", "chain_beside_warp.txt"),
          ("pipeline_timeline.json", "pipeline_timeline.json"), ("pipeline_timeline_sdr1080.json", "pipeline_timeline_sdr1080.json"),
-         ("bench_default_timeline_run.json", "bench_default_timeline_run.json"), ("bench_default_plain_after_timeline.json", "bench_default_plain_after_timeline.json")]
+         ("bench_default_timeline_run.json", "bench_default_timeline_run.json"), ("bench_default_plain_after_timeline.json", "bench_default_plain_after_timeline.json"),
+         ("bench_hdr1080.json", "bench_hdr1080.json"), ("bench_sdr2160.json", "bench_sdr2160.json"), ("bench_default_wrap6.json", "bench_default_wrap6.json"),
+         ("bench_default_no_sad_reuse.json", "bench_default_no_sad_reuse.json"), ("bench_sdr1080_no_sad_reuse.json", "bench_sdr1080_no_sad_reuse.json"),
+         ("stats_chain16_static/p_kernel_stats.csv", "chain_batch16_static_kernel_stats.csv"), ("stats_chain16_chaotic/p_kernel_stats.csv", "chain_batch16_chaotic_kernel_stats.csv"),
+         ("stats_chain16_noreuse/p_kernel_stats.csv", "chain_batch16_no_sad_reuse_kernel_stats.csv")]
 for a, b in pairs:
     if os.path.exists(os.path.join(src, a)):
         shutil.copyfile(os.path.join(src, a), os.path.join(dst, f"{rnd}_{b}")); print("copied", b)
     else:
         print("MISSING", a)
-frame_bytes = {"hdr2160_24to120": 3840 * 2160 * 3, "sdr1080_24to60": 1920 * 1080 * 3 // 2}   # P010 / NV12 output frame
-outputs_per_period = {"hdr2160_24to120": 417083 / 83333, "sdr1080_24to60": 417083 / 166667}     # source / target frame time (HopperRender.cpp:162-163)
+frame_bytes = {"hdr2160_24to120": 3840 * 2160 * 3, "sdr1080_24to60": 1920 * 1080 * 3 // 2,   # P010 / NV12 output frame
+               "hdr1080_24to120": 1920 * 1080 * 3, "sdr2160_24to60": 3840 * 2160 * 3 // 2}
+outputs_per_period = {"hdr2160_24to120": 417083 / 83333, "sdr1080_24to60": 417083 / 166667,     # source / target frame time (HopperRender.cpp:162-163)
+                      "hdr1080_24to120": 417083 / 83333, "sdr2160_24to60": 417083 / 166667}
 
 
 # pairs per batch at the bench's operating point (the PMC passes over the pipeline run the same default command)
 import json
 flow_batch = {}
-for wl, f in (("hdr2160_24to120", "bench_default.json"), ("sdr1080_24to60", "bench_sdr1080.json")):
+for wl, f in (("hdr2160_24to120", "bench_default.json"), ("sdr1080_24to60", "bench_sdr1080.json"), ("hdr1080_24to120", "bench_hdr1080.json"), ("sdr2160_24to60", "bench_sdr2160.json")):
     try:
         flow_batch[wl] = json.loads([l for l in open(os.path.join(src, f)) if l.startswith("{")][-1])["config"]["flow_batch"]
     except Exception:
@@ -38,9 +44,11 @@ def reduce_rows(path, counter, keep):
     return rows
 
 
-for wl in ("hdr2160_24to120", "sdr1080_24to60"):
+for wl in ("hdr2160_24to120", "sdr1080_24to60", "hdr1080_24to120", "sdr2160_24to60"):
     for kind, prefix, keep, extra in (("warp_period", "pmc", lambda n: "::warp_" in n, []),
                                       ("pipeline", "pmcpipe", lambda n: "hf::" in n, ["--pipeline", "--batch", str(flow_batch[wl]), "--outputs-per-period", "%.5f" % outputs_per_period[wl]])):
+        if kind == "warp_period" and wl in ("hdr1080_24to120", "sdr2160_24to60"):
+            continue       # (round 6 added these two with pipeline passes only)
         files = []
         for c in ("FETCH_SIZE", "WRITE_SIZE"):
             p = os.path.join(src, f"{prefix}_{wl}_{c}", "p_counter_collection.csv")

@@ -6,7 +6,7 @@
 #   batched pipeline at the bench's operating point, stand-alone kernel times.
 #   `tools/final_profiles.sh TAG bench` re-runs only the four bench lines -- after `copy_profiles.py` has regenerated
 #   profiles/roofline_traffic.json from the PMC passes, so that the committed lines price their bytes with THIS round's traffic record.
-TAG=${1:-r05}
+TAG=${1:-r06}
 export TMPDIR=/tmp; R=$PWD; O=$R/gpurun_out/$TAG
 if [ "$2" != bench ]; then rm -rf $O; fi
 mkdir -p $O
@@ -14,11 +14,16 @@ python bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -c 300 $O/
 python bench.py --workload sdr1080_24to60 --no-reference > $O/bench_sdr1080.json 2> $O/bench_sdr1080.err
 python bench.py --workload sdr1080_64pairs --no-reference --no-cpu-baseline --no-host-io > $O/bench_sdr1080_64pairs.json 2> $O/bench_cfg4.err
 python bench.py --workload hdr2160_nb10_blur32 --no-reference --no-cpu-baseline --no-host-io > $O/bench_hdr2160_nb10_blur32.json 2> $O/bench_cfg5.err
+python bench.py --workload hdr1080_24to120 --no-reference --no-cpu-baseline --no-host-io > $O/bench_hdr1080.json 2> $O/bench_hdr1080.err
+python bench.py --workload sdr2160_24to60 --no-reference --no-cpu-baseline --no-host-io > $O/bench_sdr2160.json 2> $O/bench_sdr2160.err
+python bench.py --pool-order wrap --no-reference --no-cpu-baseline --no-host-io --no-other-workloads --no-content-legs > $O/bench_default_wrap6.json 2>> $O/bench_default.err
+python bench.py --no-sad-reuse --no-reference --no-cpu-baseline --no-host-io --no-other-workloads --no-content-legs > $O/bench_default_no_sad_reuse.json 2>> $O/bench_default.err
+python bench.py --workload sdr1080_24to60 --no-sad-reuse --no-reference --no-cpu-baseline --no-host-io > $O/bench_sdr1080_no_sad_reuse.json 2>> $O/bench_sdr1080.err
 if [ "$2" = bench ]; then ls $O; exit 0; fi
 # the pipeline's timeline WITHOUT a profiler (hf_batch_timeline_*: start / stop events of every dispatch, one step in the middle of the timed
 # region, plus a stand-alone leg of one batch), bracketed by the plain lines above / below: concurrency per kernel, stretch vs stand-alone,
 # idle gaps per queue (tools/timeline_report.py)
-TQ="--no-cpu-baseline --no-reference --no-host-io --no-other-workloads"
+TQ="--no-cpu-baseline --no-reference --no-host-io --no-other-workloads --no-content-legs"
 python bench.py $TQ --timeline-out $O/pipeline_timeline.json > $O/bench_default_timeline_run.json 2>> $O/bench_default.err
 python bench.py $TQ --workload sdr1080_24to60 --timeline-out $O/pipeline_timeline_sdr1080.json > $O/bench_sdr1080_timeline_run.json 2>> $O/bench_sdr1080.err
 python bench.py $TQ > $O/bench_default_plain_after_timeline.json 2>> $O/bench_default.err
@@ -26,13 +31,22 @@ python tools/microbench.py > $O/microbench.txt 2>&1
 python tools/microbench.py --hdr 0 --H 1080 --W 1920 >> $O/microbench.txt 2>&1
 python tools/chain_time.py --batch 1 2 4 8 16 >> $O/microbench.txt 2>&1
 python tools/chain_time.py --batch 1 8 16 --hdr 0 --H 1080 --W 1920 >> $O/microbench.txt 2>&1
+for sc in static pan64 chaotic cut; do python tools/chain_time.py --batch 1 16 --scene $sc >> $O/microbench.txt 2>&1; done
+python tools/chain_time.py --batch 1 12 16 --no-reuse >> $O/microbench.txt 2>&1
 python tools/warp_ab.py >> $O/microbench.txt 2>&1
 cd /tmp
-Q="--no-cpu-baseline --no-reference --no-host-io --no-other-workloads"
+Q="--no-cpu-baseline --no-reference --no-host-io --no-other-workloads --no-content-legs"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_default -o p -- python3 $R/bench.py $Q > $O/bench_default_under_rocprof.json 2>/dev/null
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_sdr1080 -o p -- python3 $R/bench.py --workload sdr1080_24to60 $Q > $O/bench_sdr1080_under_rocprof.json 2>/dev/null
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_streams1 -o p -- python3 $R/bench.py --streams 1 --batch 1 --steps 2 --periods-per-step 20 $Q > /dev/null 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_chain16 -o p -- python3 $R/tools/chain_time.py --batch 16 --n 50 > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_chain16_static -o p -- python3 $R/tools/chain_time.py --batch 16 --n 50 --scene static > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_chain16_chaotic -o p -- python3 $R/tools/chain_time.py --batch 16 --n 50 --scene chaotic > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_chain16_noreuse -o p -- python3 $R/tools/chain_time.py --batch 16 --n 50 --no-reuse > /dev/null 2>&1
+for wl in hdr1080_24to120 sdr2160_24to60; do for c in FETCH_SIZE WRITE_SIZE; do   # the pipeline's bytes of the two workloads added in round 6
+  timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmcpipe_${wl}_$c -o p -- python3 $R/bench.py --workload $wl --steps 2 --warmup 1 --periods-per-step 8 --no-profile $Q > /dev/null 2>&1
+  echo "pmc pipeline $wl $c rc=$?"
+done; done
 for wl in hdr2160_24to120 sdr1080_24to60; do for c in FETCH_SIZE WRITE_SIZE; do
   # the fused period warp alone: one member, one launch at a time
   timeout 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_${wl}_$c -o p -- python3 $R/bench.py --workload $wl --streams 1 --batch 1 --steps 2 --warmup 1 --periods-per-step 12 --no-profile $Q > /dev/null 2>&1

@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/scan_op.sh "STREAMS BATCH" ... -- the default workload at several operating points (pair streams per GPU, pairs per batch), one box
 export TMPDIR=/tmp
-Q="--steps 8 --warmup 2 --no-cpu-baseline --no-reference --no-host-io --no-other-workloads ${AB_ARGS}"
+Q="--steps 8 --warmup 2 --no-cpu-baseline --no-reference --no-host-io --no-other-workloads --no-content-legs ${AB_ARGS}"
 for rep in 1 2; do for sb in "$@"; do read S B <<< "$sb"
   python bench.py $Q --streams $S --batch $B 2>/dev/null | python3 -c "
 import sys,json
