@@ -122,6 +122,10 @@ bool choose_tab_mode(hf_ctx* const* cs, int n) {
     hf_ctx* l = cs[0];
     if (!l->sadtab) return false;
     if (l->cfg.flags & HF_FLAG_SAD_REUSE_ALWAYS) return true;
+    // A lone stream (or two, three) leaves most of the device idle: a launch is as long as its slowest wave whatever the others skip, and the
+    // table kernels' computing waves take two rounds of 8 candidates per axis.  Chain alone, tables on / off: 73.0 / 70.1 us (1 pair),
+    // 84.6 / 82.0 (2), 107.7 / 112.4 (4), 215.8 / 238.1 (16).
+    if (n < 4) return false;
     float sum = 0.f;
     int have = 0;
     for (int i = 0; i < n; i++) {

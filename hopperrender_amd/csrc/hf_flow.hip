@@ -446,7 +446,7 @@ template <int WROWS, int LPR, int NW, bool PACK = false, int NH = 1>
 __device__ __forceinline__ bool ysads_tile_try(uint32_t* sad, const Geom& g, const FlowStep& a, const uint32_t* ref, int ox, int oy, int wx0, int cy0, int tid, uint32_t* stage) {
     ox = __builtin_amdgcn_readfirstlane(ox); oy = __builtin_amdgcn_readfirstlane(oy);
     wx0 = __builtin_amdgcn_readfirstlane(wx0); cy0 = __builtin_amdgcn_readfirstlane(cy0);
-    if (g.rs < 0 || g.rs > 4) return false;               // (kernel-uniform; such a launch has no dynamic LDS)
+    if (g.rs < 0 || g.rs > 4 || !a.y_rows_lds) return false;   // (kernel-uniform; such a launch has no dynamic LDS)
     if ((cy0 << g.rs) + oy + rel16(0) < 0 || ((cy0 + WROWS - 1) << g.rs) + oy + rel16(15) > g.H - 1) return false;
     switch (g.rs) {
         case 0: ysads_tile_lds<0, WROWS, LPR, NW, PACK, NH>(sad, a, ref, ox, oy, wx0, cy0, tid, stage); break;
@@ -518,7 +518,7 @@ constexpr size_t win8_stage_bytes(int rs) {
 // cx0, cy, ox, oy: the lane's own (per window).  Taken only if all four windows of the wave need no reflection.
 template <bool PACK = false, int NH = 1>
 __device__ __forceinline__ bool ysads_win8_try(uint32_t* sad, const Geom& g, const FlowStep& a, const uint32_t* ref, int ox, int oy, int cx0, int cy, int lane, uint32_t* stage) {
-    if (g.rs < 0 || g.rs > 4) return false;
+    if (g.rs < 0 || g.rs > 4 || !a.y_rows_lds) return false;
     const int cy0 = cy - ((lane & 15) >> 1);
     const bool outside = (cy0 << g.rs) + oy + rel16(0) < 0 || ((cy0 + 7) << g.rs) + oy + rel16(15) > g.H - 1;
     if (__builtin_amdgcn_ballot_w64(outside) != 0) return false;
@@ -789,14 +789,14 @@ template <> struct Map<8> {    // 16 lanes = one 8x8 window; wave = 2x2 windows
 // constants, bias terms and argmin for half the pixels, plus a butterfly; the level-2 and level-4 launches were the two most expensive
 // of the chain.)
 template <> struct Map<4> {    // 2 lanes (l, l ^ 8) = one 4x4 window; wave = 8x4 windows = 32 px x 16 rows; a 32x32 tile is TWO waves
-    static constexpr int PX = 4, NR = 2, G = 2, XM = 8, TW = 32, TH = 32, WAVES = 2, RM = 0;
+    static constexpr int PX = 4, NR = 2, G = 2, XM = 8, TW = 32, TH = 32, WAVES = 2;
     __device__ static void at(int tid, int& x, int& y) {
         const int w = tid >> 6, l = tid & 63;
         x = (l & 7) * 4; y = w * 16 + (l >> 4) * 4 + ((l >> 3) & 1) * 2;
     }
 };
 template <> struct Map<2> {    // one lane = one 2x2 window; wave = 16x4 windows = 32 px x 8 rows; workgroup tile 32x32
-    static constexpr int PX = 2, NR = 2, G = 1, XM = 1, TW = 32, TH = 32, WAVES = 4, RM = 0;
+    static constexpr int PX = 2, NR = 2, G = 1, XM = 1, TW = 32, TH = 32, WAVES = 4;
     __device__ static void at(int tid, int& x, int& y) {
         const int w = tid >> 6, l = tid & 63;
         x = (l & 15) * 2; y = w * 8 + (l >> 4) * 2;
@@ -815,7 +815,7 @@ template <> struct MapRow<4> {   // 4 lanes = one 4x4 window; wave = 4x4 windows
     }
 };
 template <> struct MapRow<2> {   // 2 lanes (l, l ^ 1) = one 2x2 window; wave = 8x4 windows; workgroup tile 16x32
-    static constexpr int PX = 2, NR = 1, G = 2, XM = 1, TW = 16, TH = 32, WAVES = 4, RM = 0;
+    static constexpr int PX = 2, NR = 1, G = 2, XM = 1, TW = 16, TH = 32, WAVES = 4;
     __device__ static void at(int tid, int& x, int& y) {
         const int w = tid >> 6, l = tid & 63, gi = l >> 1;
         x = (gi & 7) * 2; y = w * 8 + (gi >> 3) * 2 + (l & 1);
@@ -1341,12 +1341,13 @@ void launch_flow_level_small(const Geom& g, const FlowBatch& b, hipStream_t stre
     const bool rows1 = b.n <= kRowPerLaneMaxBatch && ws <= 4;
     const int tw = rows1 && ws == 2 ? MapRow<2>::TW : 32;
     const int tiles_x = (g.lw + tw - 1) / tw, tiles_y = (g.lh + 31) / 32;   // (32 x 32 tiles at every level but MapRow<2>: 16 x 32)
-    const FlowBatchArgs kb = pack_batch(b, tiles_x, tiles_y);
+    FlowBatchArgs kb = pack_batch(b, tiles_x, tiles_y);
     // dynamic LDS: the candidate rows of the Y step (full tiles only exist at the full search radius)
     const size_t lds = b.s[0].R != 16 ? 0 : ws == 32 ? ystage_bytes<32, 8, 4>(g.rs) : ws == 16 ? ystage_bytes<16, 4, 1>(g.rs) : ws == 8 ? win8_stage_bytes(g.rs) : 0;
     // windows <= 16 never span waves: one-wave workgroups (SPLIT), see flow_level_small_kernel
     const dim3 grd(xcd_grid(tiles_x, tiles_y, 1, b.n));
     auto split = [&](int waves) { return dim3(xcd_grid(tiles_x, tiles_y, waves, b.n)); };
+    kb.common.y_rows_lds = lds != 0;
     const bool tabk = b.s[0].sadtab && b.s[0].R == 16 && (b.s[0].sad_read || b.s[0].sad_write);
 #define HF_LEVEL(NAME, WS_, SPLIT_, ROWS1_, GRID, BLOCK, LDS)                                                                            \
     do {                                                                                                                                 \
@@ -1374,7 +1375,9 @@ void launch_flow_big_partial(const Geom& g, const FlowBatch& b, hipStream_t stre
     const int tiles_x = (g.lw + 63) / 64, tiles_y = (g.lh + 4 * kBigWavesPerBlock - 1) / (4 * kBigWavesPerBlock);
     const dim3 grd(xcd_grid(tiles_x, tiles_y, 1, b.n));
     const size_t lds = b.s[0].axis == 1 && b.s[0].R == 16 && kBigWavesPerBlock == 4 ? ystage_bytes<16, 16, 4>(g.rs) : 0;   // Y launches: candidate rows
-    HF_LAUNCH(b.s[0].axis ? "large_windows_y" : "large_windows_x", (flow_big_partial_kernel<kBigWavesPerBlock>), grd, dim3(64 * kBigWavesPerBlock), lds, stream, g, pack_batch(b, tiles_x, tiles_y));
+    FlowBatchArgs kb = pack_batch(b, tiles_x, tiles_y);
+    kb.common.y_rows_lds = lds != 0;
+    HF_LAUNCH(b.s[0].axis ? "large_windows_y" : "large_windows_x", (flow_big_partial_kernel<kBigWavesPerBlock>), grd, dim3(64 * kBigWavesPerBlock), lds, stream, g, kb);
 }
 
 void launch_flow_big_argmin(const Geom& g, const FlowBatch& b, hipStream_t stream) {

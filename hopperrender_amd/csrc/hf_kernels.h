@@ -153,6 +153,7 @@ struct FlowStep {
     int sad_nbx, sad_nby;
     int sad_read;            // the previous level's launch left valid tables for every full tile (this is not the chain's first small level)
     int sad_write;           // this launch refreshes them where it computes (windows 32 .. 4)
+    int y_rows_lds;          // this launch has dynamic LDS for the candidate rows of its Y steps (ysads_tile_lds / ysads_win8_lds)
     uint32_t* still_count;   // device: windows of the 32-level that chose d = 0 on both axes in this chain (the content hint, hf_calc.hip), or nullptr
     uint32_t* counters;      // diagnostic counters (hopperflow_diag.h hf_debug_counters, layout kCounter* below), nullptr: none
     int level_index;         // k of this level (its counter slot)

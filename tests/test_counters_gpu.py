@@ -81,28 +81,36 @@ def test_warp_workgroup_counters_of_a_batch(native_lib):
 
 
 def test_tables_switch_off_on_hostile_content_and_back(native_lib):
-    """The chain reports how many 32-windows kept their offsets; while hardly any does, the following chains run without SAD tables (hf_stats
-    sad_tables / still_share), with identical results, and come back when the content calms down."""
-    from hopperrender_amd import synth
-    from hopperrender_amd.calc import OpticalFlowCalcSDR
+    """The chain reports how many 32-windows kept their offsets; while hardly any does, the following chains of a batch run without SAD tables
+    (hf_stats sad_tables / still_share), with identical results, and come back when the content calms down.  (Fewer than four pairs per
+    launch never keep tables: a launch of a nearly idle device is as long as its slowest wave.)"""
+    from hopperrender_amd import capi, synth
+    from hopperrender_amd.calc import FlowBatch, OpticalFlowCalcSDR
     from oracle import oracle
-    H, W = 1080, 1920
+    H, W, n = 1080, 1920, 4
     g = oracle.make_geom(0, H, W)
     calm = synth.ContentScene("bench", H, W, False, 21)
     wild = synth.ContentScene("chaotic", H, W, False, 22)
     seq = [calm.frame(i) for i in range(4)] + [wild.frame(i) for i in range(6)] + [calm.frame(i) for i in range(4, 10)]
-    c = OpticalFlowCalcSDR(H, W, 0, 0, 8, 6, 0.0, 255.0, 270, search_radius=16)
+    lone = OpticalFlowCalcSDR(H, W, 0, 0, 8, 6, 0.0, 255.0, 270, search_radius=16)
+    cs = [OpticalFlowCalcSDR(H, W, 0, 0, 8, 6, 0.0, 255.0, 270, search_radius=16, flags=capi.HF_FLAG_ASYNC) for _ in range(n)]
+    b = FlowBatch(cs)
     modes = []
     for i, fr in enumerate(seq):
-        c.updateFrame(fr)
+        for c in cs + [lone]:
+            c.updateFrame(fr)
         if i < 2:
             continue
-        c.calculateOpticalFlow(); c.sync()
-        st = c.stats()
-        modes.append(st["sad_tables"])
+        b.calculateOpticalFlow(); b.sync()
+        lone.calculateOpticalFlow(); lone.sync()
+        modes.append(cs[0].stats()["sad_tables"])
+        assert lone.stats()["sad_tables"] == 0
         off, _, tot, _ = oracle.calculate_optical_flow(seq[i - 1], seq[i], g, 16, 0, 8, 6, 4)
-        assert (c.readOffsets() == off).all() and c.m_totalFrameDelta == tot, i
+        for c in cs + [lone]:
+            assert (c.readOffsets() == off).all() and c.m_totalFrameDelta == tot, i
     assert modes[0] == 1 and modes[1] == 1                   # calm start
     assert 0 in modes[3:8], modes                            # hostile stretch: tables off after the reports arrive
     assert modes[-1] == 1, modes                             # and on again
-    c.close()
+    b.close()
+    for c in cs + [lone]:
+        c.close()

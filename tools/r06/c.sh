@@ -1,3 +1,4 @@
 export TMPDIR=/tmp
-echo "== 1080p"; AB_ARGS="--workload sdr1080_24to60 --steps 16" bash tools/scan_op.sh "36 12" "48 12" "48 16" "32 16" "40 10" "32 8"
-echo "== 2160p"; bash tools/scan_op.sh "48 12" "64 16" "48 16" "36 12" "40 10"
+python -m pytest tests/test_lds_rows_gpu.py -x -q 2>&1 | tail -2
+bash tools/ab_bench.sh product nolds32 noldsbig
+AB_ARGS="--workload sdr1080_24to60 --steps 16" bash tools/ab_bench.sh product nolds32 noldsbig
