@@ -24,8 +24,17 @@ a = ap.parse_args([] if __name__ != "__main__" else None)
 H, W, SZ, RS = 2160, 3840, 2, 3
 g = oracle.make_geom(1, H, W)
 lw, lh = g.lw, g.lh
-sc = synth.Scene(H, W, True, a.seed, max_rect_speed=a.speed)
-fr = [sc.frame(k) for k in range(a.frames + 2)]
+_frames = {}
+
+
+def scene_frames(scene="bench"):
+    """Frames 0 .. of a content class (synth.ContentScene; bench = synth.Scene, the bench's default content)."""
+    if scene not in _frames:
+        sc = synth.Scene(H, W, True, a.seed, max_rect_speed=a.speed) if scene == "bench" else synth.ContentScene(scene, H, W, True, a.seed)
+        _frames[scene] = [sc.frame(k) for k in range(a.frames + 2)]
+    return _frames[scene]
+
+
 TS = [[0.0, 0.1998, 0.3996, 0.5994, 0.7992], [0.199, 0.3988, 0.5986, 0.7984, 0.9982]]
 
 
@@ -95,8 +104,9 @@ def policy_per_source(w, budget):  # fraction of SOURCE windows staged when each
     return (ok & (ra <= budget)).mean() * 0.5 + (ok & (rb <= budget)).mean() * 0.5
 
 
-def flows_of(n_frames):
+def flows_of(n_frames, scene="bench"):
     out = []
+    fr = scene_frames(scene)
     for k in range(n_frames):
         _, blur, _, _ = oracle.calculate_optical_flow(fr[k], fr[k + 1], g, 16, 0, 8, 6, 4)
         out.append(blur)
