@@ -67,9 +67,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s mea
 # the dominant kernel of the batched pipeline: 2160p HDR (one flow cell per 16-byte thread) runs the LDS-staged period warp
 # (one window per workgroup of 4 wave tiles), 1080p SDR the global-path kernel
 # (template prefix: the full symbol -- waves per workgroup, rows per thread -- is read from the shipped binary, see warp_symbol())
-# keyed by (hdr, frame larger than 1080p): frames above 1080p take the staged period warp, the others the global-path kernel of their element size
+# keyed by (hdr, frame larger than 1080p): 2160p HDR (flow cell = one 16-byte thread) takes the staged period warp, the others the global-path
+# kernel of their element size and cell width (names as the PMC passes of profiles/roofline_traffic.json saw them dispatched)
 WARP_SYMBOL_PREFIX = {(1, True): "warp_wg_kernel<unsigned short, 2,", (0, False): "warp_fast_kernel<unsigned char, 4, 2, 2, 8, true>",
-                      (0, True): "warp_wg_kernel<unsigned char, 2,", (1, False): "warp_fast_kernel<unsigned short, 4, 2, 2, 8, true>"}
+                      (0, True): "warp_fast_kernel<unsigned char, 8, 2, 2, 16, true>", (1, False): "warp_fast_kernel<unsigned short, 4, 2, 2, 16, true>"}
 # the other BASELINE configs, run as short legs behind the timed region of the default workload (fresh child processes, never `value`)
 OTHER_WORKLOADS = {"sdr1080_24to60": 24, "sdr1080_64pairs": 24, "hdr2160_nb10_blur32": 8, "hdr1080_24to120": 12, "sdr2160_24to60": 8}   # name: steps (about 1 s timed each)
 # Content classes (hopperrender_amd/synth.py ContentScene; SURVEY.md 8(d) "extra cases"): the reference's cost does not depend on the pixels,
@@ -748,6 +749,11 @@ def main():
             c.calculateOpticalFlow()
         c.sync()
         flow_us = 1e3 * c.profile()["flow_ms"] / max(c.profile()["flow_chains"], 1)
+        c.resetProfile()
+        for i in range(48):                            # ... and on ONE frame pair again and again (planes cache-warm): the way reference_opencl.ms_per_flow_calc is taken
+            c.calculateOpticalFlow()
+        c.sync()
+        flow_us_warm = 1e3 * c.profile()["flow_ms"] / max(c.profile()["flow_chains"], 1)
         small = FlowBatch(calcs[:nb]) if nb > 1 else None
         for x in calcs[:nb]:
             x.resetProfile()
@@ -766,7 +772,7 @@ def main():
         if small:
             small.close()
         isolated = {"warp_us": 1e3 * p["warp_ms"] / max(p["warp_launches"], 1) / nb, "fpl": p["warp_frames"] / max(p["warp_launches"], 1) / nb,
-                    "launch_us": 1e3 * p["warp_ms"] / max(p["warp_launches"], 1), "flow_chain_us": flow_us, "flow_chain_after_sync_us": flow_us_after_sync, "members": nb}
+                    "launch_us": 1e3 * p["warp_ms"] / max(p["warp_launches"], 1), "flow_chain_us": flow_us, "flow_chain_after_sync_us": flow_us_after_sync, "flow_chain_warm_us": flow_us_warm, "members": nb}
 
     # Host-I/O leg at N > 1 (the expected scaling limit is host memcpy / the PCIe root complex): EVERY rank feeds
     # one context from pinned host memory and reads every output frame back, all ranks at the same time, each in a child process
@@ -917,10 +923,11 @@ def main():
                                      + (f"; chains run {a.batch} pairs per launch (hf_batch): this is the batch's time / {a.batch}" if a.batch > 1 else ""),
             "ms_per_flow_calc_isolated": round(isolated["flow_chain_us"] / 1e3, 4) if isolated else None,
             "ms_per_flow_calc_isolated_after_sync": round(isolated["flow_chain_after_sync_us"] / 1e3, 4) if isolated else None,
+            "ms_per_flow_calc_isolated_cache_warm": round(isolated["flow_chain_warm_us"] / 1e3, 4) if isolated else None,
             "ms_per_flow_calc_isolated_note": "one pair's refinement chain + blur alone on the GPU, device time per chain, every chain on a NEW frame right behind that frame's plane "
                                               "build (its plane rows come from HBM): 48 calls back to back / 12 calls each behind a host synchronisation (what rounds 1-4 printed under "
-                                              "the first name).  tools/chain_time.py re-runs ONE frame pair, planes cache-warm, the way reference_opencl.ms_per_flow_calc is taken: 70-71 us "
-                                              "(profiles/r05_microbench.txt)",
+                                              "the first name); _cache_warm: 48 calls on ONE frame pair, planes cache-warm -- the way reference_opencl.ms_per_flow_calc is taken "
+                                              "(= tools/chain_time.py --batch 1)",
             "roofline": roof,
         }
         if host_io_ranks is not None:
