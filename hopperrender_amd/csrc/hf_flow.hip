@@ -1161,7 +1161,7 @@ __global__ __launch_bounds__(SPLIT ? 64 : 256) void flow_level_small_kernel(cons
     else flow_level_small_body<WS, SPLIT, false, ROWS1>(g, a, tile, s_part, s_rows);
 }
 
-// Windows > 32, one axis: raw SAD sums of a 32 x (8 * WPB) tile -> one atomic per candidate.
+// Windows > 32, one axis: raw SAD sums of a tile -> one atomic per candidate.
 // WPB = waves per workgroup.  Fewer waves per workgroup = more workgroups for the 256 CUs (a 480x270 grid has 135
 // 32x32 tiles) at the price of more atomics on the same R addresses of each window.
 template <int WPB, bool FULL, bool R16 = FULL>
@@ -1212,12 +1212,13 @@ __device__ __forceinline__ void flow_big_partial_body(const Geom& g, const FlowS
 
 template <int WPB>
 __global__ __launch_bounds__(64 * WPB) void flow_big_partial_kernel(const Geom g, const FlowBatchArgs batch) {
-    const TileId tile = decode_tile<1>(batch, (g.lw + 63) / 64, (g.lh + 4 * WPB - 1) / (4 * WPB));
+    constexpr int TW = 64, TH = 4 * WPB;
+    const TileId tile = decode_tile<1>(batch, (g.lw + TW - 1) / TW, (g.lh + TH - 1) / TH);
     if (!tile.valid) return;
     const FlowStep a = member_step(batch, tile.pair);
     __shared__ uint32_t s_part[WPB][16];
     extern __shared__ __attribute__((aligned(16))) uint32_t s_rows[];   // Y launches: candidate rows (launch_flow_big_partial)
-    const bool full = a.R == 16 && (tile.tx + 1) * 64 <= g.lw && (tile.ty + 1) * (4 * WPB) <= g.lh;   // see flow_level_small_kernel
+    const bool full = a.R == 16 && (tile.tx + 1) * TW <= g.lw && (tile.ty + 1) * TH <= g.lh;   // see flow_level_small_kernel
     if (full) flow_big_partial_body<WPB, true>(g, a, tile, s_part, s_rows);
     else if (a.R == 16) flow_big_partial_body<WPB, false, true>(g, a, tile, s_part, s_rows);
     else flow_big_partial_body<WPB, false>(g, a, tile, s_part, s_rows);
@@ -1370,14 +1371,26 @@ void launch_flow_level_small(const Geom& g, const FlowBatch& b, hipStream_t stre
 #undef HF_LEVEL
 }
 
-constexpr int kBigWavesPerBlock = 4;   // measured on MI355X (2160p HDR chain): 4 waves per workgroup 108.2 us, 2: 109.0 us, 1: 111.9 us (more atomics)
+// Waves per workgroup.  A chain alone (2160p HDR, 16 pairs): 4 waves 214 us, 1 wave 224 us (more atomics, and the Y launch's candidate rows
+// come out of L2 instead of LDS).  Inside the pipeline the 1080p workloads -- whose warp launches are short and leave the chain the larger
+// share of every queue -- are 2.3 % faster with one-wave workgroups (other queues' kernels hold most of every CU; a single wave finds room
+// sooner, and the warp beside it got 8 % shorter), the 2160p ones 2 % slower: a throughput driver's batches on the small grids-to-frame
+// ratios take one wave.  (Measured, round 6; a 16 x 16 one-wave Y tile with staged rows was no better than the plain one.)
+#ifndef HF_BIG_ONE_WAVE_MIN_BATCH
+#define HF_BIG_ONE_WAVE_MIN_BATCH 4
+#endif
+constexpr int kBigWavesPerBlock = 4, kBigOneWaveMinBatch = HF_BIG_ONE_WAVE_MIN_BATCH, kBigOneWaveMaxRs = 2;
 void launch_flow_big_partial(const Geom& g, const FlowBatch& b, hipStream_t stream) {
-    const int tiles_x = (g.lw + 63) / 64, tiles_y = (g.lh + 4 * kBigWavesPerBlock - 1) / (4 * kBigWavesPerBlock);
+    const bool y = b.s[0].axis == 1;
+    const char* name = y ? "large_windows_y" : "large_windows_x";
+    const int wpb = b.n >= kBigOneWaveMinBatch && g.rs <= kBigOneWaveMaxRs ? 1 : kBigWavesPerBlock;
+    const int tiles_x = (g.lw + 63) / 64, tiles_y = (g.lh + 4 * wpb - 1) / (4 * wpb);
     const dim3 grd(xcd_grid(tiles_x, tiles_y, 1, b.n));
-    const size_t lds = b.s[0].axis == 1 && b.s[0].R == 16 && kBigWavesPerBlock == 4 ? ystage_bytes<16, 16, 4>(g.rs) : 0;   // Y launches: candidate rows
+    const size_t lds = y && b.s[0].R == 16 && wpb == 4 ? ystage_bytes<16, 16, 4>(g.rs) : 0;   // Y launches: candidate rows
     FlowBatchArgs kb = pack_batch(b, tiles_x, tiles_y);
     kb.common.y_rows_lds = lds != 0;
-    HF_LAUNCH(b.s[0].axis ? "large_windows_y" : "large_windows_x", (flow_big_partial_kernel<kBigWavesPerBlock>), grd, dim3(64 * kBigWavesPerBlock), lds, stream, g, kb);
+    if (wpb == 1) HF_LAUNCH(name, (flow_big_partial_kernel<1>), grd, dim3(64), lds, stream, g, kb);
+    else HF_LAUNCH(name, (flow_big_partial_kernel<kBigWavesPerBlock>), grd, dim3(64 * kBigWavesPerBlock), lds, stream, g, kb);
 }
 
 void launch_flow_big_argmin(const Geom& g, const FlowBatch& b, hipStream_t stream) {
