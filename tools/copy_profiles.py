@@ -44,7 +44,9 @@ def reduce_rows(path, counter, keep):
     return rows
 
 
-for wl in ("hdr2160_24to120", "sdr1080_24to60", "hdr1080_24to120", "sdr2160_24to60"):
+# `python tools/copy_profiles.py TAG lines`: only the summaries above (after `final_profiles.sh TAG bench`): the PMC rows and
+# profiles/roofline_traffic.json -- whose commit hash the bench lines print -- stay as the full run left them
+for wl in (() if sys.argv[2:3] == ["lines"] else ("hdr2160_24to120", "sdr1080_24to60", "hdr1080_24to120", "sdr2160_24to60")):
     for kind, prefix, keep, extra in (("warp_period", "pmc", lambda n: "::warp_" in n, []),
                                       ("pipeline", "pmcpipe", lambda n: "hf::" in n, ["--pipeline", "--batch", str(flow_batch[wl]), "--outputs-per-period", "%.5f" % outputs_per_period[wl]])):
         if kind == "warp_period" and wl in ("hdr1080_24to120", "sdr2160_24to60"):
