@@ -12,6 +12,7 @@ pairs = [("bench_default.json", "bench_default.json"), ("bench_sdr1080.json", "b
          ("stats_sdr1080/p_kernel_stats.csv", "bench_sdr1080_kernel_stats.csv"), ("stats_streams1/p_kernel_stats.csv", "bench_streams1_kernel_stats.csv"),
          ("stats_chain16/p_kernel_stats.csv", "chain_batch16_kernel_stats.csv"), ("pmc_warp_valu.txt", "pmc_warp_instructions.txt"),
          ("pmc_warp_wg_kernel.txt", "pmc_warp_wg_kernel.txt"), ("pmc_chain_batch16.txt", "pmc_chain_batch16.txt"), ("chain_beside_warp.txt", "chain_beside_warp.txt"),
+         ("timeline_vs_trace_hdr2160_24to120.txt", "timeline_vs_trace_hdr2160_24to120.txt"), ("timeline_vs_trace_sdr1080_24to60.txt", "timeline_vs_trace_sdr1080_24to60.txt"),
          ("pipeline_timeline.json", "pipeline_timeline.json"), ("pipeline_timeline_sdr1080.json", "pipeline_timeline_sdr1080.json"),
          ("bench_default_timeline_run.json", "bench_default_timeline_run.json"), ("bench_default_plain_after_timeline.json", "bench_default_plain_after_timeline.json"),
          ("bench_hdr1080.json", "bench_hdr1080.json"), ("bench_sdr2160.json", "bench_sdr2160.json"), ("bench_default_wrap6.json", "bench_default_wrap6.json"),

@@ -65,4 +65,18 @@ bash tools/pmc_warp_batch.sh 16 > $O/pmc_warp_wg_kernel.txt 2>&1
   echo "# valu% = vector ALU busy, wait% = share of wave-cycles spent waiting, td% / tcc% = texture-data unit / L2 channels busy, L2->L1 = TCP_TCC_READ_REQ x 64 B."
   bash tools/pmc_chain_batch.sh 16 2>&1 | grep -v " rc=0$"; } > $O/pmc_chain_batch16.txt
 python3 tools/chain_beside_warp.py $O/stats_default/p_kernel_trace.csv > $O/chain_beside_warp.txt 2>&1
+# the library's event timeline and rocprofv3's kernel trace of the SAME dispatches, one process: what a start event measures, and what the
+# profiler does to the pipeline (tools/timeline_vs_trace.py)
+cd /tmp
+for wl in hdr2160_24to120 sdr1080_24to60; do
+  timeout 400 rocprofv3 --kernel-trace --output-format csv -d $O/tlx_$wl -o p -- python3 $R/bench.py $Q --steps 6 --warmup 2 --workload $wl --timeline-out $O/tlx_$wl.json > $O/tlx_bench_$wl.json 2> /dev/null
+  { python3 $R/tools/timeline_vs_trace.py $O/tlx_${wl}_raw.json $O/tlx_$wl/p_kernel_trace.csv
+    python3 -c "
+import json,sys
+t=json.load(open('$O/tlx_$wl.json')); b=json.loads(open('$O/tlx_bench_$wl.json').read().strip().splitlines()[-1])
+print('# this (profiled) run: %.0f frames/s, host enqueue %.1f ms of a %.1f ms step; queues busy by the event view: %s; mean queues busy %.2f' % (b['value'], b['host_enqueue_ms_per_step'], b['ms_per_step'], [q['busy_frac'] for q in t['queues']], t['concurrency']['mean_queues_busy']))"
+  } > $O/timeline_vs_trace_$wl.txt 2>&1
+  rm -rf $O/tlx_$wl $O/tlx_${wl}_raw.json
+done
+cd $R
 ls $O
