@@ -1374,16 +1374,16 @@ void launch_flow_level_small(const Geom& g, const FlowBatch& b, hipStream_t stre
 // Waves per workgroup.  A chain alone (2160p HDR, 16 pairs): 4 waves 214 us, 1 wave 224 us (more atomics, and the Y launch's candidate rows
 // come out of L2 instead of LDS).  Inside the pipeline the 1080p workloads -- whose warp launches are short and leave the chain the larger
 // share of every queue -- are 2.3 % faster with one-wave workgroups (other queues' kernels hold most of every CU; a single wave finds room
-// sooner, and the warp beside it got 8 % shorter), the 2160p ones 2 % slower: a throughput driver's batches on the small grids-to-frame
-// ratios take one wave.  (Measured, round 6; a 16 x 16 one-wave Y tile with staged rows was no better than the plain one.)
+// sooner, and the warp beside it got 8 % shorter), the 2160p ones (rs = 3) 2 % slower and 360p (rs = 1) 1.5 % slower: a throughput driver's
+// batches at rs = 2 take one wave.  (Measured, round 6; a 16 x 16 one-wave Y tile with staged rows was no better than the plain one.)
 #ifndef HF_BIG_ONE_WAVE_MIN_BATCH
 #define HF_BIG_ONE_WAVE_MIN_BATCH 4
 #endif
-constexpr int kBigWavesPerBlock = 4, kBigOneWaveMinBatch = HF_BIG_ONE_WAVE_MIN_BATCH, kBigOneWaveMaxRs = 2;
+constexpr int kBigWavesPerBlock = 4, kBigOneWaveMinBatch = HF_BIG_ONE_WAVE_MIN_BATCH, kBigOneWaveRs = 2;
 void launch_flow_big_partial(const Geom& g, const FlowBatch& b, hipStream_t stream) {
     const bool y = b.s[0].axis == 1;
     const char* name = y ? "large_windows_y" : "large_windows_x";
-    const int wpb = b.n >= kBigOneWaveMinBatch && g.rs <= kBigOneWaveMaxRs ? 1 : kBigWavesPerBlock;
+    const int wpb = b.n >= kBigOneWaveMinBatch && g.rs == kBigOneWaveRs ? 1 : kBigWavesPerBlock;
     const int tiles_x = (g.lw + 63) / 64, tiles_y = (g.lh + 4 * wpb - 1) / (4 * wpb);
     const dim3 grd(xcd_grid(tiles_x, tiles_y, 1, b.n));
     const size_t lds = y && b.s[0].R == 16 && wpb == 4 ? ystage_bytes<16, 16, 4>(g.rs) : 0;   // Y launches: candidate rows
