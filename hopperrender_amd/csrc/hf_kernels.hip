@@ -538,7 +538,7 @@ __device__ __forceinline__ int mirror_warp_bl(int pos, int dim) {
 template <typename E, int G, int CZ, bool DW>
 __device__ __forceinline__ Run<E, G> get_run(const E* __restrict__ rowp, int x, [[maybe_unused]] int W = 1 << 30) {
     HF_DBG_CHECK(x >= 0 && (CZ ? (x & ~1) : x) + G + (CZ ? 2 : 0) <= W + (CZ ? 2 : 0), 209);   // (a chroma run reads the pair behind it: still inside the row for interior runs)
-    if constexpr (DW && G * sizeof(E) >= 4) {   // (smaller groups are never launched on the fast path)
+    if constexpr (DW && G * sizeof(E) >= 4) {   // (2-byte groups -- 8-bit frames at rs = 1 -- keep the plain element loads)
         return CZ ? load_run_uv_dw<E, G>((const unsigned char*)rowp, x) : load_run_dw<E, G>((const unsigned char*)rowp, x);
     } else {
         return CZ ? load_run_uv<E, G>(rowp, x) : load_run<E, G>(rowp + x);
@@ -1376,7 +1376,7 @@ static bool warp_fast_shape(const Geom& g, const WarpBatchArgs& b, bool& dw) {
     const int group = cell < VEC ? cell : VEC;
     const int mode = b.s[0].mode;
     bool fast = mode >= 0 && mode <= 2 && (g.in_stride % 2) == 0 && (g.out_stride % VEC) == 0 &&
-                g.W >= 2 * VEC && group * (int)sizeof(E) >= 4 && VEC % group == 0 && VEC / group <= 4;
+                g.W >= 2 * VEC && group >= 2 && VEC % group == 0 && VEC / group <= 4;   // (group >= 2: a chroma run is made of element PAIRS)
     // dword-aligned source loads (load_run_dw) need dword-aligned frames and rows that end on a dword
     dw = ((size_t)g.in_stride * sizeof(E)) % 4 == 0 && ((size_t)g.W * sizeof(E)) % 4 == 0 && ((size_t)g.H * g.in_stride * sizeof(E)) % 4 == 0;
     for (int m = 0; m < b.n && fast; m++) {

@@ -169,12 +169,15 @@ def test_first_suitable_device_on_this_box(native_lib):
     c.close()
 
 
-def test_batched_period_matches_oracle(native_lib):
-    """... and through the oracle the reference: one batched period at 180p against the CPU restatement."""
+@pytest.mark.parametrize("H,W,mode", [(180, 320, 2), (360, 640, 2), (360, 640, 0), (360, 640, 1)])
+def test_batched_period_matches_oracle(native_lib, H, W, mode):
+    """... and through the oracle the reference: one batched period against the CPU restatement -- at 180p (rs = 0: one-pixel flow cells,
+    the generic warp kernel, one launch per output) and at 360p (rs = 1: two-pixel = two-byte cells of an 8-bit frame, which the fused
+    period warp takes since round 6: runs read with plain element loads, four cells per 8-byte thread)."""
     from hopperrender_amd import capi, synth
     from hopperrender_amd.calc import DeviceBuffer, FlowBatch, OpticalFlowCalcSDR
     from oracle import oracle
-    H, W, R, n = 180, 320, 8, 3
+    R, n = 8, 3
     g = oracle.make_geom(0, H, W)
     scenes = [synth.Scene(H, W, False, 900 + i) for i in range(n)]
     frames = [[sc.frame(k) for k in range(4)] for sc in scenes]
@@ -190,14 +193,14 @@ def test_batched_period_matches_oracle(native_lib):
         batch.updateFramesDeviceRef([dev[i][k].ptr for i in range(n)])
         if k >= 2:
             batch.calculateOpticalFlow()
-    batch.interpolatePeriod(ts, [[b.ptr for b in outs[i]] for i in range(n)], 2)
+    batch.interpolatePeriod(ts, [[b.ptr for b in outs[i]] for i in range(n)], mode)
     for i in range(n):
         members[i].sync()
         _, blur, tot, oob = oracle.calculate_optical_flow(frames[i][1], frames[i][2], g, R)
         assert oob == 0
         assert (members[i].readBlurredFlow(0) == blur).all()
         for j, t in enumerate(ts[i]):
-            ref = oracle.warp_frames(frames[i][1], frames[i][2], blur, g, np.float32(t), 2)
+            ref = oracle.warp_frames(frames[i][1], frames[i][2], blur, g, np.float32(t), mode)
             assert (outs[i][j].download(np.uint8) == ref).all(), (i, j)
     batch.close()
     for c in members:
