@@ -195,6 +195,8 @@ def warp_symbol(hdr, H=2160, W=3840):
     loaded (nm -C), so that the bench line can never name a kernel the binary does not contain."""
     from hopperrender_amd import capi
     prefix = WARP_SYMBOL_PREFIX[(1 if hdr else 0, H * W > 1920 * 1088)]
+    if not hdr and H * W <= 640 * 360:          # 8-bit frames at rs = 1: two-pixel flow cells, four per 8-byte thread
+        prefix = "warp_fast_kernel<unsigned char, 2, 2, 2, 8, true>"
     try:
         return capi.kernel_symbol(prefix)
     except Exception as e:   # (no `nm` on the box: the measurement must not die for a label)
