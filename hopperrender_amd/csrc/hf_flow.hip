@@ -392,8 +392,8 @@ template <int WROWS, int LPR, int NW> constexpr size_t ystage_bytes(int rs) {
 
 // tid: thread of the workgroup, row-major over the tile (tile row tid / LPR); (wx0, cy0): first grid column / row of the tile; ref: the thread's
 // four frame-N samples.  Workgroup-uniform call (contains a barrier when NW > 1).
-template <int RS, int WROWS, int LPR, int NW, bool PACK = false, int NH = 1>
-__device__ __forceinline__ void ysads_tile_lds(uint32_t* sad, const FlowStep& a, const uint32_t* ref, int ox, int oy, int wx0, int cy0, int tid, uint32_t* stage) {
+template <int RS, int WROWS, int LPR, int NW>
+__device__ __forceinline__ void ystage_copy(const FlowStep& a, int ox, int oy, int wx0, int cy0, int tid, uint32_t* stage) {
     using Y = YRows<RS, WROWS, LPR, NW>;
     typedef __attribute__((address_space(3))) void* lds_ptr;
     const PhaseLayout& pl = a.pl;
@@ -422,6 +422,13 @@ __device__ __forceinline__ void ysads_tile_lds(uint32_t* sad, const FlowStep& a,
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);                        // vmcnt(0): this wave's rows are in LDS
     if constexpr (NW > 1) __syncthreads();
+}
+// ... and the candidates of the thread whose tile-row-major index is tid (a one-wave workgroup that walks a taller tile in rounds of 64
+// threads passes round * 64 + lane), out of the staged rows.
+template <int RS, int WROWS, int LPR, int NW, bool PACK = false, int NH = 1>
+__device__ __forceinline__ void ystage_sads(uint32_t* sad, const FlowStep& a, const uint32_t* ref, int ox, int tid, const uint32_t* stage) {
+    using Y = YRows<RS, WROWS, LPR, NW>;
+    const int ph0 = ox & (a.pl.nph - 1);
     const uint32_t sel = 0x03020c00u | (unsigned)(ph0 & 1);
     typedef __attribute__((address_space(3))) const flow_v4* lds_chunks;
     const lds_chunks mine = (lds_chunks)stage + tid;           // tile row r of a class lies LPR r chunks behind the class's row for tile row 0
@@ -440,6 +447,11 @@ __device__ __forceinline__ void ysads_tile_lds(uint32_t* sad, const FlowStep& a,
         if constexpr (NH > 1) __builtin_amdgcn_sched_barrier(0);
     });
 }
+template <int RS, int WROWS, int LPR, int NW, bool PACK = false, int NH = 1>
+__device__ __forceinline__ void ysads_tile_lds(uint32_t* sad, const FlowStep& a, const uint32_t* ref, int ox, int oy, int wx0, int cy0, int tid, uint32_t* stage) {
+    ystage_copy<RS, WROWS, LPR, NW>(a, ox, oy, wx0, cy0, tid, stage);
+    ystage_sads<RS, WROWS, LPR, NW, PACK, NH>(sad, a, ref, ox, tid, stage);
+}
 
 // The staged form applies to full tiles (R = 16) of planes with rs <= 4 whose candidate rows need no reflection.  ox, oy: the window's.
 template <int WROWS, int LPR, int NW, bool PACK = false, int NH = 1>
@@ -456,6 +468,23 @@ __device__ __forceinline__ bool ysads_tile_try(uint32_t* sad, const Geom& g, con
         default: ysads_tile_lds<4, WROWS, LPR, NW, PACK, NH>(sad, a, ref, ox, oy, wx0, cy0, tid, stage); break;
     }
     return true;
+}
+
+// (the test of ysads_tile_try alone, and the run-time rs as a compile-time constant for code that stages in its own order)
+template <int WROWS>
+__device__ __forceinline__ bool ytile_can_stage(const Geom& g, const FlowStep& a, int oy, int cy0) {
+    if (g.rs < 0 || g.rs > 4 || !a.y_rows_lds) return false;
+    return !((cy0 << g.rs) + oy + rel16(0) < 0 || ((cy0 + WROWS - 1) << g.rs) + oy + rel16(15) > g.H - 1);
+}
+template <class F>
+__device__ __forceinline__ void with_rs(int rs, F&& f) {
+    switch (rs) {
+        case 0: f(std::integral_constant<int, 0>{}); break;
+        case 1: f(std::integral_constant<int, 1>{}); break;
+        case 2: f(std::integral_constant<int, 2>{}); break;
+        case 3: f(std::integral_constant<int, 3>{}); break;
+        default: f(std::integral_constant<int, 4>{}); break;
+    }
 }
 
 // The same for 8 x 8 windows, four per wave (Map<8>: 16 lanes = one window, lane i of it = tile row i / 2, column group i & 1): every window
@@ -1125,6 +1154,151 @@ __device__ __forceinline__ void flow_level_tab_body(const Geom& g, const FlowSte
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Level 32 of a batch: ONE WAVE per 32 x 32 window
+// ------------------------------------------------------------------------------------------
+// The four-wave workgroup of flow_level_small_kernel<32> needs four free wave slots, its registers on all four SIMDs and its candidate
+// rows' LDS on one CU at the same moment.  Alone on the device that costs nothing; beside the other queues of a throughput pipeline, whose
+// kernels take every slot the moment it frees, it was the chain's most stretched launch by far (timelines of round 6: 20-25 us alone,
+// 65-185 us inside the pipelines of the 1080p workloads; the one-wave launches of levels 16 .. 2: 2 x).  Here a wave walks its window in
+// four rounds of 64 threads x 4 pixels (8 rows each): the sums of the rounds add up in the lanes' registers where the four waves exchanged
+// theirs through LDS behind a barrier -- the same integer additions in another order -- and the Y step's candidate rows are staged once per
+// window by the one wave.  A quarter of the waves, each four times as long: for batches (launch_flow_level_small), where there are enough.
+template <bool FULL, bool R16, int NH>
+__device__ __forceinline__ void flow_level32_wave_body(const Geom& g, const FlowStep& a, const TileId& tile, [[maybe_unused]] uint32_t* s_rows) {
+    using M = Map<32>;
+    const int R = R16 ? 16 : a.R;
+    const int lane = (int)threadIdx.x;
+    int lx, ly;
+    M::at(lane, lx, ly);                                       // round v: the same columns, rows ly + 8 v
+    const int tx0 = tile.tx * M::TW, ty0 = tile.ty * M::TH;    // = the window's origin (inside the grid)
+    const int cx0 = tx0 + lx;
+    const int wx = tx0 >> a.cur.log2w, wy = ty0 >> a.cur.log2w;
+    WinConst wc = load_win_const(g, a, wx, wy, false);
+    if (a.pend.active) {   // the last large-window step (Y of the previous level) is resolved here
+        const bool leader = lane == 0 && (tx0 & (a.pend.lvl.window - 1)) == 0 && (ty0 & (a.pend.lvl.window - 1)) == 0;
+        const int v = resolve_pending(g, a, tx0, ty0, lane, leader);
+        if (a.pend.axis) wc.oy = v; else wc.ox = v;
+    }
+    const int cap_cz = (R >> 1) - 1;
+    uint32_t captured = 0;
+    int off[2] = {wc.ox, wc.oy};
+#pragma unroll
+    for (int axis = 0; axis < 2; axis++) {
+        uint32_t sad[16];
+#pragma unroll
+        for (int cz = 0; cz < 16; cz++) sad[cz] = 0u;
+        bool staged = false;
+        if constexpr (FULL) if (axis == 1) {
+            staged = ytile_can_stage<32>(g, a, __builtin_amdgcn_readfirstlane(off[1]), ty0);
+            if (staged) with_rs(g.rs, [&](auto RS) { ystage_copy<decltype(RS)::value, 32, 8, 1>(a, __builtin_amdgcn_readfirstlane(off[0]), __builtin_amdgcn_readfirstlane(off[1]), tx0, ty0, lane, s_rows); });
+        }
+#pragma unroll 1
+        for (int v = 0; v < 4; v++) {
+            const Strip<4> strip = load_strip<4, FULL>(g, a, cx0, ty0 + ly + 8 * v);
+            if (staged) with_rs(g.rs, [&](auto RS) { ystage_sads<decltype(RS)::value, 32, 8, 1, false, NH>(sad, a, strip.ref, __builtin_amdgcn_readfirstlane(off[0]), v * 64 + lane, s_rows); });
+            else strip_sads<4, true, FULL, false, R16, NH>(sad, g, a, strip, off[0], off[1], axis);
+        }
+        const int first = group_reduce<64, 1>(sad, lane);
+        const int best = group_argmin<64, R16, 1>(sad, first, a, off[axis], axis ? wc.nby : wc.nbx, wc.npix, cap_cz,
+                                                  axis == 0 && a.capture_delta, captured, lane);
+        off[axis] = (int)(int16_t)(off[axis] + rel_offset(best, R));   // adjustOffsetArrayKernelSDR.h:13-19
+    }
+    HF_DBG_CHECK(wx >= 0 && wy >= 0 && wx < a.cur.nwx && wy < a.cur.nwy, 105);
+    if (lane == 0) {
+        a.cur.tx[wy * a.cur.nwx + wx] = (int16_t)off[0];
+        a.cur.ty[wy * a.cur.nwx + wx] = (int16_t)off[1];
+        if (a.capture_delta && wx == 0 && wy == 0) *a.total_delta = captured / a.delta_divisor;   // opticalFlowCalcSDR.cpp:91-94
+        if (a.still_count && off[0] == wc.ox && off[1] == wc.oy) atomicAdd(a.still_count, 1u);   // content hint (hf_calc.hip)
+    }
+}
+
+// ... with the SAD tables (full tiles at R == 16): level 32 is the chain's first table level -- it always computes, and leaves both tables.
+__device__ __forceinline__ void flow_level32_wave_tab_body(const Geom& g, const FlowStep& a, const TileId& tile, [[maybe_unused]] uint32_t* s_rows) {
+    using M = Map<32>;
+    const int lane = (int)threadIdx.x;
+    int lx, ly;
+    M::at(lane, lx, ly);
+    const int tx0 = tile.tx * M::TW, ty0 = tile.ty * M::TH;
+    const int cx0 = tx0 + lx, cy_0 = ty0 + ly;
+    const int wx = tx0 >> a.cur.log2w, wy = ty0 >> a.cur.log2w;
+    WinConst wc = load_win_const(g, a, wx, wy, false);
+    // the lane's block of round 0 (even rows keep the left block of the strip, odd rows the right one); round v lies 4 v block rows below
+    const int nblk = a.sad_nbx * a.sad_nby;
+    const int blk = (cy_0 >> 1) * a.sad_nbx + (cx0 >> 1) + (cy_0 & 1);
+    HF_DBG_CHECK(blk >= 0 && blk + 12 * a.sad_nbx < nblk, 110);
+    flow_v4* const tab0 = (flow_v4*)a.sadtab + (size_t)blk * 2;
+    const size_t tab_axis = (size_t)nblk * 2, tab_round = (size_t)a.sad_nbx * 8;
+    if (a.pend.active) {   // the last large-window step (Y of the previous level) is resolved here
+        const bool leader = lane == 0 && (tx0 & (a.pend.lvl.window - 1)) == 0 && (ty0 & (a.pend.lvl.window - 1)) == 0;
+        const int v = resolve_pending(g, a, tx0, ty0, lane, leader);
+        if (a.pend.axis) wc.oy = v; else wc.ox = v;
+    }
+    const int cap_cz = 7;
+    uint32_t captured = 0;
+    int off[2] = {wc.ox, wc.oy};
+    const uint32_t selw = (cy_0 & 1) ? 0x07060302u : 0x05040100u;
+#pragma unroll
+    for (int axis = 0; axis < 2; axis++) {
+        if (a.counters && lane == 0) atomicAdd(a.counters + kCounterLevels + 4 * (a.level_index & 15) + 2 * axis, 1u);   // diagnostics: one window, never reusing
+        flow_v4* const tab = tab0 + axis * tab_axis;
+        bool staged = false;
+        if (axis == 1) {
+            staged = ytile_can_stage<32>(g, a, __builtin_amdgcn_readfirstlane(off[1]), ty0);
+            if (staged) with_rs(g.rs, [&](auto RS) { ystage_copy<decltype(RS)::value, 32, 8, 1>(a, __builtin_amdgcn_readfirstlane(off[0]), __builtin_amdgcn_readfirstlane(off[1]), tx0, ty0, lane, s_rows); });
+        }
+        uint32_t total = 0;
+        int first = 0;
+#pragma unroll 1
+        for (int v = 0; v < 4; v++) {
+            const Strip<4> strip = load_strip<4, true>(g, a, cx0, cy_0 + 8 * v);
+            uint32_t p[16];
+#pragma unroll
+            for (int cz = 0; cz < 16; cz++) p[cz] = 0u;
+            if (staged) with_rs(g.rs, [&](auto RS) { ystage_sads<decltype(RS)::value, 32, 8, 1, true, kTabGroups>(p, a, strip.ref, __builtin_amdgcn_readfirstlane(off[0]), v * 64 + lane, s_rows); });
+            else strip_sads<4, true, true, true, true, kTabGroups>(p, g, a, strip, off[0], off[1], axis);
+            uint32_t W[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const uint32_t q0 = p[2 * j] + lane_xor<M::RM>(p[2 * j], lane);               // both rows of the two blocks: left | right << 16
+                const uint32_t q1 = p[2 * j + 1] + lane_xor<M::RM>(p[2 * j + 1], lane);
+                W[j] = __builtin_amdgcn_perm(q1, q0, selw);                                  // this lane's block: candidates 2j, 2j + 1
+            }
+            if (a.sad_write) { tab[v * tab_round] = flow_v4{W[0], W[1], W[2], W[3]}; tab[v * tab_round + 1] = flow_v4{W[4], W[5], W[6], W[7]}; }
+            uint32_t t1[1];
+            first = packed_reduce<64, 1>(W, t1, lane);
+            total += t1[0];
+        }
+        const uint32_t tot[1] = {total};
+        const int best = group_argmin<64, true, 1>(tot, first, a, off[axis], axis ? wc.nby : wc.nbx, wc.npix, cap_cz,
+                                                   axis == 0 && a.capture_delta, captured, lane);
+        off[axis] = (int)(int16_t)(off[axis] + rel_offset(best, 16));   // adjustOffsetArrayKernelSDR.h:13-19
+    }
+    HF_DBG_CHECK(wx >= 0 && wy >= 0 && wx < a.cur.nwx && wy < a.cur.nwy, 105);
+    if (lane == 0) {
+        a.cur.tx[wy * a.cur.nwx + wx] = (int16_t)off[0];
+        a.cur.ty[wy * a.cur.nwx + wx] = (int16_t)off[1];
+        if (a.still_count && off[0] == wc.ox && off[1] == wc.oy) atomicAdd(a.still_count, 1u);   // content hint (hf_calc.hip)
+        if (a.capture_delta && wx == 0 && wy == 0) *a.total_delta = captured / a.delta_divisor;   // opticalFlowCalcSDR.cpp:91-94
+    }
+}
+
+template <bool TABK>
+__global__ __launch_bounds__(64) void flow_level32_wave_kernel(const Geom g, const FlowBatchArgs batch) {
+    const TileId tile = decode_tile<1>(batch, (g.lw + 31) / 32, (g.lh + 31) / 32);
+    if (!tile.valid) return;
+    const FlowStep a = member_step(batch, tile.pair);
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_rows[];   // candidate rows of the Y step (launch_flow_level_small)
+    const bool full = a.R == 16 && (tile.tx + 1) * 32 <= g.lw && (tile.ty + 1) * 32 <= g.lh;
+    if constexpr (TABK) {      // (a.sadtab, a.R == 16 and a.sad_write)
+        if (full) flow_level32_wave_tab_body(g, a, tile, s_rows);
+        else flow_level32_wave_body<false, true, kTabGroups>(g, a, tile, s_rows);
+    }
+    else if (full) flow_level32_wave_body<true, true, 1>(g, a, tile, s_rows);
+    else if (a.R == 16) flow_level32_wave_body<false, true, 1>(g, a, tile, s_rows);
+    else flow_level32_wave_body<false, false, 1>(g, a, tile, s_rows);
+}
+
 // TABK: the launch's chain keeps SAD tables at R == 16 -- full tiles take the table body, tiles over the grid's edge the generic one, both with
 // the candidates in groups of 8 (kTabGroups).  The kernel's register allocation is that of its fattest body, so the launches without tables
 // (16 candidates in flight everywhere) are instantiations of their own.
@@ -1337,6 +1511,10 @@ void launch_prep_frame(const Geom& g, const PhaseLayout& pl, const void* frame, 
 // Batches up to this size run the two finest levels with one row per lane (MapRow).  Chain alone, us per batched chain with a block /
 // a row per lane: 1 pair 79.5 / 71.3, 2 pairs 94.6 / 86.8, 4 pairs 122.4 / 119.2, 8 pairs 169.3 / 173.8.
 constexpr int kRowPerLaneMaxBatch = 4;
+#ifndef HF_LEVEL32_ONE_WAVE_MIN_BATCH
+#define HF_LEVEL32_ONE_WAVE_MIN_BATCH 4
+#endif
+constexpr int kLevel32OneWaveMinBatch = HF_LEVEL32_ONE_WAVE_MIN_BATCH;   // batches from this size on: level 32 as one wave per window
 void launch_flow_level_small(const Geom& g, const FlowBatch& b, hipStream_t stream) {
     const int ws = b.s[0].cur.window;
     const bool rows1 = b.n <= kRowPerLaneMaxBatch && ws <= 4;
@@ -1356,7 +1534,16 @@ void launch_flow_level_small(const Geom& g, const FlowBatch& b, hipStream_t stre
         else HF_LAUNCH(NAME, (flow_level_small_kernel<WS_, SPLIT_, ROWS1_, false>), GRID, BLOCK, LDS, stream, g, kb);                    \
     } while (0)
     switch (ws) {
-        case 32: HF_LEVEL("level_32", 32, false, false, grd, dim3(256), lds); break;
+        case 32:
+            if (b.n >= kLevel32OneWaveMinBatch) {      // one wave per window (flow_level32_wave_kernel)
+                const size_t lds1 = b.s[0].R != 16 ? 0 : ystage_bytes<32, 8, 1>(g.rs);
+                kb.common.y_rows_lds = lds1 != 0;
+                if (tabk) HF_LAUNCH("level_32", (flow_level32_wave_kernel<true>), grd, dim3(64), lds1, stream, g, kb);
+                else HF_LAUNCH("level_32", (flow_level32_wave_kernel<false>), grd, dim3(64), lds1, stream, g, kb);
+                break;
+            }
+            HF_LEVEL("level_32", 32, false, false, grd, dim3(256), lds);
+            break;
         case 16: HF_LEVEL("level_16", 16, true, false, split(Map<16>::WAVES), dim3(64), lds); break;
         case 8: HF_LEVEL("level_8", 8, true, false, split(Map<8>::WAVES), dim3(64), lds); break;
         case 4:

@@ -5,7 +5,7 @@ import collections, csv, re, statistics, sys
 
 rows = []
 for r in csv.DictReader(open(sys.argv[1])):
-    m = re.search(r"(warp_wg_kernel|flow_big_partial_kernel|flow_level_small_kernel<\d+|blur_flow_kernel)", r["Kernel_Name"])
+    m = re.search(r"(warp_wg_kernel|flow_big_partial_kernel|flow_level32_wave_kernel|flow_level_small_kernel<\d+|blur_flow_kernel)", r["Kernel_Name"])
     if m:
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), m.group(1), int(r["Queue_Id"]), int(r["Grid_Size_X"])))
 rows.sort()
@@ -24,7 +24,7 @@ def beside(s, e, q):
     return sum(min(e, we) - max(s, ws) for ws, we, wq in warps if we > s and ws < e and wq != q) / (e - s)
 
 
-for name in ("flow_big_partial_kernel", "flow_level_small_kernel<32", "flow_level_small_kernel<16", "flow_level_small_kernel<8",
+for name in ("flow_big_partial_kernel", "flow_level32_wave_kernel", "flow_level_small_kernel<32", "flow_level_small_kernel<16", "flow_level_small_kernel<8",
              "flow_level_small_kernel<4", "flow_level_small_kernel<2"):
     ks = [r for r in sel if r[2] == name and r[4] > 20000][:3000]     # batched launches only
     f = [(beside(s, e, q), (e - s) / 1e3) for s, e, _, q, _ in ks]

@@ -11,7 +11,7 @@ import statistics
 import sys
 
 LABEL = (("warp_wg_kernel", "warp_period"), ("warp_fast_kernel", "warp_period"), ("prep_grid_kernel", "grid_samples"), ("prep_phase_fast_kernel", "plane"),
-         ("flow_big_partial_kernel", "large_windows"), ("flow_level_small_kernel<32", "level_32"), ("flow_level_small_kernel<16", "level_16"),
+         ("flow_big_partial_kernel", "large_windows"), ("flow_level_small_kernel<32", "level_32"), ("flow_level32_wave_kernel", "level_32"), ("flow_level_small_kernel<16", "level_16"),
          ("flow_level_small_kernel<8", "level_8"), ("flow_level_small_kernel<4", "level_4"), ("flow_level_small_kernel<2", "level_2"), ("blur_flow_kernel", "blur"))
 
 
