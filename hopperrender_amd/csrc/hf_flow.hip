@@ -1559,18 +1559,18 @@ void launch_flow_level_small(const Geom& g, const FlowBatch& b, hipStream_t stre
 }
 
 // Waves per workgroup.  A chain alone (2160p HDR, 16 pairs): 4 waves 214 us, 1 wave 224 us (more atomics, and the Y launch's candidate rows
-// come out of L2 instead of LDS).  Inside the pipeline the 1080p workloads -- whose warp launches are short and leave the chain the larger
-// share of every queue -- are 2.3 % faster with one-wave workgroups (other queues' kernels hold most of every CU; a single wave finds room
-// sooner, and the warp beside it got 8 % shorter), the 2160p ones (rs = 3) 2 % slower and 360p (rs = 1) 1.5 % slower: a throughput driver's
-// batches at rs = 2 take one wave.  (Measured, round 6; a 16 x 16 one-wave Y tile with staged rows was no better than the plain one.)
+// come out of L2 instead of LDS).  Inside a throughput pipeline the other queues' kernels hold most of every CU and a single wave finds
+// room sooner: same-box A-B with one-wave workgroups 1080p SDR + 1.4-3 %, 2160p SDR + 2.5 %, 64 pairs + 0.9 %, 1080p HDR + 0.3 %, 2160p HDR
+// (bandwidth-bound) +- 0; 360p (rs = 1) - 1.5 %.  A throughput driver's batches at rs >= 2 take one wave.  (Measured, round 6; before level 32
+// became a one-wave launch too, 2160p HDR lost 2 % with them; a 16 x 16 one-wave Y tile with staged rows was no better than the plain one.)
 #ifndef HF_BIG_ONE_WAVE_MIN_BATCH
 #define HF_BIG_ONE_WAVE_MIN_BATCH 4
 #endif
-constexpr int kBigWavesPerBlock = 4, kBigOneWaveMinBatch = HF_BIG_ONE_WAVE_MIN_BATCH, kBigOneWaveRs = 2;
+constexpr int kBigWavesPerBlock = 4, kBigOneWaveMinBatch = HF_BIG_ONE_WAVE_MIN_BATCH, kBigOneWaveMinRs = 2;
 void launch_flow_big_partial(const Geom& g, const FlowBatch& b, hipStream_t stream) {
     const bool y = b.s[0].axis == 1;
     const char* name = y ? "large_windows_y" : "large_windows_x";
-    const int wpb = b.n >= kBigOneWaveMinBatch && g.rs == kBigOneWaveRs ? 1 : kBigWavesPerBlock;
+    const int wpb = b.n >= kBigOneWaveMinBatch && g.rs >= kBigOneWaveMinRs ? 1 : kBigWavesPerBlock;
     const int tiles_x = (g.lw + 63) / 64, tiles_y = (g.lh + 4 * wpb - 1) / (4 * wpb);
     const dim3 grd(xcd_grid(tiles_x, tiles_y, 1, b.n));
     const size_t lds = y && b.s[0].R == 16 && wpb == 4 ? ystage_bytes<16, 16, 4>(g.rs) : 0;   // Y launches: candidate rows
