@@ -149,9 +149,76 @@ __global__ __launch_bounds__(256) void blur_flow_kernel(const BlurBatch batch, i
             return;
         }
     }
-    const int T = TS + 2 * r;                     // tile edge
-    uint32_t* tile = (uint32_t*)smem;             // [T][T] packed offsets
-    int* hx = (int*)(tile + T * T);               // [T][TS] horizontal sums of x
+    if constexpr (TS == 32 && RFIX == 0) {
+        // The window-sum form at a run-time EVEN radius (launch_blur_flow starts this instantiation only where it applies: a chain that ended
+        // at 2 x 2 windows on a grid of even size): the 2r taps of an output are r whole windows for even X, half + (r - 1) + half for odd X, so
+        // with S_r[i] = v[i] + .. + v[i + r - 1] over WINDOWS the row sum is S_r[a] + S_r[a + (X & 1)], a = (X - r - (X & 1)) / 2, and the
+        // 2r x 2r sum four reads of the r x r window sums.  (16 + r)^2 gathered offsets per 32 x 32 outputs (radius 32: 2.25 per output where
+        // the pixel form gathers 25), running sums along rows and columns, 18 KB of LDS instead of 36: BASELINE config 5's blur.
+        const int X0 = blockIdx.x * 32, Y0 = blockIdx.y * 32;
+        const int NW = 16 + r;                                // windows per tile edge
+        constexpr int NS = 17;                                // S_r / window-sum values per edge
+        uint32_t* v = (uint32_t*)smem;                        // [NW][NW] packed offsets
+        int* hsx = (int*)(v + NW * NW);                       // [NW][NS] horizontal r-window sums
+        int* hsy = hsx + NW * NS;
+        int* wx = hsy + NW * NS;                              // [NS][NS] r x r window sums
+        int* wy = wx + NS * NS;
+        const int tid = threadIdx.x;
+        const int wa0 = X0 / 2 - r / 2, wb0 = Y0 / 2 - r / 2;
+        HF_DBG_CHECK(L.tx && L.ty && L.log2w == 1 && !(r & 1) && L.nwx * 2 == lw && L.nwy * 2 == lh, 215);
+        for (int i = tid; i < NW * NW; i += 256) {
+            const int j = i / NW, k = i - j * NW;
+            int wa = wa0 + k, wb = wb0 + j;
+            wa = wa < 0 ? -1 - wa : wa >= L.nwx ? 2 * L.nwx - 1 - wa : wa;
+            wb = wb < 0 ? -1 - wb : wb >= L.nwy ? 2 * L.nwy - 1 - wb : wb;
+            const int w = wb * L.nwx + wa;
+            HF_DBG_CHECK(wb >= 0 && wb < L.nwy && wa >= 0 && wa < L.nwx, 201);
+            v[i] = (uint32_t)(uint16_t)L.tx[w] | ((uint32_t)(uint16_t)L.ty[w] << 16);
+        }
+        __syncthreads();
+        for (int row = tid; row < NW; row += 256) {           // a lane walks a row with a running sum of r windows
+            const uint32_t* p = v + row * NW;
+            int sx = 0, sy = 0;
+            for (int t = 0; t < r; t++) { const uint32_t w = p[t]; sx += (int)(int16_t)(w & 0xFFFFu); sy += (int)w >> 16; }
+            hsx[row * NS] = sx; hsy[row * NS] = sy;
+            for (int k = 1; k < NS; k++) {
+                const uint32_t win = p[k + r - 1], wout = p[k - 1];
+                sx += (int)(int16_t)(win & 0xFFFFu) - (int)(int16_t)(wout & 0xFFFFu);
+                sy += ((int)win >> 16) - ((int)wout >> 16);
+                hsx[row * NS + k] = sx; hsy[row * NS + k] = sy;
+            }
+        }
+        __syncthreads();
+        for (int col = tid; col < 2 * NS; col += 256) {       // ... and a column of the row sums (x and y: a lane each)
+            const int* h = col < NS ? hsx + col : hsy + col - NS;
+            int* o = col < NS ? wx + col : wy + col - NS;
+            int sum = 0;
+            for (int t = 0; t < r; t++) sum += h[t * NS];
+            o[0] = sum;
+            for (int j = 1; j < NS; j++) { sum += h[(j + r - 1) * NS] - h[(j - 1) * NS]; o[j * NS] = sum; }
+        }
+        __syncthreads();
+        const int d = 4 * r * r, log2d = (r & (r - 1)) == 0 ? 2 + 2 * (31 - __builtin_clz(r)) : -1;
+        const int tx = tid & 31, ty = tid >> 5;               // 32 x 8 threads, four output rows each
+        const int ax = (tx - (tx & 1)) / 2, dx = tx & 1;      // (X0 is even: the parity of X is tx's)
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+            const int cy = ty + 8 * o, ay = (cy - (cy & 1)) / 2, dy = cy & 1;
+            const int i00 = ay * NS + ax, i01 = i00 + dx, i10 = i00 + dy * NS, i11 = i10 + dx;
+            const int sx = wx[i00] + wx[i01] + wx[i10] + wx[i11], sy = wy[i00] + wy[i01] + wy[i10] + wy[i11];
+            const int rx = (int)(int16_t)div_trunc(sx, d, log2d), ry = (int)(int16_t)div_trunc(sy, d, log2d);
+            if (X0 + tx < lw && Y0 + cy < lh) {
+                const size_t q = (size_t)(Y0 + cy) * lw + X0 + tx;
+                blurred[q] = (int16_t)rx;
+                blurred[(size_t)lw * lh + q] = (int16_t)ry;
+                packed[q] = ((uint32_t)rx & 0xFFFFu) | ((uint32_t)ry << 16);
+            }
+        }
+        return;
+    }
+    const int T = TS + 2 * r, TP = T + 1;         // tile edge; row pitch (odd: the row-per-lane pass below walks the banks)
+    uint32_t* tile = (uint32_t*)smem;             // [T][TP] packed offsets
+    int* hx = (int*)(tile + T * TP);              // [T][TS] horizontal sums of x
     int* hy = hx + T * TS;                        // [T][TS] ... of y
     const int tid = threadIdx.x;
     const int tx = tid & 15, ty = tid >> 4;
@@ -160,23 +227,44 @@ __global__ __launch_bounds__(256) void blur_flow_kernel(const BlurBatch batch, i
         const int wrow = (mirror_flow(y0 + py, lh) >> L.log2w) * L.nwx;
         for (int px = tx; px < T; px += 16) {
             const int w = wrow + (mirror_flow(x0 + px, lw) >> L.log2w);
-            HF_DBG_CHECK(w >= 0 && w < L.nwx * L.nwy && py * T + px < T * T, 200);
+            HF_DBG_CHECK(w >= 0 && w < L.nwx * L.nwy && py * TP + px < T * TP, 200);
             const uint32_t ox = L.tx ? (uint32_t)(uint16_t)L.tx[w] : 0u, oy = L.ty ? (uint32_t)(uint16_t)L.ty[w] : 0u;
-            tile[py * T + px] = ox | (oy << 16);
+            tile[py * TP + px] = ox | (oy << 16);
         }
     }
     __syncthreads();
-    for (int idx = tid; idx < T * TS; idx += 256) {   // taps -r .. r-1 (blurFlowKernelSDR.h:82-83)
-        const int row = idx / TS, col = idx - row * TS;    // (TS is a power of two)
-        const uint32_t* p = tile + row * T + col;
-        int sx = 0, sy = 0;
+    if constexpr (RFIX) {
+        for (int idx = tid; idx < T * TS; idx += 256) {   // taps -r .. r-1 (blurFlowKernelSDR.h:82-83)
+            const int row = idx / TS, col = idx - row * TS;    // (TS is a power of two)
+            const uint32_t* p = tile + row * TP + col;
+            int sx = 0, sy = 0;
 #pragma unroll
-        for (int k = 0; k < (RFIX ? 2 * RFIX : 1); k++) {
-            if (RFIX) { const uint32_t w = p[k]; sx += (int)(int16_t)(w & 0xFFFFu); sy += (int)w >> 16; }
+            for (int k = 0; k < 2 * RFIX; k++) { const uint32_t w = p[k]; sx += (int)(int16_t)(w & 0xFFFFu); sy += (int)w >> 16; }
+            hx[idx] = sx;
+            hy[idx] = sy;
         }
-        if (!RFIX) for (int k = 0; k < 2 * r; k++) { const uint32_t w = p[k]; sx += (int)(int16_t)(w & 0xFFFFu); sy += (int)w >> 16; }
-        hx[idx] = sx;
-        hy[idx] = sy;
+    } else {
+        // Run-time radius: a lane walks HALF A ROW with a running sum -- 2r taps for the first output, then one tap in and one out per
+        // output -- instead of 2r taps for every output (radius 32: 78 tap reads per 8 outputs where the tap loops read 512; the launch
+        // was bound by the unpack-and-add of those taps: 104 us per 12 pairs alone, 365 us inside the pipeline of BASELINE config 5).
+        // The same integers: sums of int16 offsets in 32 bits, whatever the order.
+        constexpr int HALF = TS / 2;
+        for (int task = tid; task < 2 * T; task += 256) {
+            const int row = task >> 1, c0 = (task & 1) * HALF;
+            const uint32_t* p = tile + row * TP + c0;
+            int sx = 0, sy = 0;
+            for (int k = 0; k < 2 * r; k++) { const uint32_t w = p[k]; sx += (int)(int16_t)(w & 0xFFFFu); sy += (int)w >> 16; }
+            hx[row * TS + c0] = sx;
+            hy[row * TS + c0] = sy;
+#pragma unroll
+            for (int c = 1; c < HALF; c++) {
+                const uint32_t win = p[c + 2 * r - 1], wout = p[c - 1];
+                sx += (int)(int16_t)(win & 0xFFFFu) - (int)(int16_t)(wout & 0xFFFFu);
+                sy += ((int)win >> 16) - ((int)wout >> 16);
+                hx[row * TS + c0 + c] = sx;
+                hy[row * TS + c0 + c] = sy;
+            }
+        }
     }
     __syncthreads();
     const int d = 4 * r * r, log2d = (r & (r - 1)) == 0 ? 2 + 2 * (31 - __builtin_clz(r)) : -1;
@@ -1349,13 +1437,20 @@ void launch_blur_flow(const Geom& g, const BlurBatch& b, int radius, int zero_co
                                                      // pair is faster with four times the workgroups: 4.3 vs 6.0 us)
         const dim3 grd((g.lw + 31) / 32, (g.lh + 31) / 32, b.n);
         const int T = 32 + 8;
-        const size_t smem = (size_t)T * T * sizeof(uint32_t) + 2 * (size_t)T * 32 * sizeof(int);   // 16.6 KB
+        const size_t smem = (size_t)T * (T + 1) * sizeof(uint32_t) + 2 * (size_t)T * 32 * sizeof(int);   // 16.8 KB (odd row pitch, see the kernel)
         HF_LAUNCH("blur", (blur_flow_kernel<32, 4>), grd, dim3(256), smem, stream, b, g.lw, g.lh, radius, zero_count);
+        return;
+    }
+    if (window_sums && radius >= 2 && radius <= 64 && !(radius & 1)) {   // any even radius in the window-sum form (blur_flow_kernel<32, 0>)
+        const dim3 grd((g.lw + 31) / 32, (g.lh + 31) / 32, b.n);
+        const int nw = 16 + radius;
+        const size_t smem = (size_t)nw * nw * sizeof(uint32_t) + 2 * (size_t)nw * 17 * sizeof(int) + 2 * 17 * 17 * sizeof(int);   // 18 KB at radius 32, 39 KB at 64
+        HF_LAUNCH("blur", (blur_flow_kernel<32, 0>), grd, dim3(256), smem, stream, b, g.lw, g.lh, radius, zero_count);
         return;
     }
     const dim3 grd((g.lw + 15) / 16, (g.lh + 15) / 16, b.n);
     const int T = 16 + 2 * radius;
-    const size_t smem = (size_t)T * T * sizeof(uint32_t) + 2 * (size_t)T * 16 * sizeof(int);
+    const size_t smem = (size_t)T * (T + 1) * sizeof(uint32_t) + 2 * (size_t)T * 16 * sizeof(int);
     if (smem > 48 * 1024)     // large radii (up to 64: 101 KB of the CU's 160 KB LDS) need the opt-in; the attribute is per device
         (void)hipFuncSetAttribute((const void*)blur_flow_kernel<16, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     HF_LAUNCH("blur", (blur_flow_kernel<16, 0>), grd, dim3(256), smem, stream, b, g.lw, g.lh, radius, zero_count);

@@ -82,6 +82,10 @@ def test_eager_and_graph_paths_agree(native_lib):
     (0, 360, 640, 0, 0, 16, 3, 4),     # BASELINE config 1: 640x360 SDR, 3-level
     (1, 360, 640, 0, 0, 16, 0, 16),    # blur radius extension (BASELINE config 5)
     (0, 270, 480, 0, 0, 13, 0, 32),
+    (0, 270, 480, 0, 0, 16, 0, 64),    # the largest radius: window-sum form (even radii), 80 x 80 windows per tile
+    (1, 180, 320, 0, 0, 16, 0, 2),     # the smallest even radius
+    (0, 270, 480, 0, 0, 9, 0, 7),      # odd radius: pixel form with running row sums
+    (0, 270, 482, 0, 0, 16, 0, 12),    # grid of odd width (241): pixel form at an even radius
     (0, 1090, 1922, 1984, 1936, 16, 0, 4),  # ragged 1080p-class, rs=3
     (0, 1080, 1920, 0, 0, 16, 0, 4),        # BASELINE config 2 geometry
     (1, 2160, 3840, 0, 0, 16, 0, 4),        # BASELINE config 3 geometry
