@@ -72,7 +72,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s mea
 WARP_SYMBOL_PREFIX = {(1, True): "warp_wg_kernel<unsigned short, 2,", (0, False): "warp_fast_kernel<unsigned char, 4, 2, 2, 8, true>",
                       (0, True): "warp_fast_kernel<unsigned char, 8, 2, 2, 16, true>", (1, False): "warp_fast_kernel<unsigned short, 4, 2, 2, 16, true>"}
 # the other BASELINE configs, run as short legs behind the timed region of the default workload (fresh child processes, never `value`)
-OTHER_WORKLOADS = {"sdr1080_24to60": 24, "sdr1080_64pairs": 24, "hdr2160_nb10_blur32": 8, "hdr1080_24to120": 12, "sdr2160_24to60": 8}   # name: steps (about 1 s timed each)
+OTHER_WORKLOADS = {"sdr1080_24to60": 24, "sdr1080_64pairs": 24, "hdr2160_nb10_blur32": 8, "hdr1080_24to120": 12, "sdr2160_24to60": 8,
+                   "sdr360_24to60": 64}   # name: steps (about 1 s timed each); 360p = the size of BASELINE config 1 (the reference's CPU-runnable case)
 # Content classes (hopperrender_amd/synth.py ContentScene; SURVEY.md 8(d) "extra cases"): the reference's cost does not depend on the pixels,
 # this build's does (staged-warp window fit, SAD reuse, gather coherence), so the line says what content it ran on and what the others cost
 CONTENT_LEGS = {"hdr2160_24to120": 6, "sdr1080_24to60": 16}                                   # workload: steps of each scene's leg
@@ -374,7 +375,7 @@ def other_workloads(a, budget_s=200.0):
                          "frac_compulsory": roof.get("frac_compulsory"),
                          "ms_per_flow_calc": d["ms_per_flow_calc"], "timed_region_s": d["timed_region_s"], "steps": d["steps"],
                          "pair_streams": d["config"]["pair_streams_total"], "flow_batch": d["config"]["flow_batch"],
-                         "kernel": roof["kernel"], "bytes_per_output_frame": roof["traffic_pipeline"]["hbm_bytes_per_output_frame"]}
+                         "kernel": roof["kernel"], "bytes_per_output_frame": (roof.get("traffic_pipeline") or {}).get("hbm_bytes_per_output_frame")}   # (None: no PMC record of this workload)
         except Exception as e:
             res[name] = {"error": repr(e)[:300]}
             failed.append(name)

@@ -89,11 +89,12 @@ def test_eight_ranks_share_config_4_on_one_gpu():
 
 def test_default_line_carries_the_other_baseline_configs():
     """The driver sees ONE bench line: behind the timed region of the default workload bench.py runs ~1 s legs of BASELINE configs 2, 4
-    and 5 in child processes and reports them under other_workloads (never part of `value`)."""
+    and 5, of the two sizes round 6 added and of config 1's frame size in child processes and reports them under other_workloads (never
+    part of `value`)."""
     d = run_bench(["--no-profile"], 1, "hdr2160_24to120")
     o = dict(d["other_workloads"])
     assert o.pop("failed") == []          # a leg that fails (or does not fit the legs' shared deadline) is named at the top, not hidden in its entry
-    assert set(o) == {"sdr1080_24to60", "sdr1080_64pairs", "hdr2160_nb10_blur32", "hdr1080_24to120", "sdr2160_24to60"}
+    assert set(o) == {"sdr1080_24to60", "sdr1080_64pairs", "hdr2160_nb10_blur32", "hdr1080_24to120", "sdr2160_24to60", "sdr360_24to60"}
     for name, w in o.items():
         assert "error" not in w, (name, w)
         assert w["value"] > 0 and 0 < w["frac"] < 1 and w["frac_algorithmic"] > 0 and w["timed_region_s"] > 0.3, (name, w)
